@@ -1,0 +1,286 @@
+"""ctypes front-end of the CPU oracle (oracle/ngp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by raw_ngp_amd/.  Every function takes and
+returns numpy arrays and mirrors the argument order of the reference's `_backend`
+functions so that parity tests read like calls into the reference.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libngp_oracle.so")
+
+c_f = ctypes.c_float
+c_u = ctypes.c_uint32
+c_i = ctypes.c_int
+P = ctypes.c_void_p
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds)."""
+    src = os.path.join(_HERE, "ngp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libngp_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(P)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+# ----------------------------------------------------------------------------- grid
+
+def grid_resolutions(S, H, L):
+    res = np.zeros(L, dtype=np.uint32)
+    lib().orc_grid_resolutions(c_f(S), c_u(H), c_u(L), _p(res))
+    return res
+
+
+def grid_offsets(input_dim=3, num_levels=16, level_dim=2, per_level_scale=2.0, base_resolution=16,
+                 log2_hashmap_size=19, desired_resolution=None):
+    """Restates gridencoder/grid.py:106-134 (float64 numpy, as the reference does)."""
+    if desired_resolution is not None:
+        per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+    max_params = 2 ** log2_hashmap_size
+    offsets, offset = [], 0
+    for i in range(num_levels):
+        resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+        n = min(max_params, resolution ** input_dim)
+        n = int(np.ceil(n / 8) * 8)
+        offsets.append(offset)
+        offset += n
+    offsets.append(offset)
+    return np.array(offsets, dtype=np.int32), float(per_level_scale)
+
+
+def grid_encode_forward(inputs, embeddings, offsets, B, D, C, L, max_level, S, H, want_dy_dx=False,
+                        gridtype=0, align_corners=False, interp=0):
+    inputs, embeddings, offsets = _f32(inputs), _f32(embeddings), _i32(offsets)
+    outputs = np.zeros((L, B, C), dtype=np.float32)
+    dy_dx = np.zeros((B, L * D * C), dtype=np.float32) if want_dy_dx else None
+    lib().orc_grid_encode_forward(_p(inputs), _p(embeddings), _p(offsets), _p(outputs), c_u(B), c_u(D),
+                                  c_u(C), c_u(L), c_u(max_level), c_f(S), c_u(H), _p(dy_dx),
+                                  c_u(gridtype), c_i(int(align_corners)), c_u(interp))
+    return outputs, dy_dx
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets, B, D, C, L, max_level, S, H, dy_dx=None,
+                         gridtype=0, align_corners=False, interp=0):
+    grad, inputs, embeddings, offsets = _f32(grad), _f32(inputs), _f32(embeddings), _i32(offsets)
+    dy_dx = _f32(dy_dx)
+    grad_emb = np.zeros_like(embeddings)
+    grad_in = np.zeros((B, D), dtype=np.float32) if dy_dx is not None else None
+    lib().orc_grid_encode_backward(_p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(grad_emb),
+                                   c_u(B), c_u(D), c_u(C), c_u(L), c_u(max_level), c_f(S), c_u(H),
+                                   _p(dy_dx), _p(grad_in), c_u(gridtype), c_i(int(align_corners)),
+                                   c_u(interp))
+    return grad_emb, grad_in
+
+
+def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype=0,
+                         align_corners=False):
+    inputs, embeddings, offsets = _f32(inputs), _f32(embeddings), _i32(offsets)
+    grad = _f32(grad).copy()
+    lib().orc_grad_total_variation(_p(inputs), _p(embeddings), _p(grad), _p(offsets), c_f(weight),
+                                   c_u(B), c_u(D), c_u(C), c_u(L), c_f(S), c_u(H), c_u(gridtype),
+                                   c_i(int(align_corners)))
+    return grad
+
+
+def grad_weight_decay(embeddings, grad, offsets, weight, B, C, L):
+    embeddings, offsets = _f32(embeddings), _i32(offsets)
+    grad = _f32(grad).copy()
+    lib().orc_grad_weight_decay(_p(embeddings), _p(grad), _p(offsets), c_f(weight), c_u(B), c_u(C), c_u(L))
+    return grad
+
+
+# ----------------------------------------------------------------------------- sh / freq
+
+def sh_encode_forward(inputs, B, D, degree, want_dy_dx=False):
+    inputs = _f32(inputs)
+    out = np.zeros((B, degree * degree), dtype=np.float32)
+    dy_dx = np.zeros((B, D * degree * degree), dtype=np.float32) if want_dy_dx else None
+    lib().orc_sh_encode_forward(_p(inputs), _p(out), c_u(B), c_u(D), c_u(degree), _p(dy_dx))
+    return out, dy_dx
+
+
+def sh_encode_backward(grad, inputs, B, D, degree, dy_dx):
+    grad, inputs, dy_dx = _f32(grad), _f32(inputs), _f32(dy_dx)
+    gi = np.zeros((B, D), dtype=np.float32)
+    lib().orc_sh_encode_backward(_p(grad), _p(inputs), c_u(B), c_u(D), c_u(degree), _p(dy_dx), _p(gi))
+    return gi
+
+
+def freq_encode_forward(inputs, B, D, deg, C):
+    inputs = _f32(inputs)
+    out = np.zeros((B, C), dtype=np.float32)
+    lib().orc_freq_encode_forward(_p(inputs), c_u(B), c_u(D), c_u(deg), c_u(C), _p(out))
+    return out
+
+
+def freq_encode_backward(grad, outputs, B, D, deg, C):
+    grad, outputs = _f32(grad), _f32(outputs)
+    gi = np.zeros((B, D), dtype=np.float32)
+    lib().orc_freq_encode_backward(_p(grad), _p(outputs), c_u(B), c_u(D), c_u(deg), c_u(C), _p(gi))
+    return gi
+
+
+# ----------------------------------------------------------------------------- raymarching
+
+def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near):
+    rays_o, rays_d, aabb = _f32(rays_o), _f32(rays_d), _f32(aabb)
+    nears = np.zeros(N, dtype=np.float32)
+    fars = np.zeros(N, dtype=np.float32)
+    lib().orc_near_far_from_aabb(_p(rays_o), _p(rays_d), _p(aabb), c_u(N), c_f(min_near), _p(nears), _p(fars))
+    return nears, fars
+
+
+def sph_from_ray(rays_o, rays_d, radius, N):
+    rays_o, rays_d = _f32(rays_o), _f32(rays_d)
+    coords = np.zeros((N, 2), dtype=np.float32)
+    lib().orc_sph_from_ray(_p(rays_o), _p(rays_d), c_f(radius), c_u(N), _p(coords))
+    return coords
+
+
+def morton3D(coords):
+    coords = _i32(coords)
+    N = coords.shape[0]
+    out = np.zeros(N, dtype=np.int32)
+    lib().orc_morton3D(_p(coords), c_u(N), _p(out))
+    return out
+
+
+def morton3D_invert(indices):
+    indices = _i32(indices)
+    N = indices.shape[0]
+    out = np.zeros((N, 3), dtype=np.int32)
+    lib().orc_morton3D_invert(_p(indices), c_u(N), _p(out))
+    return out
+
+
+def packbits(grid, thresh):
+    grid = _f32(grid)
+    N = grid.size // 8
+    out = np.zeros(N, dtype=np.uint8)
+    lib().orc_packbits(_p(grid), c_u(N), c_f(thresh), _p(out))
+    return out
+
+
+def flatten_rays(rays, M):
+    rays = _i32(rays)
+    N = rays.shape[0]
+    out = np.zeros(M, dtype=np.int32)
+    lib().orc_flatten_rays(_p(rays), c_u(N), c_u(M), _p(out))
+    return out
+
+
+def march_rays_train(rays_o, rays_d, rays_ldir, grid, bound, contract, dt_gamma, max_steps, C, H, nears,
+                     fars, noises):
+    """Both passes of raymarching.py:292-317; returns xyzs, dirs, ts, rays, ldirs, M."""
+    rays_o, rays_d, nears, fars, noises = map(_f32, (rays_o, rays_d, nears, fars, noises))
+    rays_ldir = _f32(rays_ldir)
+    grid = np.ascontiguousarray(grid, dtype=np.uint8)
+    N = rays_o.shape[0]
+    rays = np.zeros((N, 2), dtype=np.int32)
+    counter = np.zeros(1, dtype=np.int32)
+    args = (_p(rays_o), _p(rays_d), _p(rays_ldir), _p(grid), c_f(bound), c_i(int(contract)), c_f(dt_gamma),
+            c_u(max_steps), c_u(N), c_u(C), c_u(H), _p(nears), _p(fars))
+    lib().orc_march_rays_train(*args, None, None, None, None, _p(rays), _p(counter), _p(noises))
+    M = int(counter[0])
+    xyzs = np.zeros((M, 3), dtype=np.float32)
+    dirs = np.zeros((M, 3), dtype=np.float32)
+    ts = np.zeros((M, 2), dtype=np.float32)
+    ldirs = np.zeros((M, 3), dtype=np.float32) if rays_ldir is not None else None
+    lib().orc_march_rays_train(*args, _p(xyzs), _p(dirs), _p(ts), _p(ldirs), _p(rays), _p(counter), _p(noises))
+    return xyzs, dirs, ts, rays, ldirs, M
+
+
+def composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh):
+    sigmas, rgbs, ts, rays = _f32(sigmas), _f32(rgbs), _f32(ts), _i32(rays)
+    weights = np.zeros(M, dtype=np.float32)
+    ws = np.zeros(N, dtype=np.float32)
+    depth = np.zeros(N, dtype=np.float32)
+    image = np.zeros((N, 3), dtype=np.float32)
+    lib().orc_composite_rays_train_forward(_p(sigmas), _p(rgbs), _p(ts), _p(rays), c_u(M), c_u(N),
+                                           c_f(T_thresh), _p(weights), _p(ws), _p(depth), _p(image))
+    return weights, ws, depth, image
+
+
+def composite_rays_train_backward(grad_weights, grad_ws, grad_depth, grad_image, sigmas, rgbs, ts, rays,
+                                  weights_sum, depth, image, M, N, T_thresh):
+    a = [_f32(x) for x in (grad_weights, grad_ws, grad_depth, grad_image, sigmas, rgbs, ts)]
+    rays = _i32(rays)
+    b = [_f32(x) for x in (weights_sum, depth, image)]
+    gs = np.zeros(M, dtype=np.float32)
+    gc = np.zeros((M, 3), dtype=np.float32)
+    lib().orc_composite_rays_train_backward(*[_p(x) for x in a], _p(rays), *[_p(x) for x in b], c_u(M),
+                                            c_u(N), c_f(T_thresh), _p(gs), _p(gc))
+    return gs, gc
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, contract, dt_gamma, max_steps,
+               C, H, grid, nears, fars, noises):
+    rays_alive = _i32(rays_alive)
+    rays_t, rays_o, rays_d, nears, fars, noises = map(_f32, (rays_t, rays_o, rays_d, nears, fars, noises))
+    grid = np.ascontiguousarray(grid, dtype=np.uint8)
+    M = n_alive * n_step
+    xyzs = np.zeros((M, 3), dtype=np.float32)
+    dirs = np.zeros((M, 3), dtype=np.float32)
+    ts = np.zeros((M, 2), dtype=np.float32)
+    lib().orc_march_rays(c_u(n_alive), c_u(n_step), _p(rays_alive), _p(rays_t), _p(rays_o), _p(rays_d),
+                         c_f(bound), c_i(int(contract)), c_f(dt_gamma), c_u(max_steps), c_u(C), c_u(H),
+                         _p(grid), _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(ts), _p(noises))
+    return xyzs, dirs, ts
+
+
+def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, ts, weights_sum, depth, image):
+    """In-place on rays_alive, rays_t, weights_sum, depth, image (must be contiguous numpy arrays of
+    int32 / float32), like raymarching.py:447-468."""
+    sigmas, rgbs, ts = _f32(sigmas), _f32(rgbs), _f32(ts)
+    for a, dt in ((rays_alive, np.int32), (rays_t, np.float32), (weights_sum, np.float32),
+                  (depth, np.float32), (image, np.float32)):
+        assert a.dtype == dt and a.flags["C_CONTIGUOUS"]
+    lib().orc_composite_rays(c_u(n_alive), c_u(n_step), c_f(T_thresh), _p(rays_alive), _p(rays_t), _p(sigmas),
+                             _p(rgbs), _p(ts), _p(weights_sum), _p(depth), _p(image))
+
+
+def march_rays_train_backward(grad_xyzs, grad_dirs, ts, rays, N, M):
+    grad_xyzs, grad_dirs, ts, rays = _f32(grad_xyzs), _f32(grad_dirs), _f32(ts), _i32(rays)
+    go = np.zeros((N, 3), dtype=np.float32)
+    gd = np.zeros((N, 3), dtype=np.float32)
+    lib().orc_march_rays_train_backward(_p(grad_xyzs), _p(grad_dirs), _p(ts), _p(rays), c_u(N), c_u(M),
+                                        _p(go), _p(gd))
+    return go, gd
