@@ -1,0 +1,174 @@
+/*
+ * ngp_hip.h -- C ABI of libngp_hip.so, the MI355X (gfx950) implementation of raw_ngp's
+ * data-parallel hot path: multiresolution hash-grid encoder, spherical-harmonics
+ * encoder, density-grid ray marcher / volumetric compositor (+ the fused extensions
+ * the trainer uses).
+ *
+ * This is the drop-in boundary: every `ngp_<name>` below replaces the function of the
+ * same name that the reference exports from its pybind11 modules `_gridencoder`,
+ * `_shencoder`, `_raymarching_mob`, `_freqencoder` (declarations cited per function).
+ * The argument ORDER and MEANING are the reference's; at::Tensor arguments become raw
+ * device pointers, at::optional<Tensor> becomes a nullable pointer, and one trailing
+ * `stream` (a hipStream_t, NULL = default stream) is appended.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to contiguous buffers the CALLER allocated;
+ *     float = IEEE binary32, index arrays int32, bitfields uint8
+ *   - functions only enqueue work on `stream`; they never allocate, never synchronise,
+ *     keep no pointer after returning and are safe to capture in a hipGraph
+ *   - return 0 on success, a negative NGP_E* code otherwise; ngp_last_error() gives the
+ *     message of the calling thread's last failure (the Python shim raises RuntimeError,
+ *     which is what the reference's TORCH_CHECK / std::runtime_error surface as)
+ *   - outputs the reference requires the caller to zero-initialise stay the caller's
+ *     job (grad_embeddings, grad_inputs, weights, xyzs/dirs/ts of march_rays, outputs /
+ *     dy_dx when max_level < L)
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGP_ABI_VERSION 1
+
+#define NGP_OK 0
+#define NGP_EINVAL (-1)  /* unsupported D / C / degree, null pointer, bad size */
+#define NGP_ELAUNCH (-2) /* hipGetLastError() after a launch */
+
+typedef void *ngp_stream_t; /* hipStream_t */
+
+int ngp_abi_version(void);
+const char *ngp_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * grid encoder -- replaces gridencoder/src/gridencoder.h:12-16 (bindings.cpp:5-9)
+ *   inputs      [B, D]  in [0,1]            embeddings [offsets[L], C]
+ *   offsets     [L+1]   int32 (device)      outputs    [L, B, C]
+ *   dy_dx       [B, L*D*C] or NULL          D in {2,3,4,5}, C in {1,2,4,8,16,32}
+ *   gridtype 0 = hash, 1 = tiled; interp 0 = linear, 1 = smoothstep
+ * ---------------------------------------------------------------------------------- */
+int ngp_grid_encode_forward(const float *inputs, const float *embeddings, const int32_t *offsets,
+                            float *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                            uint32_t max_level, float S, uint32_t H, float *dy_dx, uint32_t gridtype,
+                            int align_corners, uint32_t interp, ngp_stream_t stream);
+
+/* grad [L, B, C]; grad_embeddings (pre-zeroed) += scatter; grad_inputs [B, D] written when
+ * dy_dx != NULL */
+int ngp_grid_encode_backward(const float *grad, const float *inputs, const float *embeddings,
+                             const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
+                             uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                             const float *dy_dx, float *grad_inputs, uint32_t gridtype,
+                             int align_corners, uint32_t interp, ngp_stream_t stream);
+
+int ngp_grad_total_variation(const float *inputs, const float *embeddings, float *grad,
+                             const int32_t *offsets, float weight, uint32_t B, uint32_t D, uint32_t C,
+                             uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                             ngp_stream_t stream);
+
+int ngp_grad_weight_decay(const float *embeddings, float *grad, const int32_t *offsets, float weight,
+                          uint32_t B, uint32_t C, uint32_t L, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * SH encoder -- replaces shencoder/src/shencoder.h:8-9.  D must be 3, 1 <= degree <= 8.
+ *   inputs [B,3] (unit vectors), outputs [B, degree^2], dy_dx [B, 3*degree^2] or NULL
+ * ---------------------------------------------------------------------------------- */
+int ngp_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D, uint32_t degree,
+                          float *dy_dx, ngp_stream_t stream);
+/* grad_inputs [B,3] += J^T grad (caller zero-initialises, sphere_harmonics.py:50) */
+int ngp_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D,
+                           uint32_t degree, const float *dy_dx, float *grad_inputs, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * frequency encoder -- replaces freqencoder/src/freqencoder.h (freq_encode_forward/backward)
+ *   outputs [B, C], C = D + 2*D*deg
+ * ---------------------------------------------------------------------------------- */
+int ngp_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                            float *outputs, ngp_stream_t stream);
+int ngp_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg,
+                             uint32_t C, float *grad_inputs, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * ray marching -- replaces raymarching/src/raymarching.h:7-19
+ * ---------------------------------------------------------------------------------- */
+int ngp_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
+                           float min_near, float *nears, float *fars, ngp_stream_t stream);
+int ngp_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
+                     ngp_stream_t stream);
+int ngp_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, ngp_stream_t stream);
+int ngp_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, ngp_stream_t stream);
+/* grid [N*8] floats -> bitfield [N] bytes, bit i = grid[8n+i] > density_thresh */
+int ngp_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield,
+                 ngp_stream_t stream);
+int ngp_flatten_rays(const int32_t *rays, uint32_t N, uint32_t M, int32_t *res, ngp_stream_t stream);
+
+/* Two-call protocol of raymarching.py:301-311.
+ *   call 1 (xyzs == NULL): rays[n] = (offset, count), counter[0] += total.  Offsets are the
+ *     exclusive prefix sum of the counts in ray order starting at the incoming counter[0]
+ *     (the reference's atomicAdd hands them out in scheduling order; ray order is the
+ *     reproducible member of that family and the one raymarching.py:325-328 assumes).
+ *   call 2 (xyzs != NULL): writes xyzs/dirs [M,3], ts [M,2] (, ldirs [M,3]) for those rays.
+ * rays_ldir / ldirs may be NULL.  C = cascades, H = grid size. */
+int ngp_march_rays_train(const float *rays_o, const float *rays_d, const float *rays_ldir,
+                         const uint8_t *grid, float bound, int contract, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears,
+                         const float *fars, float *xyzs, float *dirs, float *ts, float *ldirs,
+                         int32_t *rays, int32_t *counter, const float *noises, ngp_stream_t stream);
+
+int ngp_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *ts,
+                                     const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                     float *weights, float *weights_sum, float *depth, float *image,
+                                     ngp_stream_t stream);
+
+int ngp_composite_rays_train_backward(const float *grad_weights, const float *grad_weights_sum,
+                                      const float *grad_depth, const float *grad_image,
+                                      const float *sigmas, const float *rgbs, const float *ts,
+                                      const int32_t *rays, const float *weights_sum, const float *depth,
+                                      const float *image, uint32_t M, uint32_t N, float T_thresh,
+                                      float *grad_sigmas, float *grad_rgbs, ngp_stream_t stream);
+
+int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                   const float *rays_o, const float *rays_d, float bound, int contract, float dt_gamma,
+                   uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid, const float *nears,
+                   const float *fars, float *xyzs, float *dirs, float *ts, const float *noises,
+                   ngp_stream_t stream);
+
+int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive,
+                       float *rays_t, const float *sigmas, const float *rgbs, const float *ts,
+                       float *weights_sum, float *depth, float *image, ngp_stream_t stream);
+
+/* ====================================================================================
+ * Extensions (ngp_x_*): no counterpart in the reference's bindings; they fuse steps the
+ * reference does in Python/torch between two `_backend` calls so that a training step
+ * needs no host synchronisation and no layout copies.  Each names what it replaces.
+ * ================================================================================== */
+
+/* Replaces torch_scatter.segment_csr in _march_rays_train.backward (raymarching.py:319-329):
+ *   grad_rays_o[n] = sum_i grad_xyzs[i];  grad_rays_d[n] = sum_i grad_xyzs[i]*ts[i,0] + grad_dirs[i]
+ * over the samples of ray n; grad_dirs may be NULL. */
+int ngp_x_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const float *ts,
+                                    const int32_t *rays, uint32_t N, uint32_t M, float *grad_rays_o,
+                                    float *grad_rays_d, ngp_stream_t stream);
+
+/* One-call training march into a pre-sized arena (replaces raymarching.py:292-311 including the
+ * `.item()` host sync): counts, ray-ordered prefix sum, and a sample-parallel coalesced write.
+ *   t_scratch   [N * max_steps] floats of scratch (sample start times, ray-major)
+ *   M_cap       capacity of xyzs/dirs/ts/ldirs in samples; rays whose samples would not fit get
+ *               count 0 (dropped like the reference's overflow rule raymarching.cu:540)
+ *   counter     [2] int32: counter[0] = M actually written (overwritten, not accumulated),
+ *               counter[1] = M the batch would have needed
+ *   ray_idx     [M_cap] int32 or NULL: sample -> ray id (what flatten_rays would give) */
+int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const float *rays_ldir,
+                                 const uint8_t *grid, float bound, int contract, float dt_gamma,
+                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                 const float *nears, const float *fars, const float *noises,
+                                 float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
+                                 float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
+                                 ngp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGP_HIP_H */

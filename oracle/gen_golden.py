@@ -1,0 +1,177 @@
+"""Generate golden fixtures from the reference's own Python (build container only).
+
+TEST INFRASTRUCTURE.  Run as `python oracle/gen_golden.py` in the container that has
+/root/reference mounted; it imports the reference's pure-Python pieces on CPU (third-party
+modules that are not installed are replaced by inert MagicMock entries, SURVEY.md section 8c /
+Appendix B), feeds them seeded inputs and writes inputs + outputs to tests/golden/*.npz.
+Only data is written -- no reference source text.  The reference's CUDA kernels cannot be
+built or run here, so nothing below touches `_backend`.
+"""
+import argparse
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+STUBS = ["cv2", "mcubes", "trimesh", "tensorboardX", "torch_efficient_distloss", "torch_scatter", "imageio",
+         "torchmetrics", "torchmetrics.functional", "torch_ema", "lpips", "rawpy", "pymeshlab", "easydict",
+         "_gridencoder", "_shencoder", "_freqencoder", "_raymarching_mob", "nvdiffrast",
+         "nvdiffrast.torch", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=OUT)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    for name in STUBS:
+        if name not in sys.modules:
+            sys.modules[name] = MagicMock()
+    sys.path.insert(0, os.path.join(REF, "barf"))
+    sys.path.insert(0, REF)
+
+    import torch
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+
+    # ---------------------------------------------------------------- renderer helpers
+    import nerf.renderer as R
+    N = 64
+    o = rng.normal(size=(N, 3)).astype(np.float32)
+    o = 2.5 * o / np.linalg.norm(o, axis=1, keepdims=True)
+    d = (rng.uniform(-0.6, 0.6, (N, 3)) - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:8] = rng.normal(size=(8, 3)).astype(np.float32)           # some misses
+    d[8] = [0.0, 0.0, -1.0]; o[8] = [0.2, 0.3, 2.0]              # axis-parallel ray
+    aabb = np.array([-1, -1, -1, 1, 1, 1], dtype=np.float32)
+    near, far = R.near_far_from_aabb(torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(aabb), 0.05)
+    np.savez(os.path.join(args.out, "near_far_torch.npz"), rays_o=o, rays_d=d, aabb=aabb, min_near=0.05,
+             nears=near.numpy(), fars=far.numpy())
+
+    x = rng.uniform(-3, 3, (200, 3)).astype(np.float32)
+    z = R.contract(torch.from_numpy(x))
+    xr = R.uncontract(z.clone())
+    np.savez(os.path.join(args.out, "contract.npz"), x=x, z=z.numpy(), x_roundtrip=xr.numpy())
+
+    bins = np.sort(rng.uniform(0, 1, (16, 33)).astype(np.float32), axis=1)
+    wts = rng.uniform(0, 1, (16, 32)).astype(np.float32)
+    wts[3] = 0.0
+    samp = R.sample_pdf(torch.from_numpy(bins), torch.from_numpy(wts), 17, perturb=False)
+    np.savez(os.path.join(args.out, "sample_pdf.npz"), bins=bins, weights=wts, T=17, out=samp.numpy())
+
+    # ---------------------------------------------------------------- get_rays
+    import nerf.train_utils as TU
+    poses = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
+    ang = 0.7
+    poses[1, :3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    poses[:, :3, 3] = [[0.1, -0.2, 3.0], [2.0, 0.5, 1.5]]
+    intr = np.array([5.5, 5.0, 2.0, 1.5], dtype=np.float32)
+    res = {}
+    for i in range(2):
+        r = TU.get_rays(torch.from_numpy(poses[i:i + 1]), intr, 3, 4, -1)
+        res[f"rays_o_{i}"] = r["rays_o"].numpy()
+        res[f"rays_d_{i}"] = r["rays_d"].numpy()
+    np.savez(os.path.join(args.out, "get_rays.npz"), poses=poses, intrinsics=intr, H=3, W=4, **res)
+
+    # ---------------------------------------------------------------- trunc_exp
+    import activation as A
+    xe = torch.tensor([-100.0, -80.0, -5.0, 0.0, 1.0, 10.0, 80.0, 85.0], requires_grad=True)
+    ye = A.trunc_exp(xe)
+    ge = torch.autograd.grad(ye.sum(), xe)[0]
+    np.savez(os.path.join(args.out, "trunc_exp.npz"), x=xe.detach().numpy(), y=ye.detach().numpy(), grad=ge.numpy())
+
+    # ---------------------------------------------------------------- MLP + field glue
+    import nerf.network as NW
+    for act in ("relu", "softplus"):
+        opt = types.SimpleNamespace(internal_activation=act, beta=2.0)
+        torch.manual_seed(1)
+        mlp = NW.MLP(32, 16, 64, 3, opt, bias=False)
+        xin = torch.randn(10, 32, requires_grad=True)
+        yout = mlp(xin)
+        gy = torch.randn_like(yout)
+        grads = torch.autograd.grad((yout * gy).sum(), [xin] + list(mlp.parameters()))
+        np.savez(os.path.join(args.out, f"mlp_{act}.npz"), x=xin.detach().numpy(), y=yout.detach().numpy(),
+                 gy=gy.numpy(), gx=grads[0].numpy(),
+                 **{f"w{i}": p.detach().numpy() for i, p in enumerate(mlp.parameters())},
+                 **{f"gw{i}": g.numpy() for i, g in enumerate(grads[1:])})
+
+    # ---------------------------------------------------------------- GridEncoder offset tables
+    import gridencoder.grid as G
+    tabs = {}
+    for tag, kw in (("bound1", dict(desired_resolution=2048)), ("bound2", dict(desired_resolution=4096)),
+                    ("plumbing_L8", dict(num_levels=8, desired_resolution=2048)),
+                    ("prop0", dict(num_levels=5, log2_hashmap_size=17, desired_resolution=128)),
+                    ("prop1", dict(num_levels=5, log2_hashmap_size=17, desired_resolution=256))):
+        enc = G.GridEncoder(input_dim=3, level_dim=2, base_resolution=16,
+                            **{"num_levels": 16, "log2_hashmap_size": 19, **kw})
+        tabs[f"{tag}_offsets"] = enc.offsets.numpy()
+        tabs[f"{tag}_scale"] = np.float64(enc.per_level_scale)
+        tabs[f"{tag}_n_params"] = np.int64(int(enc.n_params))
+        tabs[f"{tag}_emb_shape"] = np.array(enc.embeddings.shape)
+    np.savez(os.path.join(args.out, "grid_offsets.npz"), **tabs)
+
+    # ---------------------------------------------------------------- BARF / BAA-NGP level windows
+    base = dict(bound=1.0, contract=False, grid_size=128, min_near=0.05, density_thresh=10, cuda_ray=True,
+                hashmap_size=19, hashgrid_resolution=2048, rfield=False, internal_activation="relu", beta=2.0,
+                density_activation="clamped_exp", color_activation="clamped_exp", device="cpu",
+                start_annealing=0.0, end_annealing=0.33)
+    wres = {}
+    for mode in ("barf", "baangp"):
+        opt = types.SimpleNamespace(pose_opt="none", **base)
+        net = NW.NeRFNetwork(opt)
+        opt.pose_opt = mode
+        feat = torch.arange(1, 33, dtype=torch.float32).repeat(4, 1) * 0.1
+
+        class FixedFeat(torch.nn.Module):
+            def forward(self, x, bound=1):
+                return feat.clone()
+
+        net.grid_encoder = FixedFeat()
+        seen = []
+        net.grid_mlp.register_forward_pre_hook(lambda m, inp: seen.append(inp[0].detach().clone()))
+        for ann in (0.0, 0.1, 0.33, 1.0):
+            net.update_annealing(np.float16(ann))
+            seen.clear()
+            net.common_forward(torch.zeros(4, 3))
+            wres[f"{mode}_{ann}"] = seen[0].numpy()
+    np.savez(os.path.join(args.out, "level_windows.npz"), feat=feat.numpy(), **wres)
+
+    # ---------------------------------------------------------------- run() with an analytic field
+    class Analytic(R.NeRFRenderer):
+        def density(self, x, proposal=-1, **kw):
+            r2 = (x ** 2).sum(-1)
+            return {"sigma": 30.0 * torch.exp(-3.0 * r2) * (1.0 + 0.5 * (proposal + 1))}
+
+        def forward(self, x, d, **kw):
+            r2 = (x ** 2).sum(-1)
+            return {"sigma": 30.0 * torch.exp(-3.0 * r2),
+                    "color": torch.sigmoid(3.0 * x) * (0.75 + 0.25 * d[..., :1])}
+
+    ropt = types.SimpleNamespace(bound=1.0, contract=False, grid_size=128, min_near=0.05, density_thresh=10,
+                                 cuda_ray=False, num_steps=[64, 32, 16], background="black", lambda_proposal=0.0,
+                                 lambda_distort=0.0, max_ray_batch=4096)
+    ren = Analytic(ropt)
+    ren.eval()
+    NR = 256
+    ro = rng.normal(size=(NR, 3)).astype(np.float32)
+    ro = 2.2 * ro / np.linalg.norm(ro, axis=1, keepdims=True)
+    rd = (rng.uniform(-0.5, 0.5, (NR, 3)) - ro).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    with torch.no_grad():
+        outp = ren.run(torch.from_numpy(ro), torch.from_numpy(rd), bg_color=None, perturb=False)
+    np.savez(os.path.join(args.out, "run_analytic.npz"), rays_o=ro, rays_d=rd, num_steps=np.array([64, 32, 16]),
+             image=outp["image"].numpy(), depth=outp["depth"].numpy(), weights_sum=outp["weights_sum"].numpy())
+    print("fixtures written to", args.out)
+    for f in sorted(os.listdir(args.out)):
+        print("  ", f, os.path.getsize(os.path.join(args.out, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,257 @@
+"""Loader of libngp_hip.so and the `_backend` shims.
+
+The reference's op wrappers call `_backend.<fn>(tensors..., scalars...)` on three pybind11
+modules (`_gridencoder`, `_shencoder`, `_raymarching_mob`, + `_freqencoder`).
+The objects exported here (`gridencoder_backend`, `shencoder_backend`, `raymarching_backend`,
+`freqencoder_backend`) offer the same attribute names and positional argument orders, convert
+tensors to raw device pointers, append the caller's current HIP stream and raise RuntimeError
+when the C ABI (include/ngp_hip.h) reports a failure.
+
+There is NO fallback: if the HIP library is missing or a tensor is not a contiguous device
+tensor of the right dtype the call fails loudly.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libngp_hip.so")
+
+_f, _u, _i, _p = ctypes.c_float, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p
+
+# name -> argument ctypes (the trailing stream pointer is appended automatically)
+_SIGNATURES = {
+    "ngp_grid_encode_forward": [_p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _p, _u, _i, _u],
+    "ngp_grid_encode_backward": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _p, _p, _u, _i, _u],
+    "ngp_grad_total_variation": [_p, _p, _p, _p, _f, _u, _u, _u, _u, _f, _u, _u, _i],
+    "ngp_grad_weight_decay": [_p, _p, _p, _f, _u, _u, _u],
+    "ngp_sh_encode_forward": [_p, _p, _u, _u, _u, _p],
+    "ngp_sh_encode_backward": [_p, _p, _u, _u, _u, _p, _p],
+    "ngp_freq_encode_forward": [_p, _u, _u, _u, _u, _p],
+    "ngp_freq_encode_backward": [_p, _p, _u, _u, _u, _u, _p],
+    "ngp_near_far_from_aabb": [_p, _p, _p, _u, _f, _p, _p],
+    "ngp_sph_from_ray": [_p, _p, _f, _u, _p],
+    "ngp_morton3D": [_p, _u, _p],
+    "ngp_morton3D_invert": [_p, _u, _p],
+    "ngp_packbits": [_p, _u, _f, _p],
+    "ngp_flatten_rays": [_p, _u, _u, _p],
+    "ngp_march_rays_train": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "ngp_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
+    "ngp_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
+    "ngp_march_rays": [_u, _u, _p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _p, _p, _p, _p, _p, _p, _p],
+    "ngp_composite_rays": [_u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _p],
+    "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
+    "ngp_x_march_rays_train_arena": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _u, _p, _p, _p,
+                                     _p, _p, _p, _p],
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree HIP library (built by `python -c 'import __graft_entry__ as g; g.build()'`
+    or `make -C raw_ngp_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"raw_ngp_amd: {LIB_PATH} is missing -- build it with `make -C raw_ngp_amd/csrc` "
+                "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.ngp_last_error.restype = ctypes.c_char_p
+        lib.ngp_abi_version.restype = ctypes.c_int
+        for name, args in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = list(args) + [_p]
+            fn.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def declared_symbols():
+    return ["ngp_abi_version", "ngp_last_error"] + list(_SIGNATURES)
+
+
+_DT = {"f": torch.float32, "i": torch.int32, "b": torch.uint8}
+
+
+def _ptr(t, kind, name, optional=False):
+    if t is None:
+        if optional:
+            return None
+        raise RuntimeError(f"{name} must not be None")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")  # wording of the reference's CHECK_CUDA
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if t.dtype != _DT[kind]:
+        raise RuntimeError(f"{name} must be a {_DT[kind]} tensor, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _call(name, anchor, *args):
+    lib = load()
+    dev = anchor.device
+    if torch.cuda.current_device() != dev.index:
+        with torch.cuda.device(dev):
+            rc = getattr(lib, name)(*args, torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        rc = getattr(lib, name)(*args, torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(lib.ngp_last_error().decode())
+
+
+class _GridBackend:
+    """Stands in for `_gridencoder` (gridencoder/src/bindings.cpp:5-9)."""
+
+    @staticmethod
+    def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, H, dy_dx, gridtype,
+                            align_corners, interp):
+        _call("ngp_grid_encode_forward", inputs, _ptr(inputs, "f", "inputs"), _ptr(embeddings, "f", "embeddings"),
+              _ptr(offsets, "i", "offsets"), _ptr(outputs, "f", "outputs"), B, D, C, L, max_level, float(S), H,
+              _ptr(dy_dx, "f", "dy_dx", True), gridtype, int(bool(align_corners)), interp)
+
+    @staticmethod
+    def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S, H, dy_dx,
+                             grad_inputs, gridtype, align_corners, interp):
+        _call("ngp_grid_encode_backward", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
+              _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"),
+              _ptr(grad_embeddings, "f", "grad_embeddings"), B, D, C, L, max_level, float(S), H,
+              _ptr(dy_dx, "f", "dy_dx", True), _ptr(grad_inputs, "f", "grad_inputs", True), gridtype,
+              int(bool(align_corners)), interp)
+
+    @staticmethod
+    def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
+        _call("ngp_grad_total_variation", inputs, _ptr(inputs, "f", "inputs"), _ptr(embeddings, "f", "embeddings"),
+              _ptr(grad, "f", "grad"), _ptr(offsets, "i", "offsets"), float(weight), B, D, C, L, float(S), H,
+              gridtype, int(bool(align_corners)))
+
+    @staticmethod
+    def grad_weight_decay(embeddings, grad, offsets, weight, B, C, L):
+        _call("ngp_grad_weight_decay", embeddings, _ptr(embeddings, "f", "embeddings"), _ptr(grad, "f", "grad"),
+              _ptr(offsets, "i", "offsets"), float(weight), B, C, L)
+
+
+class _SHBackend:
+    """Stands in for `_shencoder` (shencoder/src/bindings.cpp:5-7)."""
+
+    @staticmethod
+    def sh_encode_forward(inputs, outputs, B, D, C, dy_dx):
+        _call("ngp_sh_encode_forward", inputs, _ptr(inputs, "f", "inputs"), _ptr(outputs, "f", "outputs"), B, D, C,
+              _ptr(dy_dx, "f", "dy_dx", True))
+
+    @staticmethod
+    def sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs):
+        _call("ngp_sh_encode_backward", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"), B, D, C,
+              _ptr(dy_dx, "f", "dy_dx"), _ptr(grad_inputs, "f", "grad_inputs"))
+
+
+class _FreqBackend:
+    """Stands in for `_freqencoder`."""
+
+    @staticmethod
+    def freq_encode_forward(inputs, B, D, deg, C, outputs):
+        _call("ngp_freq_encode_forward", inputs, _ptr(inputs, "f", "inputs"), B, D, deg, C,
+              _ptr(outputs, "f", "outputs"))
+
+    @staticmethod
+    def freq_encode_backward(grad, outputs, B, D, deg, C, grad_inputs):
+        _call("ngp_freq_encode_backward", grad, _ptr(grad, "f", "grad"), _ptr(outputs, "f", "outputs"), B, D, deg, C,
+              _ptr(grad_inputs, "f", "grad_inputs"))
+
+
+class _RayBackend:
+    """Stands in for `_raymarching_mob` (raymarching/src/bindings.cpp:5-19)."""
+
+    @staticmethod
+    def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+        _call("ngp_near_far_from_aabb", rays_o, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
+              _ptr(aabb, "f", "aabb"), N, float(min_near), _ptr(nears, "f", "nears"), _ptr(fars, "f", "fars"))
+
+    @staticmethod
+    def sph_from_ray(rays_o, rays_d, radius, N, coords):
+        _call("ngp_sph_from_ray", rays_o, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"), float(radius), N,
+              _ptr(coords, "f", "coords"))
+
+    @staticmethod
+    def morton3D(coords, N, indices):
+        _call("ngp_morton3D", coords, _ptr(coords, "i", "coords"), N, _ptr(indices, "i", "indices"))
+
+    @staticmethod
+    def morton3D_invert(indices, N, coords):
+        _call("ngp_morton3D_invert", indices, _ptr(indices, "i", "indices"), N, _ptr(coords, "i", "coords"))
+
+    @staticmethod
+    def packbits(grid, N, density_thresh, bitfield):
+        _call("ngp_packbits", grid, _ptr(grid, "f", "grid"), N, float(density_thresh),
+              _ptr(bitfield, "b", "bitfield"))
+
+    @staticmethod
+    def flatten_rays(rays, N, M, res):
+        _call("ngp_flatten_rays", rays, _ptr(rays, "i", "rays"), N, M, _ptr(res, "i", "res"))
+
+    @staticmethod
+    def march_rays_train(rays_o, rays_d, rays_ldir, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars,
+                         xyzs, dirs, ts, ldirs, rays, counter, noises):
+        _call("ngp_march_rays_train", rays_o, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
+              _ptr(rays_ldir, "f", "rays_ldir", True), _ptr(grid, "b", "grid"), float(bound), int(bool(contract)),
+              float(dt_gamma), max_steps, N, C, H, _ptr(nears, "f", "nears"), _ptr(fars, "f", "fars"),
+              _ptr(xyzs, "f", "xyzs", True), _ptr(dirs, "f", "dirs", True), _ptr(ts, "f", "ts", True),
+              _ptr(ldirs, "f", "ldirs", True), _ptr(rays, "i", "rays"), _ptr(counter, "i", "counter"),
+              _ptr(noises, "f", "noises"))
+
+    @staticmethod
+    def composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum, depth, image):
+        _call("ngp_composite_rays_train_forward", rays, _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"),
+              _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights, "f", "weights"),
+              _ptr(weights_sum, "f", "weights_sum"), _ptr(depth, "f", "depth"), _ptr(image, "f", "image"))
+
+    @staticmethod
+    def composite_rays_train_backward(grad_weights, grad_weights_sum, grad_depth, grad_image, sigmas, rgbs, ts, rays,
+                                      weights_sum, depth, image, M, N, T_thresh, grad_sigmas, grad_rgbs):
+        _call("ngp_composite_rays_train_backward", rays, _ptr(grad_weights, "f", "grad_weights"),
+              _ptr(grad_weights_sum, "f", "grad_weights_sum"), _ptr(grad_depth, "f", "grad_depth"),
+              _ptr(grad_image, "f", "grad_image"), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"),
+              _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), _ptr(weights_sum, "f", "weights_sum"),
+              _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), M, N, float(T_thresh),
+              _ptr(grad_sigmas, "f", "grad_sigmas"), _ptr(grad_rgbs, "f", "grad_rgbs"))
+
+    @staticmethod
+    def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, contract, dt_gamma, max_steps, C, H,
+                   grid, nears, fars, xyzs, dirs, ts, noises):
+        _call("ngp_march_rays", rays_o, n_alive, n_step, _ptr(rays_alive, "i", "rays_alive"),
+              _ptr(rays_t, "f", "rays_t"), _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"), float(bound),
+              int(bool(contract)), float(dt_gamma), max_steps, C, H, _ptr(grid, "b", "grid"),
+              _ptr(nears, "f", "nears"), _ptr(fars, "f", "fars"), _ptr(xyzs, "f", "xyzs"), _ptr(dirs, "f", "dirs"),
+              _ptr(ts, "f", "ts"), _ptr(noises, "f", "noises"))
+
+    @staticmethod
+    def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, ts, weights_sum, depth, image):
+        _call("ngp_composite_rays", rays_alive, n_alive, n_step, float(T_thresh),
+              _ptr(rays_alive, "i", "rays_alive"), _ptr(rays_t, "f", "rays_t"), _ptr(sigmas, "f", "sigmas"),
+              _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"), _ptr(weights_sum, "f", "weights_sum"),
+              _ptr(depth, "f", "depth"), _ptr(image, "f", "image"))
+
+    # ---- extensions (ngp_x_*) ------------------------------------------------------------
+    @staticmethod
+    def march_rays_train_backward(grad_xyzs, grad_dirs, ts, rays, N, M, grad_rays_o, grad_rays_d):
+        _call("ngp_x_march_rays_train_backward", rays, _ptr(grad_xyzs, "f", "grad_xyzs"),
+              _ptr(grad_dirs, "f", "grad_dirs", True), _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), N, M,
+              _ptr(grad_rays_o, "f", "grad_rays_o"), _ptr(grad_rays_d, "f", "grad_rays_d"))
+
+    @staticmethod
+    def march_rays_train_arena(rays_o, rays_d, rays_ldir, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears,
+                               fars, noises, t_scratch, M_cap, xyzs, dirs, ts, ldirs, rays, counter, ray_idx):
+        _call("ngp_x_march_rays_train_arena", rays_o, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
+              _ptr(rays_ldir, "f", "rays_ldir", True), _ptr(grid, "b", "grid"), float(bound), int(bool(contract)),
+              float(dt_gamma), max_steps, N, C, H, _ptr(nears, "f", "nears"), _ptr(fars, "f", "fars"),
+              _ptr(noises, "f", "noises"), _ptr(t_scratch, "f", "t_scratch"), M_cap, _ptr(xyzs, "f", "xyzs"),
+              _ptr(dirs, "f", "dirs"), _ptr(ts, "f", "ts"), _ptr(ldirs, "f", "ldirs", True),
+              _ptr(rays, "i", "rays"), _ptr(counter, "i", "counter"), _ptr(ray_idx, "i", "ray_idx", True))
+
+
+gridencoder_backend = _GridBackend()
+shencoder_backend = _SHBackend()
+freqencoder_backend = _FreqBackend()
+raymarching_backend = _RayBackend()

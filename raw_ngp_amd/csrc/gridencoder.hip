@@ -1,0 +1,562 @@
+// Multiresolution hash / tiled grid encoder for gfx950.
+//
+// Behaviour follows the reference kernels (file:line into the reference tree):
+//   forward + dy_dx     gridencoder/src/gridencoder.cu:82-249
+//   table gradient      :252-349        input gradient :352-378
+//   total variation     :525-631        weight decay   :670-703
+//   hash / index rule   :45-79
+// The design does not: one 1-D grid whose (level, chunk) work items are dealt to the
+// 8 XCDs as contiguous level ranges (each XCD keeps the one or two 4 MiB level tables it
+// is working on in its own L2), per-level geometry (row count, strides, hash / mask /
+// modulo mode) derived once per workgroup in scalar registers, whole-row vector gathers
+// (float2 for C = 2) all issued before the first use, streaming (non-temporal) stores.
+// Arithmetic choices (explicit fmaf, no implicit contraction) mirror oracle/ngp_oracle.c.
+#include "ngp_common.hpp"
+
+namespace ngp {
+
+constexpr uint32_t kMaxLevels = 64;
+constexpr uint32_t kBlock = 256;
+
+struct LevelRes {
+    uint32_t res[kMaxLevels];
+};
+
+__device__ constexpr uint32_t kPrimes[7] = {1u,          2654435761u, 805459861u, 3674653429u,
+                                            2097192037u, 1434869437u, 2165219737u};
+
+// Per-level geometry; every field is workgroup-uniform (lives in SGPRs).
+template <uint32_t D>
+struct Geom {
+    uint32_t T;          // rows in this level
+    uint32_t res;
+    uint32_t stride[D];  // dense strides (uint32 wrap like the reference)
+    uint32_t nd;         // dims that entered the dense index before stride exceeded T
+    bool hashed;
+    uint32_t mode;       // 0: index < T by construction, 1: T is a power of two (mask), 2: modulo
+};
+
+template <uint32_t D>
+__device__ __forceinline__ Geom<D> make_geom(const int32_t *__restrict__ offsets, uint32_t level, uint32_t res,
+                                            uint32_t gridtype)
+{
+    Geom<D> g;
+    g.T = (uint32_t)(offsets[level + 1] - offsets[level]);
+    g.res = res;
+    uint32_t stride = 1, d = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < D; k++) g.stride[k] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < D; k++) {
+        if (d == k && stride <= g.T) {
+            g.stride[k] = stride;
+            stride *= res;
+            d = k + 1;
+        }
+    }
+    g.nd = d;
+    g.hashed = (gridtype == 0u) && (stride > g.T);
+    if (!g.hashed && d == D && stride <= g.T)
+        g.mode = 0;
+    else if ((g.T & (g.T - 1u)) == 0u)
+        g.mode = 1;
+    else
+        g.mode = 2;
+    return g;
+}
+
+template <uint32_t D>
+__device__ __forceinline__ uint32_t row_of(const Geom<D> &g, const uint32_t (&c)[D])
+{
+    uint32_t idx = 0;
+    if (g.hashed) {
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) idx ^= c[d] * kPrimes[d];
+    } else {
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) idx += c[d] * g.stride[d];  // stride 0 for dims past nd
+    }
+    if (g.mode == 1)
+        idx &= g.T - 1u;
+    else if (g.mode == 2)
+        idx %= g.T;
+    return idx;
+}
+
+template <uint32_t D>
+struct Cell {
+    uint32_t c[D];
+    float f[D];
+    float df[D];
+};
+
+// false when the point is outside [0,1]^D (the reference zeroes / skips those)
+template <uint32_t D>
+__device__ __forceinline__ bool locate(const float (&x)[D], uint32_t res, bool align_corners, uint32_t interp,
+                                       Cell<D> &o)
+{
+    bool inside = true;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) inside = inside && !(x[d] < 0.0f || x[d] > 1.0f);
+    if (!inside) return false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        float p;
+        uint32_t c;
+        if (align_corners) {
+            p = x[d] * (float)(res - 1u);
+            c = min((uint32_t)floorf(p), res - 2u);
+        } else {
+            p = fminf(fmaxf(fmaf(x[d], (float)res, -0.5f), 0.0f), (float)(res - 1u));
+            c = (uint32_t)floorf(p);
+        }
+        p -= (float)c;
+        if (interp == 1u) {
+            o.df[d] = 6.0f * p * (1.0f - p);
+            p = p * p * (3.0f - 2.0f * p);
+        } else {
+            o.df[d] = 1.0f;
+        }
+        o.c[d] = c;
+        o.f[d] = p;
+    }
+    return true;
+}
+
+// Row access in the widest vector the channel count allows.
+template <uint32_t C>
+struct Row {
+    float v[C];
+    __device__ __forceinline__ void load(const float *__restrict__ p)
+    {
+        if constexpr (C == 1) {
+            v[0] = p[0];
+        } else if constexpr (C == 2) {
+            const float2 t = *reinterpret_cast<const float2 *>(p);
+            v[0] = t.x;
+            v[1] = t.y;
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < C; i += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(p + i);
+                v[i] = t.x;
+                v[i + 1] = t.y;
+                v[i + 2] = t.z;
+                v[i + 3] = t.w;
+            }
+        }
+    }
+    __device__ __forceinline__ void store_stream(float *__restrict__ p) const
+    {
+        if constexpr (C == 1) {
+            __builtin_nontemporal_store(v[0], p);
+        } else if constexpr (C == 2) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 t = {v[0], v[1]};
+            __builtin_nontemporal_store(t, reinterpret_cast<f2 *>(p));
+        } else {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (uint32_t i = 0; i < C; i += 4) {
+                f4 t = {v[i], v[i + 1], v[i + 2], v[i + 3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p + i));
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------ forward
+template <uint32_t D, uint32_t C, bool JAC>
+__global__ __launch_bounds__(kBlock) void grid_forward_kernel(
+    const float *__restrict__ inputs, const float *__restrict__ table, const int32_t *__restrict__ offsets,
+    float *__restrict__ outputs, float *__restrict__ dy_dx, uint32_t B, uint32_t L, uint32_t nchunks,
+    LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp)
+{
+    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t level = item / nchunks;
+    const uint32_t b = (item - level * nchunks) * kBlock + threadIdx.x;
+    if (b >= B) return;
+
+    const Geom<D> g = make_geom<D>(offsets, level, lv.res[level], gridtype);
+    const float *__restrict__ tab = table + (size_t)(uint32_t)offsets[level] * C;
+
+    float x[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+
+    float *out = outputs + ((size_t)level * B + b) * C;
+    float *jac = JAC ? dy_dx + (size_t)b * L * D * C + (size_t)level * D * C : nullptr;
+
+    Cell<D> cl;
+    if (!locate<D>(x, g.res, align_corners, interp, cl)) {
+        Row<C> z;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) z.v[ch] = 0.0f;
+        z.store_stream(out);
+        if (JAC) {
+#pragma unroll
+            for (uint32_t i = 0; i < D * C; i++) jac[i] = 0.0f;
+        }
+        return;
+    }
+
+    // all 2^D row gathers are issued before the first multiply
+    constexpr uint32_t NCORN = 1u << D;
+    Row<C> rows[NCORN];
+    float wts[NCORN];
+#pragma unroll
+    for (uint32_t corner = 0; corner < NCORN; corner++) {
+        float w = 1.0f;
+        uint32_t c[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if (corner & (1u << d)) {
+                w *= cl.f[d];
+                c[d] = min(cl.c[d] + 1u, g.res - 1u);
+            } else {
+                w *= 1.0f - cl.f[d];
+                c[d] = cl.c[d];
+            }
+        }
+        wts[corner] = w;
+        rows[corner].load(tab + (size_t)row_of<D>(g, c) * C);
+    }
+    Row<C> acc;
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) acc.v[ch] = 0.0f;
+#pragma unroll
+    for (uint32_t corner = 0; corner < NCORN; corner++)
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) acc.v[ch] = fmaf(wts[corner], rows[corner].v[ch], acc.v[ch]);
+    acc.store_stream(out);
+
+    if constexpr (JAC) {
+        // d out / d x_gd: the corner rows are already in registers (corner bit gd = 0 / 1)
+        const float scale = (float)(align_corners ? g.res - 1u : g.res);
+#pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            float gacc[C];
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) gacc[ch] = 0.0f;
+#pragma unroll
+            for (uint32_t combo = 0; combo < (1u << (D - 1)); combo++) {
+                float w = scale;
+                uint32_t lo = 0;
+#pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = nd >= gd ? nd + 1 : nd;
+                    if (combo & (1u << nd)) {
+                        w *= cl.f[d];
+                        lo |= 1u << d;
+                    } else {
+                        w *= 1.0f - cl.f[d];
+                    }
+                }
+                const uint32_t hi = lo | (1u << gd);
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++)
+                    gacc[ch] = fmaf(w * (rows[hi].v[ch] - rows[lo].v[ch]), cl.df[gd], gacc[ch]);
+            }
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) jac[gd * C + ch] = gacc[ch];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward (float atomics)
+template <uint32_t D, uint32_t C>
+__global__ __launch_bounds__(kBlock) void grid_backward_atomic_kernel(
+    const float *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+    float *__restrict__ grad_table, uint32_t B, uint32_t nchunks, LevelRes lv, uint32_t gridtype,
+    bool align_corners, uint32_t interp)
+{
+    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t level = item / nchunks;
+    const uint32_t b = (item - level * nchunks) * kBlock + threadIdx.x;
+    if (b >= B) return;
+
+    const Geom<D> g = make_geom<D>(offsets, level, lv.res[level], gridtype);
+    float *__restrict__ gt = grad_table + (size_t)(uint32_t)offsets[level] * C;
+
+    float x[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+    Cell<D> cl;
+    if (!locate<D>(x, g.res, align_corners, interp, cl)) return;
+
+    Row<C> gr;
+    gr.load(grad + ((size_t)level * B + b) * C);
+
+#pragma unroll
+    for (uint32_t corner = 0; corner < (1u << D); corner++) {
+        float w = 1.0f;
+        uint32_t c[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if (corner & (1u << d)) {
+                w *= cl.f[d];
+                c[d] = min(cl.c[d] + 1u, g.res - 1u);
+            } else {
+                w *= 1.0f - cl.f[d];
+                c[d] = cl.c[d];
+            }
+        }
+        float *dst = gt + (size_t)row_of<D>(g, c) * C;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) unsafeAtomicAdd(dst + ch, w * gr.v[ch]);
+    }
+}
+
+// grad_inputs[b, d] = sum_{l, ch} grad[l, b, ch] * dy_dx[b, l, d, ch]   (all L levels)
+template <uint32_t D, uint32_t C>
+__global__ __launch_bounds__(kBlock) void grid_input_backward_kernel(const float *__restrict__ grad,
+                                                                     const float *__restrict__ dy_dx,
+                                                                     float *__restrict__ grad_inputs, uint32_t B,
+                                                                     uint32_t L)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const float *jac = dy_dx + (size_t)b * L * D * C;
+    float r = 0.0f;
+    for (uint32_t l = 0; l < L; l++) {
+        const float *gl = grad + ((size_t)l * B + b) * C;
+        const float *jl = jac + (size_t)l * D * C + d * C;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) r = fmaf(gl[ch], jl[ch], r);
+    }
+    grad_inputs[t] = r;
+}
+
+// ------------------------------------------------------------------ total variation
+template <uint32_t D, uint32_t C>
+__global__ __launch_bounds__(kBlock) void grid_tv_kernel(const float *__restrict__ inputs,
+                                                         const float *__restrict__ table, float *__restrict__ grad,
+                                                         const int32_t *__restrict__ offsets, float w, uint32_t B,
+                                                         uint32_t nchunks, LevelRes lv, uint32_t gridtype,
+                                                         bool align_corners)
+{
+    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t level = item / nchunks;
+    const uint32_t b = (item - level * nchunks) * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const Geom<D> g = make_geom<D>(offsets, level, lv.res[level], gridtype);
+    const float *__restrict__ tab = table + (size_t)(uint32_t)offsets[level] * C;
+    float *__restrict__ ga = grad + (size_t)(uint32_t)offsets[level] * C;
+
+    float x[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+    Cell<D> cl;
+    if (!locate<D>(x, g.res, align_corners, 0u, cl)) return;
+
+    uint32_t c[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) c[d] = cl.c[d];
+    const uint32_t centre = row_of<D>(g, c);
+    Row<C> mid;
+    mid.load(tab + (size_t)centre * C);
+    float sum[C], sq[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) sum[ch] = sq[ch] = 0.0f;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t cur = c[d];
+        // + side is taken whenever cur < res, i.e. always: the neighbour index may equal res
+        // (gridencoder.cu:595); it still lands inside the level through the hash / modulo.
+        if (cur < g.res) {
+            c[d] = cur + 1u;
+            Row<C> nb;
+            uint32_t r = row_of<D>(g, c);
+            if (g.mode == 0) r %= g.T;  // a dense index with coordinate == res can reach T
+            nb.load(tab + (size_t)r * C);
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) {
+                const float dv = mid.v[ch] - nb.v[ch];
+                sum[ch] += dv;
+                sq[ch] = fmaf(dv, dv, sq[ch]);
+            }
+        }
+        if (cur > 0u) {
+            c[d] = cur - 1u;
+            Row<C> nb;
+            nb.load(tab + (size_t)row_of<D>(g, c) * C);
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) {
+                const float dv = mid.v[ch] - nb.v[ch];
+                sum[ch] += dv;
+                sq[ch] = fmaf(dv, dv, sq[ch]);
+            }
+        }
+        c[d] = cur;
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++)
+        unsafeAtomicAdd(ga + (size_t)centre * C + ch, w * sum[ch] * (1.0f / sqrtf(sq[ch] + 1e-9f)));
+}
+
+// ------------------------------------------------------------------ weight decay
+__global__ __launch_bounds__(kBlock) void grid_wd_kernel(const float *__restrict__ table, float *__restrict__ grad,
+                                                         const int32_t *__restrict__ offsets, float weight,
+                                                         uint32_t n_elems, uint32_t C, uint32_t L)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_elems; i += gridDim.x * kBlock) {
+        const uint32_t n = i / C;
+        uint32_t level = 0, lo = 0, hi = L;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)offsets[mid] <= n) {
+                level = mid;
+                lo = mid + 1;
+            } else {
+                hi = mid;
+            }
+        }
+        const uint32_t T = (uint32_t)(offsets[level + 1] - offsets[level]);
+        grad[i] += 2.0f * weight * table[i] / (float)T;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static bool fill_levels(LevelRes &lv, float S, uint32_t H, uint32_t L)
+{
+    if (L == 0 || L > kMaxLevels) return false;
+    for (uint32_t l = 0; l < L; l++) lv.res[l] = (uint32_t)ceilf(exp2f((float)l * S) * (float)H);
+    for (uint32_t l = L; l < kMaxLevels; l++) lv.res[l] = 0;
+    return true;
+}
+
+template <uint32_t D, uint32_t C>
+static void launch_forward(const float *inputs, const float *table, const int32_t *offsets, float *outputs,
+                           float *dy_dx, uint32_t B, uint32_t L, uint32_t max_level, const LevelRes &lv,
+                           uint32_t gridtype, bool align, uint32_t interp, hipStream_t st)
+{
+    const uint32_t nchunks = ceil_div(B, kBlock);
+    const dim3 grid(nchunks * max_level);
+    if (dy_dx)
+        grid_forward_kernel<D, C, true><<<grid, kBlock, 0, st>>>(inputs, table, offsets, outputs, dy_dx, B, L,
+                                                                 nchunks, lv, gridtype, align, interp);
+    else
+        grid_forward_kernel<D, C, false><<<grid, kBlock, 0, st>>>(inputs, table, offsets, outputs, dy_dx, B, L,
+                                                                  nchunks, lv, gridtype, align, interp);
+}
+
+template <uint32_t D, uint32_t C>
+static void launch_backward(const float *grad, const float *inputs, const int32_t *offsets, float *grad_table,
+                            uint32_t B, uint32_t L, uint32_t max_level, const LevelRes &lv, const float *dy_dx,
+                            float *grad_inputs, uint32_t gridtype, bool align, uint32_t interp, hipStream_t st)
+{
+    const uint32_t nchunks = ceil_div(B, kBlock);
+    grid_backward_atomic_kernel<D, C><<<dim3(nchunks * max_level), kBlock, 0, st>>>(
+        grad, inputs, offsets, grad_table, B, nchunks, lv, gridtype, align, interp);
+    if (dy_dx && grad_inputs)
+        grid_input_backward_kernel<D, C><<<dim3(ceil_div(B * D, kBlock)), kBlock, 0, st>>>(grad, dy_dx, grad_inputs,
+                                                                                          B, L);
+}
+
+template <uint32_t D, uint32_t C>
+static void launch_tv(const float *inputs, const float *table, float *grad, const int32_t *offsets, float w,
+                      uint32_t B, uint32_t L, const LevelRes &lv, uint32_t gridtype, bool align, hipStream_t st)
+{
+    const uint32_t nchunks = ceil_div(B, kBlock);
+    grid_tv_kernel<D, C><<<dim3(nchunks * L), kBlock, 0, st>>>(inputs, table, grad, offsets, w, B, nchunks, lv,
+                                                              gridtype, align);
+}
+
+// dispatch over the (D, C) pairs the reference instantiates (gridencoder.cu:385-410)
+#define NGP_DISPATCH_C(D_, FN, ...)                         \
+    switch (C) {                                            \
+        case 1: FN<D_, 1>(__VA_ARGS__); break;              \
+        case 2: FN<D_, 2>(__VA_ARGS__); break;              \
+        case 4: FN<D_, 4>(__VA_ARGS__); break;              \
+        case 8: FN<D_, 8>(__VA_ARGS__); break;              \
+        case 16: FN<D_, 16>(__VA_ARGS__); break;            \
+        case 32: FN<D_, 32>(__VA_ARGS__); break;            \
+    }
+#define NGP_DISPATCH_DC(FN, ...)                            \
+    switch (D) {                                            \
+        case 2: NGP_DISPATCH_C(2, FN, __VA_ARGS__) break;   \
+        case 3: NGP_DISPATCH_C(3, FN, __VA_ARGS__) break;   \
+        case 4: NGP_DISPATCH_C(4, FN, __VA_ARGS__) break;   \
+        case 5: NGP_DISPATCH_C(5, FN, __VA_ARGS__) break;   \
+    }
+
+static int check_dc(const char *fn, uint32_t D, uint32_t C)
+{
+    // same messages as the reference's std::runtime_error (gridencoder.cu:392,409)
+    if (!(C == 1 || C == 2 || C == 4 || C == 8 || C == 16 || C == 32))
+        NGP_FAIL(NGP_EINVAL, "%s: GridEncoding: C must be 1, 2, 4, 8, 16 or 32.", fn);
+    if (D < 2 || D > 5) NGP_FAIL(NGP_EINVAL, "%s: GridEncoding: D must be 2, 3, 4 or 5.", fn);
+    return NGP_OK;
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" int ngp_grid_encode_forward(const float *inputs, const float *embeddings, const int32_t *offsets,
+                                       float *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                       uint32_t max_level, float S, uint32_t H, float *dy_dx, uint32_t gridtype,
+                                       int align_corners, uint32_t interp, ngp_stream_t stream)
+{
+    NGP_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null tensor");
+    if (int e = check_dc("grid_encode_forward", D, C)) return e;
+    LevelRes lv;
+    NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_forward: L must be in [1, %u]", kMaxLevels);
+    NGP_REQUIRE(max_level <= L, "grid_encode_forward: max_level > L");
+    if (B == 0 || max_level == 0) return NGP_OK;
+    NGP_DISPATCH_DC(launch_forward, inputs, embeddings, offsets, outputs, dy_dx, B, L, max_level, lv, gridtype,
+                    align_corners != 0, interp, as_stream(stream));
+    NGP_CHECK_LAUNCH("grid_encode_forward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_grid_encode_backward(const float *grad, const float *inputs, const float *embeddings,
+                                        const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
+                                        uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                        const float *dy_dx, float *grad_inputs, uint32_t gridtype,
+                                        int align_corners, uint32_t interp, ngp_stream_t stream)
+{
+    (void)embeddings;
+    NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null tensor");
+    if (int e = check_dc("grid_encode_backward", D, C)) return e;
+    LevelRes lv;
+    NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_backward: L must be in [1, %u]", kMaxLevels);
+    NGP_REQUIRE(max_level <= L, "grid_encode_backward: max_level > L");
+    if (B == 0) return NGP_OK;
+    NGP_DISPATCH_DC(launch_backward, grad, inputs, offsets, grad_embeddings, B, L, max_level, lv, dy_dx,
+                    grad_inputs, gridtype, align_corners != 0, interp, as_stream(stream));
+    NGP_CHECK_LAUNCH("grid_encode_backward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_grad_total_variation(const float *inputs, const float *embeddings, float *grad,
+                                        const int32_t *offsets, float weight, uint32_t B, uint32_t D, uint32_t C,
+                                        uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                        ngp_stream_t stream)
+{
+    NGP_REQUIRE(inputs && embeddings && grad && offsets, "grad_total_variation: null tensor");
+    if (int e = check_dc("grad_total_variation", D, C)) return e;
+    LevelRes lv;
+    NGP_REQUIRE(fill_levels(lv, S, H, L), "grad_total_variation: L must be in [1, %u]", kMaxLevels);
+    if (B == 0) return NGP_OK;
+    const float w = weight / (float)(2u * D);
+    NGP_DISPATCH_DC(launch_tv, inputs, embeddings, grad, offsets, w, B, L, lv, gridtype, align_corners != 0,
+                    as_stream(stream));
+    NGP_CHECK_LAUNCH("grad_total_variation");
+    return NGP_OK;
+}
+
+extern "C" int ngp_grad_weight_decay(const float *embeddings, float *grad, const int32_t *offsets, float weight,
+                                     uint32_t B, uint32_t C, uint32_t L, ngp_stream_t stream)
+{
+    NGP_REQUIRE(embeddings && grad && offsets, "grad_weight_decay: null tensor");
+    NGP_REQUIRE(L >= 1, "grad_weight_decay: L must be >= 1");
+    const uint64_t n = (uint64_t)B * C;
+    NGP_REQUIRE(n < (1ull << 32), "grad_weight_decay: table too large");
+    if (n == 0) return NGP_OK;
+    const uint32_t blocks = min(ceil_div((uint32_t)n, kBlock), 256u * 16u);
+    grid_wd_kernel<<<dim3(blocks), kBlock, 0, as_stream(stream)>>>(embeddings, grad, offsets, weight, (uint32_t)n, C, L);
+    NGP_CHECK_LAUNCH("grad_weight_decay");
+    return NGP_OK;
+}

@@ -1,0 +1,52 @@
+// Shared host/device helpers for libngp_hip.so (gfx950 only; no CUDA dual paths).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ngp_hip.h"
+
+namespace ngp {
+
+// ---------------------------------------------------------------- error plumbing
+char *error_buffer();  // thread-local, 512 bytes (defined in capi_common.hip)
+
+#define NGP_FAIL(code, ...)                                   \
+    do {                                                      \
+        snprintf(ngp::error_buffer(), 512, __VA_ARGS__);      \
+        return (code);                                        \
+    } while (0)
+
+#define NGP_REQUIRE(cond, ...)                                \
+    do {                                                      \
+        if (!(cond)) NGP_FAIL(NGP_EINVAL, __VA_ARGS__);       \
+    } while (0)
+
+#define NGP_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) NGP_FAIL(NGP_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline hipStream_t as_stream(ngp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device helpers
+constexpr int kWave = 64;  // CDNA wavefront
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+// XCD-aware work-item remap.  Workgroups are dealt round-robin over the 8 XCDs, so the
+// blocks {b : b % 8 == k} share one XCD (and its 4 MiB L2).  This bijection hands XCD
+// group k the contiguous work-item range [k*n/8, (k+1)*n/8): items that share data
+// (one level's hash table) then share an L2.  Placement only changes speed.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n)
+{
+    const uint32_t q = n >> 3, r = n & 7u, k = bid & 7u, i = bid >> 3;
+    const uint32_t base = k < r ? k * (q + 1) : r * (q + 1) + (k - r) * q;
+    return base + i;
+}
+
+}  // namespace ngp

@@ -1,0 +1,781 @@
+// Density-grid guided ray marcher and volumetric compositor for gfx950.
+//
+// Behaviour (reference tree): raymarching/src/raymarching.cu
+//   :42-81 mip / Morton helpers     :91-145 near_far_from_aabb   :162-198 sph_from_ray
+//   :214-254 morton3D(_invert)      :267-289 packbits            :303-319 flatten_rays
+//   :337-491 march_rays_train       :519-597 / :623-712 composite_rays_train fwd / bwd
+//   :731-846 march_rays             :860-941 composite_rays
+// Differences in design: sample offsets come from a wave-ballot / prefix-sum scan in ray
+// order (deterministic; the reference's atomicAdd order is not), the arena variant marches
+// ONCE (sample start times go to a scratch slab) and expands samples with one lane per
+// sample and coalesced stores, flatten_rays is sample-parallel.  The stepping arithmetic is
+// written operation for operation like oracle/ngp_oracle.c so that per-ray sample counts
+// agree bit for bit.
+#include "ngp_common.hpp"
+
+namespace ngp {
+
+constexpr uint32_t kRayBlock = 64;   // one wave per workgroup: divergent per-ray loops
+constexpr uint32_t kFlatBlock = 256;
+constexpr float kSqrt3 = 1.7320508075688772f;
+constexpr float kRPi = 0.3183098861837907f;
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z)
+{
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t compact_bits(uint32_t x)
+{
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+// frexp exponent clamped to [0, cascades-1]
+__device__ __forceinline__ int mip_of(float mx, float cascades)
+{
+    int e;
+    frexpf(mx, &e);
+    return (int)fminf(cascades - 1.0f, fmaxf(0.0f, (float)e));
+}
+
+// ------------------------------------------------------------------ small per-ray / per-cell kernels
+__global__ void near_far_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                const float *__restrict__ aabb, uint32_t N, float min_near,
+                                float *__restrict__ nears, float *__restrict__ fars)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float tn = 0.0f, tf = 0.0f;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float o = rays_o[(size_t)n * 3 + a], r = 1.0f / rays_d[(size_t)n * 3 + a];
+        float t0 = (aabb[a] - o) * r, t1 = (aabb[3 + a] - o) * r;
+        if (t0 > t1) {
+            const float s = t0;
+            t0 = t1;
+            t1 = s;
+        }
+        if (a == 0) {
+            tn = t0;
+            tf = t1;
+        } else if (!miss) {
+            if (tn > t1 || t0 > tf) {
+                miss = true;
+            } else {
+                if (t0 > tn) tn = t0;
+                if (t1 < tf) tf = t1;
+            }
+        }
+    }
+    if (miss) {
+        nears[n] = fars[n] = 3.402823466e+38f;
+        return;
+    }
+    if (tn < min_near) tn = min_near;
+    nears[n] = tn;
+    fars[n] = tf;
+}
+
+__global__ void sph_from_ray_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float radius,
+                                    uint32_t N, float *__restrict__ coords)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[(size_t)n * 3], oy = rays_o[(size_t)n * 3 + 1], oz = rays_o[(size_t)n * 3 + 2];
+    const float dx = rays_d[(size_t)n * 3], dy = rays_d[(size_t)n * 3 + 1], dz = rays_d[(size_t)n * 3 + 2];
+    const float A = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float Bh = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+    const float Cc = fmaf(oz, oz, fmaf(oy, oy, ox * ox)) - radius * radius;
+    const float t = (-Bh + sqrtf(Bh * Bh - A * Cc)) / A;
+    const float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
+    const float theta = atan2f(sqrtf(fmaf(z, z, x * x)), y);
+    const float phi = atan2f(z, x);
+    coords[(size_t)n * 2] = 2.0f * theta * kRPi - 1.0f;
+    coords[(size_t)n * 2 + 1] = phi * kRPi;
+}
+
+__global__ void morton3D_kernel(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton3((uint32_t)coords[(size_t)n * 3], (uint32_t)coords[(size_t)n * 3 + 1],
+                                  (uint32_t)coords[(size_t)n * 3 + 2]);
+}
+
+__global__ void morton3D_invert_kernel(const int32_t *__restrict__ indices, uint32_t N, int32_t *__restrict__ coords)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t v = (uint32_t)indices[n];
+    coords[(size_t)n * 3] = (int32_t)compact_bits(v);
+    coords[(size_t)n * 3 + 1] = (int32_t)compact_bits(v >> 1);
+    coords[(size_t)n * 3 + 2] = (int32_t)compact_bits(v >> 2);
+}
+
+// one output byte per lane: two 16-byte loads in, one byte out (wave writes 64 contiguous bytes)
+__global__ void packbits_kernel(const float *__restrict__ grid, uint32_t N, float thresh, uint8_t *__restrict__ bitfield)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2];
+    const float4 b = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2 + 1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;
+    bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;
+    bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;
+    bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;
+    bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+// sample -> ray id.  The reference fills each ray's segment from one lane; here a whole wave owns
+// a ray and lane k fills elements k, k+64, ... of its segment (coalesced stores).
+__global__ void flatten_rays_kernel(const int32_t *__restrict__ rays, uint32_t N, uint32_t M, int32_t *__restrict__ res)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    if (wave >= N) return;
+    const uint32_t off = (uint32_t)rays[(size_t)wave * 2], cnt = (uint32_t)rays[(size_t)wave * 2 + 1];
+    for (uint32_t i = lane; i < cnt; i += kWave)
+        if (off + i < M) res[off + i] = (int32_t)wave;
+}
+
+// ------------------------------------------------------------------ the stepping rule
+struct Marcher {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, cascades, Hm1;
+    bool contract;
+    const uint8_t *__restrict__ grid;
+
+    __device__ __forceinline__ void setup(const float *__restrict__ o, const float *__restrict__ d, bool inference,
+                                          float bound_, bool contract_, float dt_gamma_, uint32_t max_steps,
+                                          uint32_t C, uint32_t H, const uint8_t *__restrict__ grid_)
+    {
+        ox = o[0]; oy = o[1]; oz = o[2];
+        dx = d[0]; dy = d[1]; dz = d[2];
+        if (inference) {
+            rdx = 1.0f / (dx + 1e-10f); rdy = 1.0f / (dy + 1e-10f); rdz = 1.0f / (dz + 1e-10f);
+        } else {
+            rdx = 1.0f / dx; rdy = 1.0f / dy; rdz = 1.0f / dz;
+        }
+        bound = bound_;
+        contract = contract_;
+        dt_gamma = dt_gamma_;
+        dt_min = 2.0f * kSqrt3 / (float)max_steps;
+        dt_max = 2.0f * kSqrt3 * bound_ / (float)H;
+        Hf = (float)H;
+        Hm1 = (float)(H - 1u);
+        rH = 1.0f / (float)H;
+        H3 = (float)(H * H * H);
+        cascades = (float)C;
+        grid = grid_;
+    }
+
+    // One evaluation at parameter t.  true: a sample starts at t (p = contracted position, dt its
+    // length; the caller advances t).  false: empty space was skipped, t has been advanced.
+    __device__ __forceinline__ bool probe(float &t, float &dt_out, float &px, float &py, float &pz) const
+    {
+        const float x = clampf(fmaf(t, dx, ox), -bound, bound);
+        const float y = clampf(fmaf(t, dy, oy), -bound, bound);
+        const float z = clampf(fmaf(t, dz, oz), -bound, bound);
+        float dt = clampf(t * dt_gamma, dt_min, dt_max);
+
+        const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+        const int level = max(mip_of(mag, cascades), mip_of(dt * Hf * 0.5f, cascades));
+        const float mip_bound = fminf(scalbnf(1.0f, level), bound);
+        const float mip_rbound = 1.0f / mip_bound;
+
+        float cx = x, cy = y, cz = z;
+        const bool outside = contract && mag > 1.0f;
+        if (outside) {
+            const float s = (2.0f - 1.0f / mag) / mag;
+            cx *= s; cy *= s; cz *= s;
+        }
+        const int nx = (int)clampf(0.5f * fmaf(cx, mip_rbound, 1.0f) * Hf, 0.0f, Hm1);
+        const int ny = (int)clampf(0.5f * fmaf(cy, mip_rbound, 1.0f) * Hf, 0.0f, Hm1);
+        const int nz = (int)clampf(0.5f * fmaf(cz, mip_rbound, 1.0f) * Hf, 0.0f, Hm1);
+
+        const uint32_t bit = (uint32_t)((float)level * H3 + (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        const bool occ = (grid[bit >> 3] >> (bit & 7u)) & 1u;
+
+        if (occ || outside) {
+            px = cx; py = cy; pz = cz;
+            dt_out = dt;
+            return true;
+        }
+        const float sx = copysignf(1.0f, dx), sy = copysignf(1.0f, dy), sz = copysignf(1.0f, dz);
+        const float tx = fmaf(fmaf(((float)nx + 0.5f + 0.5f * sx) * rH, 2.0f, -1.0f), mip_bound, -cx) * rdx;
+        const float ty = fmaf(fmaf(((float)ny + 0.5f + 0.5f * sy) * rH, 2.0f, -1.0f), mip_bound, -cy) * rdy;
+        const float tz = fmaf(fmaf(((float)nz + 0.5f + 0.5f * sz) * rH, 2.0f, -1.0f), mip_bound, -cz) * rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            dt = clampf(t * dt_gamma, dt_min, dt_max);
+            t += dt;
+        } while (t < tt);
+        return false;
+    }
+
+    // Position / step of the sample that STARTS at t (pure function of the ray and t); used by
+    // the arena expansion, which re-derives what probe() returned when it emitted the sample.
+    __device__ __forceinline__ void sample_at(float t, float &dt, float &px, float &py, float &pz) const
+    {
+        const float x = clampf(fmaf(t, dx, ox), -bound, bound);
+        const float y = clampf(fmaf(t, dy, oy), -bound, bound);
+        const float z = clampf(fmaf(t, dz, oz), -bound, bound);
+        dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+        px = x; py = y; pz = z;
+        if (contract && mag > 1.0f) {
+            const float s = (2.0f - 1.0f / mag) / mag;
+            px *= s; py *= s; pz *= s;
+        }
+    }
+};
+
+// ------------------------------------------------------------------ training march (reference protocol)
+// pass 1: count samples per ray (lane = ray).  MODE 0 writes rays[n,1]; MODE 1 additionally stores
+// each sample's start time to t_scratch[n*max_steps + k] (arena variant).
+template <int MODE>
+__global__ __launch_bounds__(kRayBlock) void march_count_kernel(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid, float bound,
+    bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+    const float *__restrict__ nears, const float *__restrict__ fars, const float *__restrict__ noises,
+    int32_t *__restrict__ rays, float *__restrict__ t_scratch)
+{
+    const uint32_t n = blockIdx.x * kRayBlock + threadIdx.x;
+    if (n >= N) return;
+    Marcher m;
+    m.setup(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, false, bound, contract, dt_gamma, max_steps, C, H, grid);
+    const float far = fars[n];
+    float t = nears[n];
+    t = fmaf(clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
+    uint32_t step = 0;
+    float *slab = MODE == 1 ? t_scratch + (size_t)n * max_steps : nullptr;
+    while (t < far && step < max_steps) {
+        float dt, px, py, pz;
+        if (m.probe(t, dt, px, py, pz)) {
+            if (MODE == 1) slab[step] = t;
+            t += dt;
+            step++;
+        }
+    }
+    rays[(size_t)n * 2 + 1] = (int32_t)step;
+}
+
+// Exclusive prefix sum of rays[:,1] into rays[:,0] in ray order; one workgroup of 1024 lanes
+// walks the rays in tiles (wave shuffle scan + one LDS hop per tile).
+//   reference protocol (arena == false): offsets start at the incoming counter[0]; counter[0] = end.
+//   arena (M_cap > 0): offsets start at 0; a ray is kept while offset + count <= M_cap (offsets are
+//   monotone, so the kept rays are a prefix of the batch); dropped rays get count 0.
+//   counter[0] = samples of the kept rays (<= M_cap), counter[1] = samples the batch needed.
+__global__ __launch_bounds__(1024) void march_scan_kernel(int32_t *__restrict__ rays, uint32_t N,
+                                                         int32_t *__restrict__ counter, uint32_t M_cap,
+                                                         bool arena)
+{
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry_s, kept_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    if (tid == 0) {
+        carry_s = arena ? 0u : (uint32_t)counter[0];
+        kept_s = 0u;
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < N; base += 1024u) {
+        const uint32_t n = base + tid;
+        const uint32_t cnt = n < N ? (uint32_t)rays[(size_t)n * 2 + 1] : 0u;
+        uint32_t v = cnt;  // inclusive scan inside the wave
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t up = __shfl_up(v, d, 64);
+            if (lane >= d) v += up;
+        }
+        if (lane == 63u) wave_sum[wid] = v;
+        __syncthreads();
+        uint32_t wave_off = 0, tile_total = 0;
+        for (uint32_t w = 0; w < 16u; w++) {
+            if (w < wid) wave_off += wave_sum[w];
+            tile_total += wave_sum[w];
+        }
+        const uint32_t carry = carry_s;
+        const uint32_t off = carry + wave_off + v - cnt;
+        if (n < N) {
+            if (!arena) {
+                rays[(size_t)n * 2] = (int32_t)off;
+            } else {
+                const bool keep = off + cnt <= M_cap;
+                rays[(size_t)n * 2] = (int32_t)(keep ? off : M_cap);
+                if (keep)
+                    atomicAdd(&kept_s, cnt);
+                else
+                    rays[(size_t)n * 2 + 1] = 0;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) carry_s = carry + tile_total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (arena) {
+            counter[0] = (int32_t)kept_s;
+            counter[1] = (int32_t)carry_s;
+        } else {
+            counter[0] = (int32_t)carry_s;
+        }
+    }
+}
+
+// pass 2 of the reference protocol: re-march and write (lane = ray, like the reference).
+__global__ __launch_bounds__(kRayBlock) void march_write_kernel(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ rays_ldir,
+    const uint8_t *__restrict__ grid, float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N,
+    uint32_t C, uint32_t H, const float *__restrict__ nears, const float *__restrict__ fars,
+    const float *__restrict__ noises, const int32_t *__restrict__ rays, float *__restrict__ xyzs,
+    float *__restrict__ dirs, float *__restrict__ ts, float *__restrict__ ldirs)
+{
+    const uint32_t n = blockIdx.x * kRayBlock + threadIdx.x;
+    if (n >= N) return;
+    Marcher m;
+    m.setup(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, false, bound, contract, dt_gamma, max_steps, C, H, grid);
+    const uint32_t off = (uint32_t)rays[(size_t)n * 2], budget = (uint32_t)rays[(size_t)n * 2 + 1];
+    float lx = 0, ly = 0, lz = 0;
+    if (rays_ldir) {
+        lx = rays_ldir[(size_t)n * 3]; ly = rays_ldir[(size_t)n * 3 + 1]; lz = rays_ldir[(size_t)n * 3 + 2];
+    }
+    const float far = fars[n];
+    float t = nears[n];
+    t = fmaf(clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
+    uint32_t step = 0;
+    while (t < far && step < budget) {
+        float dt, px, py, pz;
+        if (m.probe(t, dt, px, py, pz)) {
+            t += dt;
+            const size_t i = (size_t)off + step;
+            xyzs[i * 3] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
+            dirs[i * 3] = m.dx; dirs[i * 3 + 1] = m.dy; dirs[i * 3 + 2] = m.dz;
+            ts[i * 2] = t; ts[i * 2 + 1] = dt;
+            if (ldirs) {
+                ldirs[i * 3] = lx; ldirs[i * 3 + 1] = ly; ldirs[i * 3 + 2] = lz;
+            }
+            step++;
+        }
+    }
+}
+
+// arena expansion: one WAVE per ray, lanes stride over that ray's samples; every output array is
+// written with consecutive lanes on consecutive samples (coalesced), nothing is re-marched.
+__global__ __launch_bounds__(256) void march_expand_kernel(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ rays_ldir,
+    float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+    const int32_t *__restrict__ rays, const float *__restrict__ t_scratch, float *__restrict__ xyzs,
+    float *__restrict__ dirs, float *__restrict__ ts, float *__restrict__ ldirs, int32_t *__restrict__ ray_idx)
+{
+    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[(size_t)n * 2], cnt = (uint32_t)rays[(size_t)n * 2 + 1];
+    if (cnt == 0) return;
+    Marcher m;
+    m.setup(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, false, bound, contract, dt_gamma, max_steps, C, H, nullptr);
+    float lx = 0, ly = 0, lz = 0;
+    if (rays_ldir) {
+        lx = rays_ldir[(size_t)n * 3]; ly = rays_ldir[(size_t)n * 3 + 1]; lz = rays_ldir[(size_t)n * 3 + 2];
+    }
+    const float *slab = t_scratch + (size_t)n * max_steps;
+    for (uint32_t k = lane; k < cnt; k += kWave) {
+        const float t = slab[k];
+        float dt, px, py, pz;
+        m.sample_at(t, dt, px, py, pz);
+        const size_t i = (size_t)off + k;
+        xyzs[i * 3] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
+        dirs[i * 3] = m.dx; dirs[i * 3 + 1] = m.dy; dirs[i * 3 + 2] = m.dz;
+        ts[i * 2] = t + dt; ts[i * 2 + 1] = dt;
+        if (ldirs) {
+            ldirs[i * 3] = lx; ldirs[i * 3 + 1] = ly; ldirs[i * 3 + 2] = lz;
+        }
+        if (ray_idx) ray_idx[i] = (int32_t)n;
+    }
+}
+
+// ------------------------------------------------------------------ compositing (training)
+__global__ __launch_bounds__(kRayBlock) void composite_train_forward_kernel(
+    const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ ts,
+    const int32_t *__restrict__ rays, uint32_t M, uint32_t N, float T_thresh, float *__restrict__ weights,
+    float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image)
+{
+    const uint32_t n = blockIdx.x * kRayBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[(size_t)n * 2], cnt = (uint32_t)rays[(size_t)n * 2 + 1];
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0;
+    if (cnt != 0 && off + cnt <= M) {
+        for (uint32_t i = off; i < off + cnt; i++) {
+            const float2 tt = reinterpret_cast<const float2 *>(ts)[i];
+            const float alpha = 1.0f - __expf(-sigmas[i] * tt.y);
+            const float w = alpha * T;
+            weights[i] = w;
+            r = fmaf(w, rgbs[(size_t)i * 3], r);
+            g = fmaf(w, rgbs[(size_t)i * 3 + 1], g);
+            b = fmaf(w, rgbs[(size_t)i * 3 + 2], b);
+            ws += w;
+            d = fmaf(w, tt.x, d);
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+        }
+    }
+    weights_sum[n] = ws;
+    depth[n] = d;
+    image[(size_t)n * 3] = r;
+    image[(size_t)n * 3 + 1] = g;
+    image[(size_t)n * 3 + 2] = b;
+}
+
+__global__ __launch_bounds__(kRayBlock) void composite_train_backward_kernel(
+    const float *__restrict__ grad_weights, const float *__restrict__ grad_weights_sum,
+    const float *__restrict__ grad_depth, const float *__restrict__ grad_image, const float *__restrict__ sigmas,
+    const float *__restrict__ rgbs, const float *__restrict__ ts, const int32_t *__restrict__ rays,
+    const float *__restrict__ weights_sum, const float *__restrict__ depth, const float *__restrict__ image, uint32_t M,
+    uint32_t N, float T_thresh, float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs)
+{
+    const uint32_t n = blockIdx.x * kRayBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[(size_t)n * 2], cnt = (uint32_t)rays[(size_t)n * 2 + 1];
+    if (cnt == 0 || off + cnt > M) return;
+    const float gr = grad_image[(size_t)n * 3], gg = grad_image[(size_t)n * 3 + 1], gb = grad_image[(size_t)n * 3 + 2];
+    const float gws = grad_weights_sum[n], gd = grad_depth[n];
+    const float rF = image[(size_t)n * 3], gF = image[(size_t)n * 3 + 1], bF = image[(size_t)n * 3 + 2];
+    const float wsF = weights_sum[n], dF = depth[n];
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0;
+    for (uint32_t i = off; i < off + cnt; i++) {
+        const float2 tt = reinterpret_cast<const float2 *>(ts)[i];
+        const float dt = tt.y, tm = tt.x;
+        const float c0 = rgbs[(size_t)i * 3], c1 = rgbs[(size_t)i * 3 + 1], c2 = rgbs[(size_t)i * 3 + 2];
+        const float alpha = 1.0f - __expf(-sigmas[i] * dt);
+        const float w = alpha * T;
+        r = fmaf(w, c0, r);
+        g = fmaf(w, c1, g);
+        b = fmaf(w, c2, b);
+        ws += w;
+        d = fmaf(w, tm, d);
+        T *= 1.0f - alpha;  // the closed form below uses T after the update (raymarching.cu:681-696)
+        grad_rgbs[(size_t)i * 3] = gr * w;
+        grad_rgbs[(size_t)i * 3 + 1] = gg * w;
+        grad_rgbs[(size_t)i * 3 + 2] = gb * w;
+        float s = gr * fmaf(T, c0, -(rF - r));
+        s = fmaf(gg, fmaf(T, c1, -(gF - g)), s);
+        s = fmaf(gb, fmaf(T, c2, -(bF - b)), s);
+        s = fmaf(gws + grad_weights[i], T - (wsF - ws), s);
+        s = fmaf(gd, fmaf(T, tm, -(dF - d)), s);
+        grad_sigmas[i] = dt * s;
+        if (T < T_thresh) break;
+    }
+}
+
+// ------------------------------------------------------------------ inference pair
+__global__ __launch_bounds__(kRayBlock) void march_rays_kernel(
+    uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive, const float *__restrict__ rays_t,
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound, bool contract, float dt_gamma,
+    uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *__restrict__ grid, const float *__restrict__ fars,
+    float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ ts, const float *__restrict__ noises)
+{
+    const uint32_t n = blockIdx.x * kRayBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t ray = (uint32_t)rays_alive[n];
+    Marcher m;
+    m.setup(rays_o + (size_t)ray * 3, rays_d + (size_t)ray * 3, true, bound, contract, dt_gamma, max_steps, C, H, grid);
+    const float far = fars[ray];
+    float t = rays_t[ray];
+    t = fmaf(clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
+    uint32_t step = 0;
+    const size_t base = (size_t)n * n_step;
+    while (t < far && step < n_step) {
+        float dt, px, py, pz;
+        if (m.probe(t, dt, px, py, pz)) {
+            t += dt;
+            const size_t i = base + step;
+            xyzs[i * 3] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
+            dirs[i * 3] = m.dx; dirs[i * 3 + 1] = m.dy; dirs[i * 3 + 2] = m.dz;
+            ts[i * 2] = t; ts[i * 2 + 1] = dt;
+            step++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kRayBlock) void composite_rays_kernel(
+    uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
+    const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ ts,
+    float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image)
+{
+    const uint32_t n = blockIdx.x * kRayBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t ray = (uint32_t)rays_alive[n];
+    const size_t base = (size_t)n * n_step;
+    float t = 0.0f;
+    float d = depth[ray], r = image[(size_t)ray * 3], g = image[(size_t)ray * 3 + 1], b = image[(size_t)ray * 3 + 2];
+    float ws = weights_sum[ray];
+    uint32_t step = 0;
+    while (step < n_step) {
+        const size_t i = base + step;
+        const float2 tt = reinterpret_cast<const float2 *>(ts)[i];
+        if (tt.x == 0.0f) break;
+        const float alpha = 1.0f - __expf(-sigmas[i] * tt.y);
+        const float T = 1.0f - ws;
+        const float w = alpha * T;
+        ws += w;
+        t = tt.x;
+        d = fmaf(w, t, d);
+        r = fmaf(w, rgbs[i * 3], r);
+        g = fmaf(w, rgbs[i * 3 + 1], g);
+        b = fmaf(w, rgbs[i * 3 + 2], b);
+        if (T < T_thresh) break;
+        step++;
+    }
+    if (step < n_step)
+        rays_alive[n] = -1;
+    else
+        rays_t[ray] = t;
+    weights_sum[ray] = ws;
+    depth[ray] = d;
+    image[(size_t)ray * 3] = r;
+    image[(size_t)ray * 3 + 1] = g;
+    image[(size_t)ray * 3 + 2] = b;
+}
+
+// ------------------------------------------------------------------ ray gradients (segment sums)
+// one wave per ray: lanes stride over the ray's samples, then a butterfly reduction
+__global__ __launch_bounds__(256) void march_train_backward_kernel(
+    const float *__restrict__ grad_xyzs, const float *__restrict__ grad_dirs, const float *__restrict__ ts,
+    const int32_t *__restrict__ rays, uint32_t N, uint32_t M, float *__restrict__ grad_rays_o,
+    float *__restrict__ grad_rays_d)
+{
+    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[(size_t)n * 2], cnt = (uint32_t)rays[(size_t)n * 2 + 1];
+    float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0};
+    if (off + cnt <= M) {
+        for (uint32_t k = lane; k < cnt; k += kWave) {
+            const size_t i = (size_t)off + k;
+            const float t = ts[i * 2];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float gx = grad_xyzs[i * 3 + c];
+                so[c] += gx;
+                sd[c] += gx * t + (grad_dirs ? grad_dirs[i * 3 + c] : 0.0f);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            so[c] += __shfl_xor(so[c], d, 64);
+            sd[c] += __shfl_xor(sd[c], d, 64);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            grad_rays_o[(size_t)n * 3 + c] = so[c];
+            grad_rays_d[(size_t)n * 3 + c] = sd[c];
+        }
+    }
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+#define NGP_1D(n, blk) dim3(ceil_div((n), (blk))), dim3(blk), 0, as_stream(stream)
+
+extern "C" int ngp_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
+                                      float min_near, float *nears, float *fars, ngp_stream_t stream)
+{
+    NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null tensor");
+    if (N == 0) return NGP_OK;
+    near_far_kernel<<<NGP_1D(N, 256u)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+    NGP_CHECK_LAUNCH("near_far_from_aabb");
+    return NGP_OK;
+}
+
+extern "C" int ngp_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
+                                ngp_stream_t stream)
+{
+    NGP_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null tensor");
+    if (N == 0) return NGP_OK;
+    sph_from_ray_kernel<<<NGP_1D(N, 256u)>>>(rays_o, rays_d, radius, N, coords);
+    NGP_CHECK_LAUNCH("sph_from_ray");
+    return NGP_OK;
+}
+
+extern "C" int ngp_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, ngp_stream_t stream)
+{
+    NGP_REQUIRE(coords && indices, "morton3D: null tensor");
+    if (N == 0) return NGP_OK;
+    morton3D_kernel<<<NGP_1D(N, 256u)>>>(coords, N, indices);
+    NGP_CHECK_LAUNCH("morton3D");
+    return NGP_OK;
+}
+
+extern "C" int ngp_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, ngp_stream_t stream)
+{
+    NGP_REQUIRE(coords && indices, "morton3D_invert: null tensor");
+    if (N == 0) return NGP_OK;
+    morton3D_invert_kernel<<<NGP_1D(N, 256u)>>>(indices, N, coords);
+    NGP_CHECK_LAUNCH("morton3D_invert");
+    return NGP_OK;
+}
+
+extern "C" int ngp_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield,
+                            ngp_stream_t stream)
+{
+    NGP_REQUIRE(grid && bitfield, "packbits: null tensor");
+    NGP_REQUIRE(((uintptr_t)grid & 15u) == 0, "packbits: grid must be 16-byte aligned");
+    if (N == 0) return NGP_OK;
+    packbits_kernel<<<NGP_1D(N, 256u)>>>(grid, N, density_thresh, bitfield);
+    NGP_CHECK_LAUNCH("packbits");
+    return NGP_OK;
+}
+
+extern "C" int ngp_flatten_rays(const int32_t *rays, uint32_t N, uint32_t M, int32_t *res, ngp_stream_t stream)
+{
+    NGP_REQUIRE(rays && res, "flatten_rays: null tensor");
+    if (N == 0) return NGP_OK;
+    flatten_rays_kernel<<<dim3(ceil_div(N, kFlatBlock / kWave)), dim3(kFlatBlock), 0, as_stream(stream)>>>(rays, N, M, res);
+    NGP_CHECK_LAUNCH("flatten_rays");
+    return NGP_OK;
+}
+
+extern "C" int ngp_march_rays_train(const float *rays_o, const float *rays_d, const float *rays_ldir,
+                                    const uint8_t *grid, float bound, int contract, float dt_gamma,
+                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears,
+                                    const float *fars, float *xyzs, float *dirs, float *ts, float *ldirs,
+                                    int32_t *rays, int32_t *counter, const float *noises, ngp_stream_t stream)
+{
+    NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises, "march_rays_train: null tensor");
+    NGP_REQUIRE(max_steps > 0 && H > 0 && C > 0, "march_rays_train: max_steps, C and H must be positive");
+    if (N == 0) return NGP_OK;
+    if (xyzs == nullptr) {
+        march_count_kernel<0><<<NGP_1D(N, kRayBlock)>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N,
+                                                       C, H, nears, fars, noises, rays, nullptr);
+        march_scan_kernel<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(rays, N, counter, 0u, false);
+    } else {
+        NGP_REQUIRE(dirs && ts, "march_rays_train: dirs / ts missing in the write pass");
+        NGP_REQUIRE(!rays_ldir || ldirs, "march_rays_train: rays_ldir given without an ldirs output");
+        march_write_kernel<<<NGP_1D(N, kRayBlock)>>>(rays_o, rays_d, rays_ldir, grid, bound, contract != 0, dt_gamma,
+                                                    max_steps, N, C, H, nears, fars, noises, rays, xyzs, dirs, ts,
+                                                    rays_ldir ? ldirs : nullptr);
+    }
+    NGP_CHECK_LAUNCH("march_rays_train");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const float *rays_ldir,
+                                            const uint8_t *grid, float bound, int contract, float dt_gamma,
+                                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                            const float *nears, const float *fars, const float *noises,
+                                            float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
+                                            float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
+                                            ngp_stream_t stream)
+{
+    NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && t_scratch && xyzs && dirs && ts,
+                "march_rays_train_arena: null tensor");
+    NGP_REQUIRE(max_steps > 0 && H > 0 && C > 0 && M_cap > 0, "march_rays_train_arena: bad sizes");
+    if (N == 0) return NGP_OK;
+    march_count_kernel<1><<<NGP_1D(N, kRayBlock)>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C,
+                                                   H, nears, fars, noises, rays, t_scratch);
+    march_scan_kernel<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(rays, N, counter, M_cap, true);
+    march_expand_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
+        rays_o, rays_d, rays_ldir, bound, contract != 0, dt_gamma, max_steps, N, C, H, rays, t_scratch, xyzs, dirs, ts,
+        rays_ldir ? ldirs : nullptr, ray_idx);
+    NGP_CHECK_LAUNCH("march_rays_train_arena");
+    return NGP_OK;
+}
+
+extern "C" int ngp_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *ts,
+                                                const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                                float *weights, float *weights_sum, float *depth, float *image,
+                                                ngp_stream_t stream)
+{
+    NGP_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null tensor");
+    NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && weights), "composite_rays_train_forward: null sample tensor");
+    if (N == 0) return NGP_OK;
+    composite_train_forward_kernel<<<NGP_1D(N, kRayBlock)>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum,
+                                                            depth, image);
+    NGP_CHECK_LAUNCH("composite_rays_train_forward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_composite_rays_train_backward(const float *grad_weights, const float *grad_weights_sum,
+                                                 const float *grad_depth, const float *grad_image,
+                                                 const float *sigmas, const float *rgbs, const float *ts,
+                                                 const int32_t *rays, const float *weights_sum, const float *depth,
+                                                 const float *image, uint32_t M, uint32_t N, float T_thresh,
+                                                 float *grad_sigmas, float *grad_rgbs, ngp_stream_t stream)
+{
+    NGP_REQUIRE(grad_weights_sum && grad_depth && grad_image && rays && weights_sum && depth && image,
+                "composite_rays_train_backward: null tensor");
+    if (N == 0 || M == 0) return NGP_OK;
+    NGP_REQUIRE(grad_weights && sigmas && rgbs && ts && grad_sigmas && grad_rgbs,
+                "composite_rays_train_backward: null sample tensor");
+    composite_train_backward_kernel<<<NGP_1D(N, kRayBlock)>>>(grad_weights, grad_weights_sum, grad_depth, grad_image, sigmas,
+                                                             rgbs, ts, rays, weights_sum, depth, image, M, N, T_thresh,
+                                                             grad_sigmas, grad_rgbs);
+    NGP_CHECK_LAUNCH("composite_rays_train_backward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                              const float *rays_o, const float *rays_d, float bound, int contract, float dt_gamma,
+                              uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid, const float *nears,
+                              const float *fars, float *xyzs, float *dirs, float *ts, const float *noises,
+                              ngp_stream_t stream)
+{
+    (void)nears;
+    if (n_alive == 0 || n_step == 0) return NGP_OK;
+    NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && ts && noises,
+                "march_rays: null tensor");
+    march_rays_kernel<<<NGP_1D(n_alive, kRayBlock)>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
+                                                     contract != 0, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, ts,
+                                                     noises);
+    NGP_CHECK_LAUNCH("march_rays");
+    return NGP_OK;
+}
+
+extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive,
+                                  float *rays_t, const float *sigmas, const float *rgbs, const float *ts,
+                                  float *weights_sum, float *depth, float *image, ngp_stream_t stream)
+{
+    if (n_alive == 0) return NGP_OK;
+    NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && ts && weights_sum && depth && image, "composite_rays: null tensor");
+    composite_rays_kernel<<<NGP_1D(n_alive, kRayBlock)>>>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, ts,
+                                                         weights_sum, depth, image);
+    NGP_CHECK_LAUNCH("composite_rays");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const float *ts,
+                                               const int32_t *rays, uint32_t N, uint32_t M, float *grad_rays_o,
+                                               float *grad_rays_d, ngp_stream_t stream)
+{
+    NGP_REQUIRE(rays && grad_rays_o && grad_rays_d, "march_rays_train_backward: null tensor");
+    NGP_REQUIRE(M == 0 || (grad_xyzs && ts), "march_rays_train_backward: null sample tensor");
+    if (N == 0) return NGP_OK;
+    march_train_backward_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(grad_xyzs, grad_dirs, ts, rays, N,
+                                                                                          M, grad_rays_o, grad_rays_d);
+    NGP_CHECK_LAUNCH("march_rays_train_backward");
+    return NGP_OK;
+}

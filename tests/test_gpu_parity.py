@@ -1,0 +1,440 @@
+"""GPU parity: every C-ABI entry point (called through the `_backend` shims, i.e. exactly what the
+op wrappers call) against the CPU oracle on the same seeded inputs.
+
+Bars: integer / byte / index outputs bit-exact; float outputs within the tolerance written next
+to each check (fp32 kernels; differences come from fma/evaluation order, `__expf` and -- for the
+scatter-add -- the order of float atomics)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_oracle_raymarching import brick_bitfield, make_rays, synth_samples  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def be():
+    from raw_ngp_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- grid encoder
+
+GRID_CASES = [
+    # D, C, L, H, log2T, desired, gridtype, align, interp, B
+    (3, 2, 16, 16, 19, 2048, 0, False, 0, 20000),     # the north-star configuration
+    (3, 2, 16, 16, 19, 4096, 0, False, 0, 4097),      # bound 2 table, ragged B
+    (3, 2, 8, 16, 19, 2048, 0, False, 0, 5000),       # plumbing config (L=8)
+    (3, 2, 5, 16, 17, 128, 0, False, 1, 3000),        # proposal grid, smoothstep
+    (2, 4, 6, 4, 9, 64, 0, True, 0, 1000),
+    (3, 1, 6, 4, 9, 64, 1, False, 0, 1000),           # tiled
+    (3, 8, 4, 4, 10, 32, 0, True, 1, 777),
+    (4, 2, 4, 4, 10, 16, 0, False, 0, 500),
+    (5, 2, 3, 3, 10, 8, 0, False, 0, 300),
+    (3, 16, 3, 4, 9, 16, 0, False, 0, 300),
+    (3, 32, 2, 4, 9, 8, 0, False, 0, 200),
+]
+
+
+def grid_setup(orc, D, C, L, H, log2T, desired, B, seed=0):
+    rng = np.random.default_rng(seed)
+    offsets, scale = orc.grid_offsets(input_dim=D, num_levels=L, level_dim=C, base_resolution=H,
+                                      log2_hashmap_size=log2T, desired_resolution=desired)
+    S = float(np.log2(scale))
+    table = rng.uniform(-1, 1, (offsets[-1], C)).astype(np.float32)
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2, 0] = -1e-3      # outside -> zeros
+    x[3, D - 1] = 1.0001
+    x[4] = 0.5           # exactly on cell boundaries of power-of-two levels
+    return offsets, S, table, x
+
+
+@pytest.mark.parametrize("case", GRID_CASES, ids=lambda c: f"D{c[0]}C{c[1]}L{c[2]}g{c[6]}a{int(c[7])}i{c[8]}")
+def test_grid_forward_and_jacobian(be, orc, case):
+    D, C, L, H, log2T, desired, gridtype, align, interp, B = case
+    offsets, S, table, x = grid_setup(orc, D, C, L, H, log2T, desired, B)
+    ref, ref_j = orc.grid_encode_forward(x, table, offsets, B, D, C, L, L, S, H, True, gridtype, align, interp)
+    out = torch.empty(L, B, C, device="cuda")
+    jac = torch.empty(B, L * D * C, device="cuda")
+    be.gridencoder_backend.grid_encode_forward(dev(x), dev(table), dev(offsets), out, B, D, C, L, L, S, H, jac,
+                                               gridtype, align, interp)
+    # identical operation order in both -> agreement to rounding of the last fma
+    np.testing.assert_allclose(host(out), ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(host(jac), ref_j, rtol=1e-5, atol=1e-3 * np.abs(ref_j).max())
+    # without dy_dx, and with max_level < L (tail pre-zeroed by the caller)
+    out2 = torch.zeros(L, B, C, device="cuda")
+    be.gridencoder_backend.grid_encode_forward(dev(x), dev(table), dev(offsets), out2, B, D, C, L, L - 1, S, H, None,
+                                               gridtype, align, interp)
+    np.testing.assert_allclose(host(out2)[:L - 1], ref[:L - 1], rtol=1e-6, atol=1e-6)
+    assert torch.all(out2[L - 1] == 0)
+
+
+@pytest.mark.parametrize("case", GRID_CASES[:7], ids=lambda c: f"D{c[0]}C{c[1]}L{c[2]}g{c[6]}")
+def test_grid_backward(be, orc, case):
+    D, C, L, H, log2T, desired, gridtype, align, interp, B = case
+    offsets, S, table, x = grid_setup(orc, D, C, L, H, log2T, desired, B, seed=1)
+    rng = np.random.default_rng(2)
+    g = rng.normal(size=(L, B, C)).astype(np.float32)
+    _, jac = orc.grid_encode_forward(x, table, offsets, B, D, C, L, L, S, H, True, gridtype, align, interp)
+    ref_gt, ref_gi = orc.grid_encode_backward(g, x, table, offsets, B, D, C, L, L, S, H, jac, gridtype, align, interp)
+    gt = torch.zeros(int(offsets[-1]), C, device="cuda")
+    gi = torch.zeros(B, D, device="cuda")
+    be.gridencoder_backend.grid_encode_backward(dev(g), dev(x), dev(table), dev(offsets), gt, B, D, C, L, L, S, H,
+                                                dev(jac), gi, gridtype, align, interp)
+    # float atomics in hardware order vs a double-precision sum: error ~ eps * sum|terms|
+    scale = np.abs(ref_gt).max()
+    np.testing.assert_allclose(host(gt), ref_gt, rtol=1e-4, atol=2e-6 * max(scale, 1.0) * 8)
+    np.testing.assert_allclose(host(gi), ref_gi, rtol=1e-5, atol=1e-4 * np.abs(ref_gi).max())
+
+
+def test_grid_tv_and_wd(be, orc):
+    D, C, L, H = 3, 2, 6, 4
+    offsets, S, table, _ = grid_setup(orc, D, C, L, H, 9, 48, 16)
+    rng = np.random.default_rng(3)
+    B = 4000
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    g0 = rng.normal(size=table.shape).astype(np.float32)
+    ref = orc.grad_total_variation(x, table, g0, offsets, 1e-2, B, D, C, L, S, H)
+    g = dev(g0)
+    be.gridencoder_backend.grad_total_variation(dev(x), dev(table), g, dev(offsets), 1e-2, B, D, C, L, S, H, 0, False)
+    np.testing.assert_allclose(host(g), ref, rtol=1e-4, atol=1e-5)
+    n = int(offsets[-1])
+    ref = orc.grad_weight_decay(table, g0, offsets, 0.1, n, C, L)
+    g = dev(g0)
+    be.gridencoder_backend.grad_weight_decay(dev(table), g, dev(offsets), 0.1, n, C, L)
+    np.testing.assert_allclose(host(g), ref, rtol=1e-6, atol=1e-7)
+
+
+def test_grid_rejects_bad_arguments(be):
+    t = torch.zeros(8, 3, device="cuda")
+    off = torch.zeros(3, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="C must be"):
+        be.gridencoder_backend.grid_encode_forward(t, torch.zeros(8, 3, device="cuda"), off, t, 8, 3, 3, 2, 2, 1.0, 4,
+                                                   None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="D must be"):
+        be.gridencoder_backend.grid_encode_forward(t, torch.zeros(8, 2, device="cuda"), off, t, 8, 6, 2, 2, 2, 1.0, 4,
+                                                   None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        be.gridencoder_backend.grid_encode_forward(t.t(), torch.zeros(8, 2, device="cuda"), off, t, 8, 3, 2, 2, 2, 1.0,
+                                                   4, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        be.gridencoder_backend.grid_encode_forward(t.cpu(), torch.zeros(8, 2, device="cuda"), off, t, 8, 3, 2, 2, 2,
+                                                   1.0, 4, None, 0, False, 0)
+
+
+# ----------------------------------------------------------------------------- SH / freq
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_forward_backward(be, orc, degree):
+    rng = np.random.default_rng(degree)
+    B = 5000
+    v = rng.normal(size=(B, 3))
+    v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    v[:3] = [[0, 0, 1], [1, 0, 0], [0, -1, 0]]
+    ref, ref_j = orc.sh_encode_forward(v, B, 3, degree, True)
+    n = degree * degree
+    out = torch.empty(B, n, device="cuda")
+    jac = torch.empty(B, 3 * n, device="cuda")
+    be.shencoder_backend.sh_encode_forward(dev(v), out, B, 3, degree, jac)
+    # fp32 Horner vs the oracle's double evaluation: a few ulp of the largest monomial
+    np.testing.assert_allclose(host(out), ref, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(host(jac), ref_j, rtol=1e-5, atol=2e-5)
+    out2 = torch.empty(B, n, device="cuda")
+    be.shencoder_backend.sh_encode_forward(dev(v), out2, B, 3, degree, None)
+    assert torch.equal(out, out2)
+    g = rng.normal(size=(B, n)).astype(np.float32)
+    ref_gi = orc.sh_encode_backward(g, v, B, 3, degree, ref_j)
+    gi = torch.zeros(B, 3, device="cuda")
+    be.shencoder_backend.sh_encode_backward(dev(g), dev(v), B, 3, degree, jac, gi)
+    np.testing.assert_allclose(host(gi), ref_gi, rtol=1e-4, atol=1e-4 * np.abs(ref_gi).max())
+
+
+def test_sh_rejects_bad_degree(be):
+    t = torch.zeros(4, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="degree"):
+        be.shencoder_backend.sh_encode_forward(t, torch.zeros(4, 81, device="cuda"), 4, 3, 9, None)
+
+
+def test_freq(be, orc):
+    rng = np.random.default_rng(0)
+    B, D, deg = 3000, 3, 6
+    C = D + 2 * D * deg
+    x = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+    ref = orc.freq_encode_forward(x, B, D, deg, C)
+    out = torch.empty(B, C, device="cuda")
+    be.freqencoder_backend.freq_encode_forward(dev(x), B, D, deg, C, out)
+    np.testing.assert_allclose(host(out), ref, rtol=1e-5, atol=2e-6)
+    g = rng.normal(size=(B, C)).astype(np.float32)
+    ref_gi = orc.freq_encode_backward(g, ref, B, D, deg, C)
+    gi = torch.zeros(B, D, device="cuda")
+    be.freqencoder_backend.freq_encode_backward(dev(g), dev(ref), B, D, deg, C, gi)
+    np.testing.assert_allclose(host(gi), ref_gi, rtol=1e-5, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- integer kernels (bit-exact)
+
+def test_morton_packbits_flatten_bit_exact(be, orc):
+    H = 128
+    g = np.arange(H, dtype=np.int32)
+    coords = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    idx = torch.empty(H ** 3, dtype=torch.int32, device="cuda")
+    be.raymarching_backend.morton3D(dev(coords), H ** 3, idx)
+    assert np.array_equal(host(idx), orc.morton3D(coords))
+    back = torch.empty(H ** 3, 3, dtype=torch.int32, device="cuda")
+    be.raymarching_backend.morton3D_invert(idx, H ** 3, back)
+    assert np.array_equal(host(back), coords)
+
+    rng = np.random.default_rng(0)
+    grid = rng.uniform(-1, 2, (2, H ** 3)).astype(np.float32)
+    grid[0, :6] = [0.5, np.nextafter(np.float32(0.5), np.float32(1)), np.nan, np.inf, -np.inf, 0.4999999]
+    bits = torch.empty(2 * H ** 3 // 8, dtype=torch.uint8, device="cuda")
+    be.raymarching_backend.packbits(dev(grid), 2 * H ** 3 // 8, 0.5, bits)
+    assert np.array_equal(host(bits), orc.packbits(grid, 0.5))
+    assert np.array_equal(host(bits), np.packbits(grid.reshape(-1) > np.float32(0.5), bitorder="little"))
+
+    cnt = rng.integers(0, 200, 500).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt[:-1])]).astype(np.int32)
+    rays = np.stack([off, cnt], 1).astype(np.int32)
+    M = int(cnt.sum())
+    res = torch.zeros(M, dtype=torch.int32, device="cuda")
+    be.raymarching_backend.flatten_rays(dev(rays), 500, M, res)
+    assert np.array_equal(host(res), orc.flatten_rays(rays, M))
+
+
+def test_near_far_and_sph(be, orc):
+    rng = np.random.default_rng(1)
+    N = 5000
+    o, d = make_rays(rng, N)
+    d[:500] = rng.normal(size=(500, 3)).astype(np.float32)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], dtype=np.float32)
+    rn, rf = orc.near_far_from_aabb(o, d, aabb, N, 0.05)
+    nears = torch.empty(N, device="cuda")
+    fars = torch.empty(N, device="cuda")
+    be.raymarching_backend.near_far_from_aabb(dev(o), dev(d), dev(aabb), N, 0.05, nears, fars)
+    assert np.array_equal(host(nears), rn) and np.array_equal(host(fars), rf)   # same IEEE ops -> bit-exact
+    o2 = rng.uniform(-0.5, 0.5, (N, 3)).astype(np.float32)
+    ref = orc.sph_from_ray(o2, d, 3.0, N)
+    c = torch.empty(N, 2, device="cuda")
+    be.raymarching_backend.sph_from_ray(dev(o2), dev(d), 3.0, N, c)
+    np.testing.assert_allclose(host(c), ref, atol=2e-6)    # atan2f implementations differ by ulps
+
+
+# ----------------------------------------------------------------------------- training march
+
+MARCH_CASES = [
+    # N, H, max_steps, C, bound, contract, dt_gamma, ldir
+    (4096, 128, 1024, 1, 1.0, False, 0.0, False),       # north-star
+    (1000, 128, 1024, 2, 2.0, False, 0.0, True),        # reference default bound, light dirs
+    (777, 64, 512, 3, 4.0, False, 1.0 / 128, False),    # cone stepping, 3 cascades
+    (500, 64, 256, 2, 8.0, True, 0.0, False),           # contraction
+]
+
+
+def march_inputs(orc, case, seed=0):
+    N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
+    rng = np.random.default_rng(seed)
+    bits, _ = brick_bitfield(orc, H, cascades=C, seed=seed, fill=0.08)
+    o, d = make_rays(rng, N, radius=2.5 * bound if not contract else 3.0, jitter=0.6 * bound if not contract else 0.5)
+    aabb = np.array([-bound] * 3 + [bound] * 3, dtype=np.float32)
+    nears, fars = orc.near_far_from_aabb(o, d, aabb, N, 0.05)
+    noises = rng.uniform(0, 1, N).astype(np.float32)
+    ld = rng.normal(size=(N, 3)).astype(np.float32) if ldir else None
+    return bits, o, d, ld, nears, fars, noises
+
+
+@pytest.mark.parametrize("case", MARCH_CASES, ids=lambda c: f"N{c[0]}H{c[1]}C{c[3]}b{c[4]}c{int(c[5])}g{c[6] > 0}")
+def test_march_rays_train_two_pass(be, orc, case):
+    N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
+    bits, o, d, ld, nears, fars, noises = march_inputs(orc, case)
+    rx, rd, rt, rrays, rl, M = orc.march_rays_train(o, d, ld, bits, bound, contract, dt_gamma, max_steps, C, H, nears,
+                                                    fars, noises)
+    assert M > 0
+    rays = torch.empty(N, 2, dtype=torch.int32, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    targs = (dev(o), dev(d), dev(ld) if ldir else None, dev(bits), bound, contract, dt_gamma, max_steps, N, C, H,
+             dev(nears), dev(fars))
+    be.raymarching_backend.march_rays_train(*targs, None, None, None, None, rays, counter, dev(noises))
+    assert int(counter.item()) == M
+    assert np.array_equal(host(rays), rrays)                       # counts AND ray-ordered offsets, bit-exact
+    xyzs = torch.zeros(M, 3, device="cuda")
+    dirs = torch.zeros(M, 3, device="cuda")
+    ts = torch.zeros(M, 2, device="cuda")
+    ldirs = torch.zeros(M, 3, device="cuda") if ldir else None
+    be.raymarching_backend.march_rays_train(*targs, xyzs, dirs, ts, ldirs, rays, counter, dev(noises))
+    assert np.array_equal(host(xyzs), rx) and np.array_equal(host(dirs), rd) and np.array_equal(host(ts), rt)
+    if ldir:
+        assert np.array_equal(host(ldirs), rl)
+
+
+@pytest.mark.parametrize("case", MARCH_CASES, ids=lambda c: f"N{c[0]}H{c[1]}C{c[3]}b{c[4]}c{int(c[5])}g{c[6] > 0}")
+def test_march_rays_train_arena(be, orc, case):
+    N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
+    bits, o, d, ld, nears, fars, noises = march_inputs(orc, case, seed=1)
+    rx, rd, rt, rrays, rl, M = orc.march_rays_train(o, d, ld, bits, bound, contract, dt_gamma, max_steps, C, H, nears,
+                                                    fars, noises)
+    from raw_ngp_amd.raymarching import MarchArena
+    for cap in (M + 1000, max(M // 2, 1)):                          # roomy arena, then one that overflows
+        ar = MarchArena(N, max_steps, cap, "cuda", with_ldirs=ldir)
+        be.raymarching_backend.march_rays_train_arena(dev(o), dev(d), dev(ld) if ldir else None, dev(bits), bound,
+                                                      contract, dt_gamma, max_steps, N, C, H, dev(nears), dev(fars),
+                                                      dev(noises), ar.t_scratch, cap, ar.xyzs, ar.dirs, ar.ts,
+                                                      ar.ldirs, ar.rays, ar.counter, ar.ray_idx)
+        written, needed = host(ar.counter)
+        assert needed == M
+        got = host(ar.rays)
+        if cap >= M:
+            assert written == M and np.array_equal(got, rrays)
+        else:
+            keep = (rrays[:, 0] + rrays[:, 1]) <= cap
+            assert written == rrays[keep, 1].sum() <= cap
+            assert np.array_equal(got[keep], rrays[keep]) and np.all(got[~keep, 1] == 0)
+        w = int(written)
+        assert np.array_equal(host(ar.xyzs)[:w], rx[:w]) and np.array_equal(host(ar.ts)[:w], rt[:w])
+        assert np.array_equal(host(ar.dirs)[:w], rd[:w])
+        assert np.array_equal(host(ar.ray_idx)[:w], orc.flatten_rays(rrays, M)[:w])
+        if ldir:
+            assert np.array_equal(host(ar.ldirs)[:w], rl[:w])
+
+
+def test_march_empty_inputs(be, orc):
+    H = 32
+    bits = np.zeros(H ** 3 // 8, dtype=np.uint8)
+    o = np.array([[0, 0, 3.0]], dtype=np.float32)
+    d = np.array([[0, 0.01, -1.0]], dtype=np.float32)
+    nears = np.array([2.0], dtype=np.float32)
+    fars = np.array([4.0], dtype=np.float32)
+    rays = torch.full((1, 2), -7, dtype=torch.int32, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    be.raymarching_backend.march_rays_train(dev(o), dev(d), None, dev(bits), 1.0, False, 0.0, 64, 1, 1, H, dev(nears),
+                                            dev(fars), None, None, None, None, rays, counter,
+                                            torch.zeros(1, device="cuda"))
+    assert host(rays).tolist() == [[0, 0]] and int(counter.item()) == 0
+    # N = 0 is a no-op
+    be.raymarching_backend.march_rays_train(dev(o)[:0], dev(d)[:0], None, dev(bits), 1.0, False, 0.0, 64, 0, 1, H,
+                                            dev(nears)[:0], dev(fars)[:0], None, None, None, None, rays[:0], counter,
+                                            torch.zeros(0, device="cuda"))
+
+
+# ----------------------------------------------------------------------------- compositing
+
+@pytest.mark.parametrize("T_thresh", [0.0, 1e-8, 1e-4])
+def test_composite_train_forward_backward(be, orc, T_thresh):
+    rng = np.random.default_rng(5)
+    N = 4096
+    sig, rgb, ts, rays, M = synth_samples(rng, N)
+    rw, rws, rdep, rimg = orc.composite_rays_train_forward(sig, rgb, ts, rays, M, N, T_thresh)
+    w = torch.zeros(M, device="cuda")
+    ws = torch.empty(N, device="cuda")
+    dep = torch.empty(N, device="cuda")
+    img = torch.empty(N, 3, device="cuda")
+    be.raymarching_backend.composite_rays_train_forward(dev(sig), dev(rgb), dev(ts), dev(rays), M, N, T_thresh, w, ws,
+                                                        dep, img)
+    # __expf vs libm expf (few ulp on alpha) accumulated over <= 80 samples; where T crosses
+    # T_thresh within rounding the stop index may differ by one sample of weight <= T_thresh
+    tol = dict(rtol=2e-4, atol=2e-6 + 2 * T_thresh)
+    np.testing.assert_allclose(host(w), rw, **tol)
+    np.testing.assert_allclose(host(ws), rws, **tol)
+    np.testing.assert_allclose(host(dep), rdep, rtol=2e-4, atol=1e-5 + 8 * T_thresh)
+    np.testing.assert_allclose(host(img), rimg, **tol)
+
+    gw = rng.normal(size=M).astype(np.float32)
+    gws = rng.normal(size=N).astype(np.float32)
+    gdep = rng.normal(size=N).astype(np.float32)
+    gimg = rng.normal(size=(N, 3)).astype(np.float32)
+    rgs, rgc = orc.composite_rays_train_backward(gw, gws, gdep, gimg, sig, rgb, ts, rays, rws, rdep, rimg, M, N, T_thresh)
+    gs = torch.zeros(M, device="cuda")
+    gc = torch.zeros(M, 3, device="cuda")
+    be.raymarching_backend.composite_rays_train_backward(dev(gw), dev(gws), dev(gdep), dev(gimg), dev(sig), dev(rgb),
+                                                         dev(ts), dev(rays), dev(rws), dev(rdep), dev(rimg), M, N,
+                                                         T_thresh, gs, gc)
+    np.testing.assert_allclose(host(gc), rgc, rtol=2e-4, atol=1e-5 + 8 * T_thresh)
+    # grad_sigma subtracts nearly equal running sums: bound the error relative to the ray scale
+    err = np.abs(host(gs) - rgs)
+    assert np.all(err <= 2e-3 * np.abs(rgs) + 1e-3 * np.abs(ts[:, 1]) * 50 + 1e-6)
+
+
+def test_composite_train_empty_and_overflow(be):
+    rays = torch.tensor([[0, 0], [0, 3], [2, 5]], dtype=torch.int32, device="cuda")
+    sig = torch.ones(4, device="cuda")
+    rgb = torch.ones(4, 3, device="cuda")
+    ts = torch.tensor([[0.1, 0.1], [0.2, 0.1], [0.3, 0.1], [0.4, 0.1]], device="cuda")
+    w = torch.zeros(4, device="cuda")
+    ws = torch.full((3,), 9.0, device="cuda")
+    dep = torch.full((3,), 9.0, device="cuda")
+    img = torch.full((3, 3), 9.0, device="cuda")
+    from raw_ngp_amd import _lib
+    _lib.raymarching_backend.composite_rays_train_forward(sig, rgb, ts, rays, 4, 3, 1e-4, w, ws, dep, img)
+    assert ws[0] == 0 and ws[2] == 0 and torch.all(img[0] == 0) and torch.all(img[2] == 0) and dep[2] == 0
+    assert ws[1] > 0 and torch.all(w[:3] > 0) and w[3] == 0
+
+
+# ----------------------------------------------------------------------------- inference pair
+
+def test_inference_pair(be, orc):
+    rng = np.random.default_rng(9)
+    N, H, max_steps = 2000, 128, 1024
+    bits, _ = brick_bitfield(orc, H, seed=3)
+    o, d = make_rays(rng, N)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], dtype=np.float32)
+    nears, fars = orc.near_far_from_aabb(o, d, aabb, N, 0.05)
+    alive = np.arange(N, dtype=np.int32)[::2].copy()
+    n_alive, n_step = alive.size, 4
+    rays_t = nears.copy()
+    noises = rng.uniform(0, 1, n_alive).astype(np.float32)
+    rx, rd, rt = orc.march_rays(n_alive, n_step, alive, rays_t, o, d, 1.0, False, 0.0, max_steps, 1, H, bits, nears, fars,
+                                noises)
+    M = n_alive * n_step
+    xyzs = torch.zeros(M, 3, device="cuda")
+    dirs = torch.zeros(M, 3, device="cuda")
+    ts = torch.zeros(M, 2, device="cuda")
+    be.raymarching_backend.march_rays(n_alive, n_step, dev(alive), dev(rays_t), dev(o), dev(d), 1.0, False, 0.0, max_steps,
+                                      1, H, dev(bits), dev(nears), dev(fars), xyzs, dirs, ts, dev(noises))
+    assert np.array_equal(host(xyzs), rx) and np.array_equal(host(dirs), rd) and np.array_equal(host(ts), rt)
+
+    sig = (40.0 * np.exp(-4 * (rx ** 2).sum(1))).astype(np.float32)
+    col = (0.5 + 0.5 * np.sin(3 * rx)).astype(np.float32)
+    ws = rng.uniform(0, 0.3, N).astype(np.float32)
+    dep = rng.uniform(0, 1, N).astype(np.float32)
+    img = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+    r_alive, r_t, r_ws, r_dep, r_img = alive.copy(), rays_t.copy(), ws.copy(), dep.copy(), img.copy()
+    orc.composite_rays(n_alive, n_step, 1e-2, r_alive, r_t, sig, col, rt, r_ws, r_dep, r_img)
+    g_alive, g_t, g_ws, g_dep, g_img = dev(alive), dev(rays_t), dev(ws), dev(dep), dev(img)
+    be.raymarching_backend.composite_rays(n_alive, n_step, 1e-2, g_alive, g_t, dev(sig), dev(col), ts, g_ws, g_dep, g_img)
+    assert np.array_equal(host(g_alive), r_alive)
+    np.testing.assert_allclose(host(g_t), r_t, rtol=0, atol=0)
+    np.testing.assert_allclose(host(g_ws), r_ws, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(host(g_dep), r_dep, rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(host(g_img), r_img, rtol=2e-4, atol=2e-6)
+
+
+def test_ray_gradient_segment_sum(be, orc):
+    rng = np.random.default_rng(10)
+    N = 3000
+    cnt = rng.integers(0, 150, N).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt[:-1])]).astype(np.int32)
+    M = int(cnt.sum())
+    rays = np.stack([off, cnt], 1).astype(np.int32)
+    gx = rng.normal(size=(M, 3)).astype(np.float32)
+    gd = rng.normal(size=(M, 3)).astype(np.float32)
+    ts = rng.uniform(0, 3, (M, 2)).astype(np.float32)
+    ro, rd = orc.march_rays_train_backward(gx, gd, ts, rays, N, M)
+    go = torch.empty(N, 3, device="cuda")
+    gdd = torch.empty(N, 3, device="cuda")
+    be.raymarching_backend.march_rays_train_backward(dev(gx), dev(gd), dev(ts), dev(rays), N, M, go, gdd)
+    np.testing.assert_allclose(host(go), ro, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(gdd), rd, rtol=1e-4, atol=2e-4)
