@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: training rays/s on a synthetic 800x800 Lego-style scene.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+  step      = one optimiser step of the density-grid path: 4096 random rays -> near/far -> occupancy march
+              -> hash-grid + SH encode -> tiny MLPs -> composite -> MSE -> backward (composite, MLPs, SH,
+              hash-grid scatter) -> Adam, plus the density-grid refresh every 16 steps (amortised).
+              Rays, images, tables and the occupancy grid are resident in HBM before the timed region.
+  value     = world_size * rays_per_step * K / max-over-ranks wall time of the K timed steps.
+  burn-in   = untimed training steps before the W warm-up steps, so that the 16 full density-grid sweeps
+              are over and the occupancy grid has converged (metric definition):
+              setup, not part of W or K.
+  roofline  = the dominant kernel of the step, timed live with HIP events around each of its launches
+              inside the timed region; algorithmic bytes per sample from SURVEY.md section 8d.
+  cpu_baseline = the same step restated on the CPU oracle (oracle/ngp_oracle.c kernels + torch CPU MLPs and
+              Adam) on a bounded ray sample, all host cores (kind "port": the reference has no CPU path for
+              the encoders and its CUDA kernels cannot be built here).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from raw_ngp_amd import _lib, parallel  # noqa: E402
+from raw_ngp_amd.nerf.network import NeRFNetwork  # noqa: E402
+from raw_ngp_amd.nerf.options import Options  # noqa: E402
+from raw_ngp_amd.nerf.scene import SyntheticDataset  # noqa: E402
+from raw_ngp_amd.nerf.trainer import Trainer  # noqa: E402
+
+METRIC = "training rays/sec + PSNR@5k-iters, NeRF-synthetic Lego 800², 1/2/4/8 MI355X"
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# dominant-kernel candidates: C symbol -> (index of the sample-count argument, algorithmic bytes/sample)
+ROOFLINE_KERNELS = {
+    "ngp_grid_encode_backward": (5, 12 + 16 * (8 + 64)),      # 1164 B/sample, SURVEY.md section 8d
+    "ngp_grid_encode_forward": (4, 12 + 16 * (64 + 8)),       # 1164 B/sample
+}
+
+
+def cpu_baseline(opt, n_rays, steps, seed=0):
+    """One training step restated on the CPU oracle; returns rays/s and the thread count."""
+    from oracle import oracle as orc
+    import torch.nn.functional as F
+    threads = os.cpu_count() or 1
+    orc.set_threads(threads)
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cpu")
+    data = SyntheticDataset(opt, dev, "train", n_views=2, H=100, W=100)
+    H = opt.grid_size
+    occ = data.occupancy_grid(H, opt.bound).numpy()
+    xs, ys, zs = np.nonzero(occ)
+    grid = np.zeros((1, H ** 3), dtype=np.float32)
+    grid[0, orc.morton3D(np.stack([xs, ys, zs], 1).astype(np.int32))] = 1.0
+    bits = orc.packbits(grid, 0.5)
+    D, C, L, Hb = 3, 2, 16, 16
+    offsets, scale = orc.grid_offsets(desired_resolution=opt.hashgrid_resolution * opt.bound,
+                                      log2_hashmap_size=opt.hashmap_size)
+    S = float(np.log2(scale))
+    table = torch.nn.Parameter(torch.from_numpy(rng.uniform(-1e-4, 1e-4, (int(offsets[-1]), C)).astype(np.float32)))
+    w_grid = [torch.nn.Parameter(torch.randn(o, i) * (1.0 / i) ** 0.5) for i, o in ((32, 64), (64, 64), (64, 16))]
+    w_view = [torch.nn.Parameter(torch.randn(o, i) * (1.0 / i) ** 0.5) for i, o in ((31, 64), (64, 64), (64, 3))]
+    optim = torch.optim.Adam([table] + w_grid + w_view, lr=opt.lr, eps=1e-15)
+    aabb = np.array([-opt.bound] * 3 + [opt.bound] * 3, dtype=np.float32)
+
+    def mlp(x, ws):
+        for k, w in enumerate(ws):
+            x = F.linear(x, w)
+            if k < len(ws) - 1:
+                x = F.relu(x)
+        return x
+
+    def step():
+        r = data.sample_rays(n_rays)
+        o, d = r["rays_o"].numpy().copy(), r["rays_d"].numpy().copy()
+        img = r["images"]
+        gt = (img[:, :3] * img[:, 3:]).numpy()
+        nears, fars = orc.near_far_from_aabb(o, d, aabb, n_rays, opt.min_near)
+        noises = rng.uniform(0, 1, n_rays).astype(np.float32)
+        xyzs, dirs, ts, rays, _, M = orc.march_rays_train(o, d, None, bits, opt.bound, False, 0.0, opt.max_steps, 1, H,
+                                                          nears, fars, noises)
+        if M == 0:
+            return 0
+        x01 = ((xyzs + opt.bound) / (2 * opt.bound)).astype(np.float32)
+        enc, _ = orc.grid_encode_forward(x01, table.detach().numpy(), offsets, M, D, C, L, L, S, Hb)
+        feat = torch.from_numpy(np.ascontiguousarray(enc.transpose(1, 0, 2).reshape(M, L * C))).requires_grad_(True)
+        dn = dirs / np.linalg.norm(dirs, axis=1, keepdims=True)
+        sh, _ = orc.sh_encode_forward(dn.astype(np.float32), M, 3, 4)
+        h = mlp(feat, w_grid)
+        sigma = torch.exp(h[:, 0])
+        color = torch.clamp(torch.exp(mlp(torch.cat([h[:, 1:], torch.from_numpy(sh)], 1), w_view) - 5.0), max=5.0)
+        w, ws, dep, image = orc.composite_rays_train_forward(sigma.detach().numpy(), color.detach().numpy(), ts, rays, M,
+                                                            n_rays, opt.T_thresh)
+        g_img = (2.0 / (3 * n_rays)) * (image - gt)
+        gs, gc = orc.composite_rays_train_backward(np.zeros(M, np.float32), np.zeros(n_rays, np.float32),
+                                                   np.zeros(n_rays, np.float32), g_img.astype(np.float32),
+                                                   sigma.detach().numpy(), color.detach().numpy(), ts, rays, ws, dep, image,
+                                                   M, n_rays, opt.T_thresh)
+        optim.zero_grad()
+        ((sigma * torch.from_numpy(gs)).sum() + (color * torch.from_numpy(gc)).sum()).backward()
+        g_enc = np.ascontiguousarray(feat.grad.numpy().reshape(M, L, C).transpose(1, 0, 2))
+        g_tab, _ = orc.grid_encode_backward(g_enc, x01, table.detach().numpy(), offsets, M, D, C, L, L, S, Hb)
+        table.grad = torch.from_numpy(g_tab)
+        optim.step()
+        return M
+
+    step()
+    t0 = time.perf_counter()
+    samples = sum(step() for _ in range(steps))
+    dt = time.perf_counter() - t0
+    return {"value": n_rays * steps / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} training steps of {n_rays} rays ({samples // max(steps, 1)} samples/step) on the "
+                      f"oracle kernels + torch-CPU MLP/Adam, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--burnin", type=int, default=320, help="untimed training steps before warm-up (grid convergence)")
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--views", type=int, default=100)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--roofline-kernel", default="ngp_grid_encode_backward", choices=sorted(ROOFLINE_KERNELS))
+    ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--psnr-iters", type=int, default=0, help="if > 0: keep training to this many iterations and report PSNR")
+    ap.add_argument("--arena", type=int, default=0, help="sample arena capacity (0 = reference two-pass march)")
+    args = ap.parse_args()
+
+    rank, world, local = parallel.init_from_env("cuda")
+    assert world == max(args.gpus, 1) or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    _lib.load()
+    torch.manual_seed(0)
+
+    opt = Options(bound=1.0, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena)
+    data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
+    model = NeRFNetwork(opt)
+    trainer = Trainer(opt, model, data, device=dev)
+
+    trainer.train(args.burnin)
+    trainer.train(args.warmup)
+
+    # ---- timed region -------------------------------------------------------------------------
+    arg_idx, bytes_per_sample = ROOFLINE_KERNELS[args.roofline_kernel]
+    parallel.barrier()
+    torch.cuda.synchronize()
+    _lib.set_probe(args.roofline_kernel, arg_idx)
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(args.steps):
+        trainer.train_step()
+        samples += trainer.last_num_points
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    probe = _lib.probe_results()
+    _lib.set_probe(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    psnr = None
+    if args.psnr_iters > trainer.global_step:
+        trainer.train(args.psnr_iters - trainer.global_step)
+    if args.psnr_iters > 0:
+        val = SyntheticDataset(opt, dev, "val", n_views=4, H=args.res, W=args.res)
+        psnr = trainer.evaluate(val)
+
+    if rank == 0:
+        launches, units, ksec = probe
+        roof = None
+        if launches:
+            ach = units * bytes_per_sample / ksec / 1e9
+            roof = {"bound": "hbm", "kernel": args.roofline_kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "launches": launches, "avg_us": round(ksec / launches * 1e6, 2),
+                    "bytes_per_sample": bytes_per_sample, "samples_per_launch": round(units / launches)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(Options(bound=1.0), args.cpu_rays, args.cpu_steps)
+            cpu["value"] = round(cpu["value"], 1)
+        line = {
+            "metric": METRIC, "value": round(world * args.rays * args.steps / dt, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: Lego-style 800x800 procedural scene, hashgrid L=16 F=2 T=2^19, "
+                                   "density-grid march (cuda_ray path), 4096 rays/batch/GPU, fp32 MLPs",
+                       "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
+                       "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
+                       "parallelism": f"dp{world}", "arena": args.arena},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if psnr is not None:
+            line["psnr"] = {"iters": trainer.global_step, "value": round(float(psnr), 3)}
+        print(json.dumps(line), flush=True)
+    if parallel.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

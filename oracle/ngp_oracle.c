@@ -224,7 +224,9 @@ void orc_grid_encode_backward(const float *grad, const float *inputs, const floa
     orc_grid_resolutions(S, H, L, res_tab);
     const size_t n_rows = (size_t)(uint32_t)offsets[L];
     double *acc = (double *)calloc(n_rows * C, sizeof(double));
-    for (uint32_t level = 0; level < max_level; level++) {
+    /* levels own disjoint row ranges: parallel over levels keeps the per-row order (level, b, corner) */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t level = 0; level < (int64_t)max_level; level++) {
         double *gt = acc + (size_t)(uint32_t)offsets[level] * C;
         const uint32_t T = (uint32_t)(offsets[level + 1] - offsets[level]);
         const uint32_t res = res_tab[level];

@@ -90,14 +90,35 @@ def _ptr(t, kind, name, optional=False):
     return t.data_ptr()
 
 
+# Optional per-kernel probe (bench.py): HIP events recorded on the launch stream around every call of ONE
+# C symbol, plus the value of one integer argument (the number of samples the launch processes).
+_probe = {"name": None, "arg": 0, "events": []}
+
+
+def set_probe(name, units_arg=0):
+    _probe["name"], _probe["arg"], _probe["events"] = name, units_arg, []
+
+
+def probe_results():
+    """(launches, total units, total seconds) of the probed symbol since set_probe()."""
+    torch.cuda.synchronize()
+    ev = _probe["events"]
+    return len(ev), sum(u for _, _, u in ev), sum(a.elapsed_time(b) for a, b, _ in ev) * 1e-3
+
+
 def _call(name, anchor, *args):
     lib = load()
     dev = anchor.device
-    if torch.cuda.current_device() != dev.index:
-        with torch.cuda.device(dev):
-            rc = getattr(lib, name)(*args, torch.cuda.current_stream(dev).cuda_stream)
-    else:
-        rc = getattr(lib, name)(*args, torch.cuda.current_stream(dev).cuda_stream)
+    probing = _probe["name"] == name
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        if probing:
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record(stream)
+        rc = getattr(lib, name)(*args, stream.cuda_stream)
+        if probing:
+            stop.record(stream)
+            _probe["events"].append((start, stop, int(args[_probe["arg"]])))
     if rc != 0:
         raise RuntimeError(lib.ngp_last_error().decode())
 

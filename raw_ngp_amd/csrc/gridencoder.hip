@@ -499,12 +499,12 @@ extern "C" int ngp_grid_encode_forward(const float *inputs, const float *embeddi
                                        uint32_t max_level, float S, uint32_t H, float *dy_dx, uint32_t gridtype,
                                        int align_corners, uint32_t interp, ngp_stream_t stream)
 {
+    if (B == 0 || max_level == 0) return NGP_OK;
     NGP_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null tensor");
     if (int e = check_dc("grid_encode_forward", D, C)) return e;
     LevelRes lv;
     NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_forward: L must be in [1, %u]", kMaxLevels);
     NGP_REQUIRE(max_level <= L, "grid_encode_forward: max_level > L");
-    if (B == 0 || max_level == 0) return NGP_OK;
     NGP_DISPATCH_DC(launch_forward, inputs, embeddings, offsets, outputs, dy_dx, B, L, max_level, lv, gridtype,
                     align_corners != 0, interp, as_stream(stream));
     NGP_CHECK_LAUNCH("grid_encode_forward");
@@ -517,13 +517,13 @@ extern "C" int ngp_grid_encode_backward(const float *grad, const float *inputs, 
                                         const float *dy_dx, float *grad_inputs, uint32_t gridtype,
                                         int align_corners, uint32_t interp, ngp_stream_t stream)
 {
+    if (B == 0) return NGP_OK;
     (void)embeddings;
     NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null tensor");
     if (int e = check_dc("grid_encode_backward", D, C)) return e;
     LevelRes lv;
     NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_backward: L must be in [1, %u]", kMaxLevels);
     NGP_REQUIRE(max_level <= L, "grid_encode_backward: max_level > L");
-    if (B == 0) return NGP_OK;
     NGP_DISPATCH_DC(launch_backward, grad, inputs, offsets, grad_embeddings, B, L, max_level, lv, dy_dx,
                     grad_inputs, gridtype, align_corners != 0, interp, as_stream(stream));
     NGP_CHECK_LAUNCH("grid_encode_backward");
@@ -535,11 +535,11 @@ extern "C" int ngp_grad_total_variation(const float *inputs, const float *embedd
                                         uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
                                         ngp_stream_t stream)
 {
+    if (B == 0) return NGP_OK;
     NGP_REQUIRE(inputs && embeddings && grad && offsets, "grad_total_variation: null tensor");
     if (int e = check_dc("grad_total_variation", D, C)) return e;
     LevelRes lv;
     NGP_REQUIRE(fill_levels(lv, S, H, L), "grad_total_variation: L must be in [1, %u]", kMaxLevels);
-    if (B == 0) return NGP_OK;
     const float w = weight / (float)(2u * D);
     NGP_DISPATCH_DC(launch_tv, inputs, embeddings, grad, offsets, w, B, L, lv, gridtype, align_corners != 0,
                     as_stream(stream));
@@ -550,11 +550,11 @@ extern "C" int ngp_grad_total_variation(const float *inputs, const float *embedd
 extern "C" int ngp_grad_weight_decay(const float *embeddings, float *grad, const int32_t *offsets, float weight,
                                      uint32_t B, uint32_t C, uint32_t L, ngp_stream_t stream)
 {
+    const uint64_t n = (uint64_t)B * C;
+    if (n == 0) return NGP_OK;
     NGP_REQUIRE(embeddings && grad && offsets, "grad_weight_decay: null tensor");
     NGP_REQUIRE(L >= 1, "grad_weight_decay: L must be >= 1");
-    const uint64_t n = (uint64_t)B * C;
     NGP_REQUIRE(n < (1ull << 32), "grad_weight_decay: table too large");
-    if (n == 0) return NGP_OK;
     const uint32_t blocks = min(ceil_div((uint32_t)n, kBlock), 256u * 16u);
     grid_wd_kernel<<<dim3(blocks), kBlock, 0, as_stream(stream)>>>(embeddings, grad, offsets, weight, (uint32_t)n, C, L);
     NGP_CHECK_LAUNCH("grad_weight_decay");

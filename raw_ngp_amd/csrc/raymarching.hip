@@ -604,8 +604,8 @@ using namespace ngp;
 extern "C" int ngp_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
                                       float min_near, float *nears, float *fars, ngp_stream_t stream)
 {
-    NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null tensor");
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null tensor");
     near_far_kernel<<<NGP_1D(N, 256u)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
     NGP_CHECK_LAUNCH("near_far_from_aabb");
     return NGP_OK;
@@ -614,8 +614,8 @@ extern "C" int ngp_near_far_from_aabb(const float *rays_o, const float *rays_d, 
 extern "C" int ngp_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
                                 ngp_stream_t stream)
 {
-    NGP_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null tensor");
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null tensor");
     sph_from_ray_kernel<<<NGP_1D(N, 256u)>>>(rays_o, rays_d, radius, N, coords);
     NGP_CHECK_LAUNCH("sph_from_ray");
     return NGP_OK;
@@ -623,8 +623,8 @@ extern "C" int ngp_sph_from_ray(const float *rays_o, const float *rays_d, float 
 
 extern "C" int ngp_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, ngp_stream_t stream)
 {
-    NGP_REQUIRE(coords && indices, "morton3D: null tensor");
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(coords && indices, "morton3D: null tensor");
     morton3D_kernel<<<NGP_1D(N, 256u)>>>(coords, N, indices);
     NGP_CHECK_LAUNCH("morton3D");
     return NGP_OK;
@@ -632,8 +632,8 @@ extern "C" int ngp_morton3D(const int32_t *coords, uint32_t N, int32_t *indices,
 
 extern "C" int ngp_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, ngp_stream_t stream)
 {
-    NGP_REQUIRE(coords && indices, "morton3D_invert: null tensor");
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(coords && indices, "morton3D_invert: null tensor");
     morton3D_invert_kernel<<<NGP_1D(N, 256u)>>>(indices, N, coords);
     NGP_CHECK_LAUNCH("morton3D_invert");
     return NGP_OK;
@@ -642,9 +642,9 @@ extern "C" int ngp_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *
 extern "C" int ngp_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield,
                             ngp_stream_t stream)
 {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(grid && bitfield, "packbits: null tensor");
     NGP_REQUIRE(((uintptr_t)grid & 15u) == 0, "packbits: grid must be 16-byte aligned");
-    if (N == 0) return NGP_OK;
     packbits_kernel<<<NGP_1D(N, 256u)>>>(grid, N, density_thresh, bitfield);
     NGP_CHECK_LAUNCH("packbits");
     return NGP_OK;
@@ -652,8 +652,8 @@ extern "C" int ngp_packbits(const float *grid, uint32_t N, float density_thresh,
 
 extern "C" int ngp_flatten_rays(const int32_t *rays, uint32_t N, uint32_t M, int32_t *res, ngp_stream_t stream)
 {
-    NGP_REQUIRE(rays && res, "flatten_rays: null tensor");
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays && res, "flatten_rays: null tensor");
     flatten_rays_kernel<<<dim3(ceil_div(N, kFlatBlock / kWave)), dim3(kFlatBlock), 0, as_stream(stream)>>>(rays, N, M, res);
     NGP_CHECK_LAUNCH("flatten_rays");
     return NGP_OK;
@@ -665,9 +665,9 @@ extern "C" int ngp_march_rays_train(const float *rays_o, const float *rays_d, co
                                     const float *fars, float *xyzs, float *dirs, float *ts, float *ldirs,
                                     int32_t *rays, int32_t *counter, const float *noises, ngp_stream_t stream)
 {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises, "march_rays_train: null tensor");
     NGP_REQUIRE(max_steps > 0 && H > 0 && C > 0, "march_rays_train: max_steps, C and H must be positive");
-    if (N == 0) return NGP_OK;
     if (xyzs == nullptr) {
         march_count_kernel<0><<<NGP_1D(N, kRayBlock)>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N,
                                                        C, H, nears, fars, noises, rays, nullptr);
@@ -691,10 +691,10 @@ extern "C" int ngp_x_march_rays_train_arena(const float *rays_o, const float *ra
                                             float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
                                             ngp_stream_t stream)
 {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && t_scratch && xyzs && dirs && ts,
                 "march_rays_train_arena: null tensor");
     NGP_REQUIRE(max_steps > 0 && H > 0 && C > 0 && M_cap > 0, "march_rays_train_arena: bad sizes");
-    if (N == 0) return NGP_OK;
     march_count_kernel<1><<<NGP_1D(N, kRayBlock)>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C,
                                                    H, nears, fars, noises, rays, t_scratch);
     march_scan_kernel<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(rays, N, counter, M_cap, true);
@@ -710,9 +710,9 @@ extern "C" int ngp_composite_rays_train_forward(const float *sigmas, const float
                                                 float *weights, float *weights_sum, float *depth, float *image,
                                                 ngp_stream_t stream)
 {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null tensor");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && weights), "composite_rays_train_forward: null sample tensor");
-    if (N == 0) return NGP_OK;
     composite_train_forward_kernel<<<NGP_1D(N, kRayBlock)>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum,
                                                             depth, image);
     NGP_CHECK_LAUNCH("composite_rays_train_forward");
@@ -726,9 +726,9 @@ extern "C" int ngp_composite_rays_train_backward(const float *grad_weights, cons
                                                  const float *image, uint32_t M, uint32_t N, float T_thresh,
                                                  float *grad_sigmas, float *grad_rgbs, ngp_stream_t stream)
 {
+    if (N == 0 || M == 0) return NGP_OK;
     NGP_REQUIRE(grad_weights_sum && grad_depth && grad_image && rays && weights_sum && depth && image,
                 "composite_rays_train_backward: null tensor");
-    if (N == 0 || M == 0) return NGP_OK;
     NGP_REQUIRE(grad_weights && sigmas && rgbs && ts && grad_sigmas && grad_rgbs,
                 "composite_rays_train_backward: null sample tensor");
     composite_train_backward_kernel<<<NGP_1D(N, kRayBlock)>>>(grad_weights, grad_weights_sum, grad_depth, grad_image, sigmas,
@@ -744,8 +744,8 @@ extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *
                               const float *fars, float *xyzs, float *dirs, float *ts, const float *noises,
                               ngp_stream_t stream)
 {
-    (void)nears;
     if (n_alive == 0 || n_step == 0) return NGP_OK;
+    (void)nears;
     NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && ts && noises,
                 "march_rays: null tensor");
     march_rays_kernel<<<NGP_1D(n_alive, kRayBlock)>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
@@ -771,9 +771,9 @@ extern "C" int ngp_x_march_rays_train_backward(const float *grad_xyzs, const flo
                                                const int32_t *rays, uint32_t N, uint32_t M, float *grad_rays_o,
                                                float *grad_rays_d, ngp_stream_t stream)
 {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays && grad_rays_o && grad_rays_d, "march_rays_train_backward: null tensor");
     NGP_REQUIRE(M == 0 || (grad_xyzs && ts), "march_rays_train_backward: null sample tensor");
-    if (N == 0) return NGP_OK;
     march_train_backward_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(grad_xyzs, grad_dirs, ts, rays, N,
                                                                                           M, grad_rays_o, grad_rays_d);
     NGP_CHECK_LAUNCH("march_rays_train_backward");

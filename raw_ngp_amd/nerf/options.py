@@ -1,0 +1,58 @@
+"""Hot-path options with the reference's flag names and defaults (main.py:10-125).
+
+The reference passes one argparse Namespace (`opt`) everywhere; NeRFNetwork / NeRFRenderer here read
+the same attribute names, so either this dataclass or the reference's own Namespace can be handed in.
+Only flags that reach the hot path are listed; dataset / logging / mesh flags are out of scope.
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+
+@dataclass
+class Options:
+    # scene / marching (main.py:31-53)
+    bound: float = 2.0
+    contract: bool = False
+    min_near: float = 0.05
+    T_thresh: float = 1e-8
+    cuda_ray: bool = True
+    max_steps: int = 1024
+    num_steps: List[int] = field(default_factory=lambda: [256, 96, 48])
+    update_extra_interval: int = 16
+    max_ray_batch: int = 4096 * 4
+    grid_size: int = 128
+    dt_gamma: float = 0.0
+    density_thresh: float = 10.0
+    background: str = "black"
+    # encoder (main.py:55-56)
+    hashgrid_resolution: int = 2048
+    hashmap_size: int = 19
+    # batch (main.py:59-61)
+    num_rays: int = 4096
+    adaptive_num_rays: bool = False
+    num_points: int = 2 ** 18
+    # regularisers (main.py:64-69)
+    lambda_entropy: float = 0.0
+    lambda_tv: float = 0.0
+    lambda_wd: float = 0.0
+    lambda_orientation: float = 0.0
+    lambda_proposal: float = 1.0
+    lambda_distort: float = 0.0
+    # field (main.py:90-92,101,106-109,121)
+    internal_activation: str = "relu"
+    color_activation: str = "clamped_exp"
+    density_activation: str = "clamped_exp"
+    rfield: bool = False
+    pose_opt: str = "none"
+    start_annealing: float = 0.0
+    end_annealing: float = 0.33
+    beta: float = 2.0
+    compute_normals: bool = False
+    # training (main.py:16,40-41)
+    fp16: bool = False
+    iters: int = 20000
+    lr: float = 1e-2
+    device: str = "cuda"
+    # --- extensions of this implementation (no reference counterpart) -----------------------------
+    fused_mlp: bool = False       # hand-written MFMA tiny-MLP instead of nn.Linear stacks
+    arena_capacity: int = 0       # > 0: sample arena (no host sync per step); 0 = reference 2-pass protocol

@@ -1,0 +1,75 @@
+"""Ray generation and metrics used by the harness.
+
+`get_rays` follows the reference's nerf/train_utils.py:96-172 (pixel centre +0.5, camera looks
+down -z, y flipped, directions NOT normalised); `PSNRMeter` follows :203-248."""
+import os
+import random
+
+import numpy as np
+import torch
+
+
+def seed_everything(seed):
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+@torch.autocast("cuda", enabled=False)
+def get_rays(poses, intrinsics, H, W, N=-1, coords=None, ldirs=None, generator=None):
+    """poses [B,4,4] cam2world (B = 1, or B = N with one pose per ray), intrinsics (fx, fy, cx, cy).
+    N > 0 draws N random pixels (with replacement, like torch.randint in the reference)."""
+    device = poses.device
+    if isinstance(intrinsics, np.ndarray) or (torch.is_tensor(intrinsics) and intrinsics.dim() == 1):
+        fx, fy, cx, cy = [float(v) for v in intrinsics]
+    else:
+        fx, fy, cx, cy = intrinsics[:, 0], intrinsics[:, 1], intrinsics[:, 2], intrinsics[:, 3]
+    results = {}
+    if N > 0:
+        if coords is not None:
+            inds = coords[:, 0] * W + coords[:, 1]
+        else:
+            inds = torch.randint(0, H * W, size=[N], device=device, generator=generator)
+        ii = (inds % W)
+        jj = torch.div(inds, W, rounding_mode="floor")
+        results["i"], results["j"] = ii.long(), jj.long()
+        i, j = ii.float() + 0.5, jj.float() + 0.5
+    else:
+        j, i = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                              torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+        i, j = i.reshape(-1) + 0.5, j.reshape(-1) + 0.5
+    directions = torch.stack(((i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)), dim=-1)
+    rays_d = (directions.unsqueeze(1) @ poses[:, :3, :3].transpose(-1, -2)).squeeze(1)
+    results["rays_o"] = poses[:, :3, 3].expand_as(rays_d)
+    results["rays_d"] = rays_d
+    results["rays_ldir"] = ldirs.expand_as(rays_d) if ldirs is not None else None
+    return results
+
+
+class PSNRMeter:
+    """Per-image PSNR averaged over images, max pixel value 1."""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.V, self.N = 0.0, 0
+
+    def update(self, preds, truths):
+        if torch.is_tensor(preds):
+            preds = preds.detach().float().cpu().numpy()
+        if torch.is_tensor(truths):
+            truths = truths.detach().float().cpu().numpy()
+        psnr = -10 * np.log10(np.mean((preds - truths) ** 2))
+        self.V += psnr
+        self.N += 1
+        return psnr
+
+    def measure(self):
+        return self.V / max(self.N, 1)
+
+    def report(self):
+        return f"PSNR = {self.measure():.6f}"

@@ -1,0 +1,63 @@
+"""Data-parallel plumbing on CPU: world_size 2 over gloo (the GPU path uses the same code over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from raw_ngp_amd import parallel
+    r, w, _ = parallel.init_from_env("cpu")
+    assert (r, w) == (rank, world) and parallel.world_size() == world
+    torch.manual_seed(100 + rank)                                  # ranks start different ...
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16, bias=False), torch.nn.ReLU(), torch.nn.Linear(16, 3, bias=False))
+    table = torch.nn.Parameter(torch.randn(1 << 20, 2) * 1e-2)      # "big" tensor: reduced on its own
+    model.register_parameter("table", table)
+    parallel.broadcast_module(model)                                # ... and are made identical
+    w0 = [p.detach().clone() for p in model.parameters()]
+    gen = torch.Generator().manual_seed(7 + rank)                   # every rank: its own ray batch
+    x = torch.randn(32, 8, generator=gen)
+    idx = torch.randint(0, 1 << 20, (32,), generator=gen)
+    loss = (model[2](model[1](model[0](x))) ** 2).mean() + (table[idx] ** 2).sum()
+    loss.backward()
+    local = [p.grad.detach().clone() for p in model.parameters()]
+    red = parallel.GradReducer(model)
+    assert len(red.big) == 1 and len(red.small) == 2
+    red.all_reduce()
+    torch.save({"w0": w0, "local": local, "reduced": [p.grad.clone() for p in model.parameters()]},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True) for r in range(world)]
+    for a, b in zip(outs[0]["w0"], outs[1]["w0"]):
+        assert torch.equal(a, b)                                    # broadcast made the replicas identical
+    for k in range(3):
+        mean = (outs[0]["local"][k] + outs[1]["local"][k]) / 2
+        for r in range(world):
+            np.testing.assert_allclose(outs[r]["reduced"][k].numpy(), mean.numpy(), rtol=1e-6, atol=1e-7)
+    assert not torch.equal(outs[0]["local"][2], outs[1]["local"][2])   # the shards really differed
+
+
+def test_single_process_is_a_noop():
+    from raw_ngp_amd import parallel
+    assert parallel.world_size() == 1 and parallel.rank() == 0
+    m = torch.nn.Linear(2, 2)
+    parallel.broadcast_module(m)
+    parallel.GradReducer(m).all_reduce()
+    parallel.barrier()
