@@ -50,7 +50,8 @@ def cpu_baseline(opt, n_rays, steps, seed=0):
     """One training step restated on the CPU oracle; returns rays/s and the thread count."""
     from oracle import oracle as orc
     import torch.nn.functional as F
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of host cores (16); more OpenMP threads than that only thrash
+    threads = min(len(os.sched_getaffinity(0)), 16)
     orc.set_threads(threads)
     torch.set_num_threads(threads)
     rng = np.random.default_rng(seed)

@@ -26,6 +26,7 @@
 #ifndef NGP_HIP_H
 #define NGP_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -167,6 +168,24 @@ int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const
                                  float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
                                  float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
                                  ngp_stream_t stream);
+
+/* Hash-grid table gradient without global float atomics (D = 3, C = 2 only): same result as
+ * ngp_grid_encode_backward's scatter (grad_embeddings += ...; different summation order), computed as
+ * bin -> LDS reduce (csrc/grid_backward_binned.hip).  Needs caller-owned scratch:
+ *   workspace_bytes >= ngp_x_grid_backward_workspace_bytes(B, L, n_rows_total), 16-byte aligned,
+ *   n_rows_total = rows of `embeddings` (= offsets[L], known to the host from the tensor shape).
+ * Does not compute grad_inputs (call ngp_grid_encode_backward's input part separately if needed). */
+size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, uint32_t n_rows_total);
+int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,
+                                      float *grad_embeddings, uint32_t B, uint32_t L, uint32_t max_level,
+                                      float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                      uint32_t interp, uint32_t n_rows_total, void *workspace,
+                                      size_t workspace_bytes, ngp_stream_t stream);
+
+/* grad_inputs[b, d] = sum_{l, ch} grad[l, b, ch] * dy_dx[b, l, d, ch] -- the second half of
+ * ngp_grid_encode_backward (gridencoder.cu:352-378) on its own. */
+int ngp_x_grid_input_backward(const float *grad, const float *dy_dx, float *grad_inputs, uint32_t B, uint32_t D,
+                              uint32_t C, uint32_t L, ngp_stream_t stream);
 
 #ifdef __cplusplus
 }

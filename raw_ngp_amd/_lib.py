@@ -41,6 +41,8 @@ _SIGNATURES = {
     "ngp_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
     "ngp_march_rays": [_u, _u, _p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _p, _p, _p, _p, _p, _p, _p],
     "ngp_composite_rays": [_u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _p],
+    "ngp_x_grid_encode_backward_binned": [_p, _p, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _p, ctypes.c_size_t],
+    "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u],
     "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_march_rays_train_arena": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _u, _p, _p, _p,
                                      _p, _p, _p, _p],
@@ -61,6 +63,8 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
         lib.ngp_last_error.restype = ctypes.c_char_p
         lib.ngp_abi_version.restype = ctypes.c_int
+        lib.ngp_x_grid_backward_workspace_bytes.argtypes = [_u, _u, _u]
+        lib.ngp_x_grid_backward_workspace_bytes.restype = ctypes.c_size_t
         for name, args in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = list(args) + [_p]
@@ -70,7 +74,7 @@ def load():
 
 
 def declared_symbols():
-    return ["ngp_abi_version", "ngp_last_error"] + list(_SIGNATURES)
+    return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes"] + list(_SIGNATURES)
 
 
 _DT = {"f": torch.float32, "i": torch.int32, "b": torch.uint8}
@@ -133,9 +137,24 @@ class _GridBackend:
               _ptr(offsets, "i", "offsets"), _ptr(outputs, "f", "outputs"), B, D, C, L, max_level, float(S), H,
               _ptr(dy_dx, "f", "dy_dx", True), gridtype, int(bool(align_corners)), interp)
 
+    # D = 3, C = 2 (the field's encoder) takes the atomic-free binned scatter; everything else, or
+    # use_binned_backward = False, takes the reference-shaped float-atomic kernel.
+    use_binned_backward = True
+
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S, H, dy_dx,
                              grad_inputs, gridtype, align_corners, interp):
+        if _GridBackend.use_binned_backward and D == 3 and C == 2 and B * L * 8 < 2 ** 32:
+            rows = embeddings.shape[0]
+            nbytes = load().ngp_x_grid_backward_workspace_bytes(B, L, rows)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=grad.device)
+            _call("ngp_x_grid_encode_backward_binned", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
+                  _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings"), B, L, max_level,
+                  float(S), H, gridtype, int(bool(align_corners)), interp, rows, ws.data_ptr(), nbytes)
+            if dy_dx is not None and grad_inputs is not None:
+                _call("ngp_x_grid_input_backward", grad, _ptr(grad, "f", "grad"), _ptr(dy_dx, "f", "dy_dx"),
+                      _ptr(grad_inputs, "f", "grad_inputs"), B, D, C, L)
+            return
         _call("ngp_grid_encode_backward", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
               _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"),
               _ptr(grad_embeddings, "f", "grad_embeddings"), B, D, C, L, max_level, float(S), H,

@@ -11,159 +11,9 @@
 // modulo mode) derived once per workgroup in scalar registers, whole-row vector gathers
 // (float2 for C = 2) all issued before the first use, streaming (non-temporal) stores.
 // Arithmetic choices (explicit fmaf, no implicit contraction) mirror oracle/ngp_oracle.c.
-#include "ngp_common.hpp"
+#include "grid_common.hpp"
 
 namespace ngp {
-
-constexpr uint32_t kMaxLevels = 64;
-constexpr uint32_t kBlock = 256;
-
-struct LevelRes {
-    uint32_t res[kMaxLevels];
-};
-
-__device__ constexpr uint32_t kPrimes[7] = {1u,          2654435761u, 805459861u, 3674653429u,
-                                            2097192037u, 1434869437u, 2165219737u};
-
-// Per-level geometry; every field is workgroup-uniform (lives in SGPRs).
-template <uint32_t D>
-struct Geom {
-    uint32_t T;          // rows in this level
-    uint32_t res;
-    uint32_t stride[D];  // dense strides (uint32 wrap like the reference)
-    uint32_t nd;         // dims that entered the dense index before stride exceeded T
-    bool hashed;
-    uint32_t mode;       // 0: index < T by construction, 1: T is a power of two (mask), 2: modulo
-};
-
-template <uint32_t D>
-__device__ __forceinline__ Geom<D> make_geom(const int32_t *__restrict__ offsets, uint32_t level, uint32_t res,
-                                            uint32_t gridtype)
-{
-    Geom<D> g;
-    g.T = (uint32_t)(offsets[level + 1] - offsets[level]);
-    g.res = res;
-    uint32_t stride = 1, d = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < D; k++) g.stride[k] = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < D; k++) {
-        if (d == k && stride <= g.T) {
-            g.stride[k] = stride;
-            stride *= res;
-            d = k + 1;
-        }
-    }
-    g.nd = d;
-    g.hashed = (gridtype == 0u) && (stride > g.T);
-    if (!g.hashed && d == D && stride <= g.T)
-        g.mode = 0;
-    else if ((g.T & (g.T - 1u)) == 0u)
-        g.mode = 1;
-    else
-        g.mode = 2;
-    return g;
-}
-
-template <uint32_t D>
-__device__ __forceinline__ uint32_t row_of(const Geom<D> &g, const uint32_t (&c)[D])
-{
-    uint32_t idx = 0;
-    if (g.hashed) {
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) idx ^= c[d] * kPrimes[d];
-    } else {
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) idx += c[d] * g.stride[d];  // stride 0 for dims past nd
-    }
-    if (g.mode == 1)
-        idx &= g.T - 1u;
-    else if (g.mode == 2)
-        idx %= g.T;
-    return idx;
-}
-
-template <uint32_t D>
-struct Cell {
-    uint32_t c[D];
-    float f[D];
-    float df[D];
-};
-
-// false when the point is outside [0,1]^D (the reference zeroes / skips those)
-template <uint32_t D>
-__device__ __forceinline__ bool locate(const float (&x)[D], uint32_t res, bool align_corners, uint32_t interp,
-                                       Cell<D> &o)
-{
-    bool inside = true;
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) inside = inside && !(x[d] < 0.0f || x[d] > 1.0f);
-    if (!inside) return false;
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) {
-        float p;
-        uint32_t c;
-        if (align_corners) {
-            p = x[d] * (float)(res - 1u);
-            c = min((uint32_t)floorf(p), res - 2u);
-        } else {
-            p = fminf(fmaxf(fmaf(x[d], (float)res, -0.5f), 0.0f), (float)(res - 1u));
-            c = (uint32_t)floorf(p);
-        }
-        p -= (float)c;
-        if (interp == 1u) {
-            o.df[d] = 6.0f * p * (1.0f - p);
-            p = p * p * (3.0f - 2.0f * p);
-        } else {
-            o.df[d] = 1.0f;
-        }
-        o.c[d] = c;
-        o.f[d] = p;
-    }
-    return true;
-}
-
-// Row access in the widest vector the channel count allows.
-template <uint32_t C>
-struct Row {
-    float v[C];
-    __device__ __forceinline__ void load(const float *__restrict__ p)
-    {
-        if constexpr (C == 1) {
-            v[0] = p[0];
-        } else if constexpr (C == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(p);
-            v[0] = t.x;
-            v[1] = t.y;
-        } else {
-#pragma unroll
-            for (uint32_t i = 0; i < C; i += 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(p + i);
-                v[i] = t.x;
-                v[i + 1] = t.y;
-                v[i + 2] = t.z;
-                v[i + 3] = t.w;
-            }
-        }
-    }
-    __device__ __forceinline__ void store_stream(float *__restrict__ p) const
-    {
-        if constexpr (C == 1) {
-            __builtin_nontemporal_store(v[0], p);
-        } else if constexpr (C == 2) {
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            f2 t = {v[0], v[1]};
-            __builtin_nontemporal_store(t, reinterpret_cast<f2 *>(p));
-        } else {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-            for (uint32_t i = 0; i < C; i += 4) {
-                f4 t = {v[i], v[i + 1], v[i + 2], v[i + 3]};
-                __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p + i));
-            }
-        }
-    }
-};
 
 // ------------------------------------------------------------------ forward
 template <uint32_t D, uint32_t C, bool JAC>
@@ -418,14 +268,6 @@ __global__ __launch_bounds__(kBlock) void grid_wd_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------ host side
-static bool fill_levels(LevelRes &lv, float S, uint32_t H, uint32_t L)
-{
-    if (L == 0 || L > kMaxLevels) return false;
-    for (uint32_t l = 0; l < L; l++) lv.res[l] = (uint32_t)ceilf(exp2f((float)l * S) * (float)H);
-    for (uint32_t l = L; l < kMaxLevels; l++) lv.res[l] = 0;
-    return true;
-}
-
 template <uint32_t D, uint32_t C>
 static void launch_forward(const float *inputs, const float *table, const int32_t *offsets, float *outputs,
                            float *dy_dx, uint32_t B, uint32_t L, uint32_t max_level, const LevelRes &lv,
@@ -527,6 +369,24 @@ extern "C" int ngp_grid_encode_backward(const float *grad, const float *inputs, 
     NGP_DISPATCH_DC(launch_backward, grad, inputs, offsets, grad_embeddings, B, L, max_level, lv, dy_dx,
                     grad_inputs, gridtype, align_corners != 0, interp, as_stream(stream));
     NGP_CHECK_LAUNCH("grid_encode_backward");
+    return NGP_OK;
+}
+
+template <uint32_t D, uint32_t C>
+static void launch_input_backward(const float *grad, const float *dy_dx, float *grad_inputs, uint32_t B, uint32_t L,
+                                  hipStream_t st)
+{
+    grid_input_backward_kernel<D, C><<<dim3(ceil_div(B * D, kBlock)), kBlock, 0, st>>>(grad, dy_dx, grad_inputs, B, L);
+}
+
+extern "C" int ngp_x_grid_input_backward(const float *grad, const float *dy_dx, float *grad_inputs, uint32_t B,
+                                         uint32_t D, uint32_t C, uint32_t L, ngp_stream_t stream)
+{
+    if (B == 0) return NGP_OK;
+    NGP_REQUIRE(grad && dy_dx && grad_inputs, "grid_input_backward: null tensor");
+    if (int e = check_dc("grid_input_backward", D, C)) return e;
+    NGP_DISPATCH_DC(launch_input_backward, grad, dy_dx, grad_inputs, B, L, as_stream(stream));
+    NGP_CHECK_LAUNCH("grid_input_backward");
     return NGP_OK;
 }
 

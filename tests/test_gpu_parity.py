@@ -84,22 +84,33 @@ def test_grid_forward_and_jacobian(be, orc, case):
     assert torch.all(out2[L - 1] == 0)
 
 
+@pytest.mark.parametrize("binned", [True, False], ids=["binned", "atomic"])
 @pytest.mark.parametrize("case", GRID_CASES[:7], ids=lambda c: f"D{c[0]}C{c[1]}L{c[2]}g{c[6]}")
-def test_grid_backward(be, orc, case):
+def test_grid_backward(be, orc, case, binned, monkeypatch):
+    """binned = bin -> LDS-reduce scatter (D3 C2 only, what the op wrapper uses); atomic = reference-shaped."""
+    monkeypatch.setattr(type(be.gridencoder_backend), "use_binned_backward", binned)
     D, C, L, H, log2T, desired, gridtype, align, interp, B = case
     offsets, S, table, x = grid_setup(orc, D, C, L, H, log2T, desired, B, seed=1)
     rng = np.random.default_rng(2)
     g = rng.normal(size=(L, B, C)).astype(np.float32)
     _, jac = orc.grid_encode_forward(x, table, offsets, B, D, C, L, L, S, H, True, gridtype, align, interp)
     ref_gt, ref_gi = orc.grid_encode_backward(g, x, table, offsets, B, D, C, L, L, S, H, jac, gridtype, align, interp)
-    gt = torch.zeros(int(offsets[-1]), C, device="cuda")
+    pre = np.random.default_rng(3).normal(size=(int(offsets[-1]), C)).astype(np.float32)   # "+=" semantics
+    gt = dev(pre)
     gi = torch.zeros(B, D, device="cuda")
     be.gridencoder_backend.grid_encode_backward(dev(g), dev(x), dev(table), dev(offsets), gt, B, D, C, L, L, S, H,
                                                 dev(jac), gi, gridtype, align, interp)
-    # float atomics in hardware order vs a double-precision sum: error ~ eps * sum|terms|
+    # float sums in hardware order vs a double-precision sum: error ~ eps * sum|terms|
     scale = np.abs(ref_gt).max()
-    np.testing.assert_allclose(host(gt), ref_gt, rtol=1e-4, atol=2e-6 * max(scale, 1.0) * 8)
+    np.testing.assert_allclose(host(gt) - pre, ref_gt, rtol=1e-4, atol=2e-6 * max(scale, 1.0) * 8)
     np.testing.assert_allclose(host(gi), ref_gi, rtol=1e-5, atol=1e-4 * np.abs(ref_gi).max())
+    # max_level < L leaves the tail levels' rows untouched
+    gt2 = torch.zeros(int(offsets[-1]), C, device="cuda")
+    be.gridencoder_backend.grid_encode_backward(dev(g), dev(x), dev(table), dev(offsets), gt2, B, D, C, L, L - 1, S, H,
+                                                None, None, gridtype, align, interp)
+    assert torch.all(gt2[int(offsets[L - 1]):] == 0)
+    np.testing.assert_allclose(host(gt2)[:int(offsets[L - 1])], ref_gt[:int(offsets[L - 1])], rtol=1e-4,
+                               atol=2e-6 * max(scale, 1.0) * 8)
 
 
 def test_grid_tv_and_wd(be, orc):

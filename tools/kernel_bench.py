@@ -77,9 +77,12 @@ def main():
     if want("grid_bwd"):
         grad = torch.randn(L, B, C, device="cuda", generator=g)
         gt = torch.zeros(rows, C, device="cuda")
-        sec = timeit(lambda: gb.grid_encode_backward(grad, x, table, offsets, gt, B, D, C, L, L, S, H, None, None, 0, False, 0),
-                     max(args.iters // 5, 3), warmup=2)
-        report("grid_encode_backward(atomics)", sec, B * (12 + L * (8 + 64)))
+        for binned in (True, False):
+            type(gb).use_binned_backward = binned
+            sec = timeit(lambda: gb.grid_encode_backward(grad, x, table, offsets, gt, B, D, C, L, L, S, H, None, None, 0, False, 0),
+                         max(args.iters // 5, 3), warmup=2)
+            report("grid_encode_backward(%s)" % ("binned" if binned else "atomics"), sec, B * (12 + L * (8 + 64)))
+        type(gb).use_binned_backward = True
     if want("sh"):
         v = torch.randn(B, 3, device="cuda", generator=g)
         v = v / v.norm(dim=-1, keepdim=True)
