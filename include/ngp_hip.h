@@ -187,6 +187,37 @@ int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, co
 int ngp_x_grid_input_backward(const float *grad, const float *dy_dx, float *grad_inputs, uint32_t B, uint32_t D,
                               uint32_t C, uint32_t L, ngp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused tiny-MLP field (csrc/fused_mlp*.hip): replaces the six nn.Linear GEMMs + slicing / cat /
+ * activation kernels of nerf/network.py:27-35,74-143 for the default field configuration
+ * (grid_mlp 32-64-64-16, view_mlp 31-64-64-3, bias-free, ReLU, density trunc_exp, colour clamped_exp,
+ * no rfield).  f16 MFMA operands with f32 accumulation = the precision of the reference's `--fp16`
+ * autocast path; weights stay fp32 masters in torch layout [out][in].
+ *   image  scratch of ngp_x_mlp_image_bytes() bytes, 16-byte aligned: f16 operand fragments, rebuilt by
+ *          ngp_x_mlp_prepare whenever the weights change (once per optimiser step)
+ *   enc    hash-grid features in the level-major slab layout the grid kernel writes: [16][stride][2]
+ *   dirs   [M,3] view directions (any length; normalised in-kernel)
+ *   M_dev  optional device int32: number of valid samples (clamped to M); NULL = use M
+ * ---------------------------------------------------------------------------------- */
+size_t ngp_x_mlp_image_bytes(void);
+int ngp_x_mlp_prepare(const float *w1, const float *w2, const float *w3, const float *w4, const float *w5,
+                      const float *w6, void *image, ngp_stream_t stream);
+/* sigma [M], rgb [M,3] */
+int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
+                      const void *image, float *sigma, float *rgb, ngp_stream_t stream);
+
+/* Backward of the fused field.  dsigma [M], drgb [M,3] = dL/d(sigma, rgb); outputs d(enc) in the slab
+ * layout of `enc` (rows >= M untouched) and the six weight gradients (fp32, torch layout, OVERWRITTEN).
+ * Activations are recomputed from enc / dirs; nothing from the forward call is needed.  `loss_scale`
+ * multiplies the incoming deltas before they become f16 operands and is divided out of every output
+ * (the role GradScaler plays in the reference's --fp16 path, train_utils.py:404,897); 1024 is a good value.
+ * workspace: ngp_x_mlp_backward_workspace_bytes(M) bytes, 16-byte aligned. */
+size_t ngp_x_mlp_backward_workspace_bytes(uint32_t M);
+int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float *dirs, const float *dsigma,
+                       const float *drgb, const int32_t *M_dev, uint32_t M, const void *image, float loss_scale,
+                       float *denc, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6,
+                       void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,9 @@ _SIGNATURES = {
     "ngp_composite_rays": [_u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _p],
     "ngp_x_grid_encode_backward_binned": [_p, _p, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _p, ctypes.c_size_t],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u],
+    "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
+    "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
+    "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_march_rays_train_arena": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _u, _p, _p, _p,
                                      _p, _p, _p, _p],
@@ -65,6 +68,10 @@ def load():
         lib.ngp_abi_version.restype = ctypes.c_int
         lib.ngp_x_grid_backward_workspace_bytes.argtypes = [_u, _u, _u]
         lib.ngp_x_grid_backward_workspace_bytes.restype = ctypes.c_size_t
+        lib.ngp_x_mlp_image_bytes.argtypes = []
+        lib.ngp_x_mlp_image_bytes.restype = ctypes.c_size_t
+        lib.ngp_x_mlp_backward_workspace_bytes.argtypes = [_u]
+        lib.ngp_x_mlp_backward_workspace_bytes.restype = ctypes.c_size_t
         for name, args in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = list(args) + [_p]
@@ -74,7 +81,8 @@ def load():
 
 
 def declared_symbols():
-    return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes"] + list(_SIGNATURES)
+    return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes",
+            "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes"] + list(_SIGNATURES)
 
 
 _DT = {"f": torch.float32, "i": torch.int32, "b": torch.uint8}
@@ -291,7 +299,38 @@ class _RayBackend:
               _ptr(rays, "i", "rays"), _ptr(counter, "i", "counter"), _ptr(ray_idx, "i", "ray_idx", True))
 
 
+class _MlpBackend:
+    """Fused tiny-MLP field (extension; no counterpart among the reference's bindings)."""
+
+    @staticmethod
+    def image_bytes():
+        return int(load().ngp_x_mlp_image_bytes())
+
+    @staticmethod
+    def prepare(weights, image):
+        """weights: the six fp32 matrices (grid_mlp.net.0..2, view_mlp.net.0..2) in torch layout."""
+        _call("ngp_x_mlp_prepare", image, *[_ptr(w, "f", f"w{i + 1}") for i, w in enumerate(weights)],
+              image.data_ptr())
+
+    @staticmethod
+    def forward(enc, stride, dirs, M_dev, M, image, sigma, rgb):
+        _call("ngp_x_mlp_forward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"),
+              _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb"))
+
+
+    @staticmethod
+    def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws):
+        """dws: six pre-allocated fp32 tensors shaped like the weights (overwritten)."""
+        nbytes = load().ngp_x_mlp_backward_workspace_bytes(M)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+        _call("ngp_x_mlp_backward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"),
+              _ptr(dsigma, "f", "dsigma"), _ptr(drgb, "f", "drgb"), _ptr(M_dev, "i", "M_dev", True), M,
+              image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"),
+              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], ws.data_ptr(), nbytes)
+
+
 gridencoder_backend = _GridBackend()
+mlp_backend = _MlpBackend()
 shencoder_backend = _SHBackend()
 freqencoder_backend = _FreqBackend()
 raymarching_backend = _RayBackend()

@@ -1,0 +1,251 @@
+// Fused tiny-MLP field evaluation on the matrix cores (gfx950 MFMA, f16 operands, f32 accumulate).
+//
+// Replaces, for the default field configuration, what the reference does as six nn.Linear GEMMs plus
+// slicing / cat / activation kernels per direction (nerf/network.py:27-35, :74-143; under `--fp16` those
+// GEMMs run in fp16 autocast, renderer.py:546):
+//     h     = W3 relu(W2 relu(W1 enc))                 enc = 32 hash-grid features
+//     sigma = exp(h[0])                                  (trunc_exp, activation.py:9-19)
+//     rgb   = min(exp(W6 relu(W5 relu(W4 [h[1:16], SH16(dir)])) - 5), 5)        (clamped_exp)
+// One wave = 32 samples; the six layers are chained through MFMA accumulators (see mlp_common.hpp), so no
+// activation ever leaves the register file in the forward pass; the encoder output is consumed in the
+// level-major [L, stride, 2] slab layout the grid kernel writes (no permute), SH is evaluated in-kernel.
+#include "mlp_common.hpp"
+#include "sh_eval.hpp"
+
+namespace ngp {
+
+struct MlpWeights {
+    const float *w1, *w2, *w3, *w4, *w5, *w6;
+};
+
+// ------------------------------------------------------------------ weight image
+__device__ __forceinline__ float frag_elem(uint32_t f, uint32_t r, uint32_t h, uint32_t t, const MlpWeights &W)
+{
+    if (f < F_W2) {
+        const uint32_t i = f - F_W1, rb = i >> 1, s = i & 1;
+        return W.w1[(32 * rb + r) * 32 + kperm(s, h, t)];
+    }
+    if (f < F_W3) {
+        const uint32_t i = f - F_W2, rb = i >> 2, kb = (i >> 1) & 1, s = i & 1;
+        return W.w2[(32 * rb + r) * 64 + 32 * kb + kperm(s, h, t)];
+    }
+    if (f < F_W4) {
+        const uint32_t i = f - F_W3, kb = i >> 1, s = i & 1;
+        return r < 16 ? W.w3[r * 64 + 32 * kb + kperm(s, h, t)] : 0.0f;
+    }
+    if (f < F_W5) {
+        const uint32_t i = f - F_W4, rb = i >> 1, s = i & 1, k = kperm(s, h, t);
+        return k >= 1 ? W.w4[(32 * rb + r) * 31 + k - 1] : 0.0f;
+    }
+    if (f < F_W6) {
+        const uint32_t i = f - F_W5, rb = i >> 2, kb = (i >> 1) & 1, s = i & 1;
+        return W.w5[(32 * rb + r) * 64 + 32 * kb + kperm(s, h, t)];
+    }
+    if (f < T_W6) {
+        const uint32_t i = f - F_W6, kb = i >> 1, s = i & 1;
+        return r < 3 ? W.w6[r * 64 + 32 * kb + kperm(s, h, t)] : 0.0f;
+    }
+    if (f < T_W5) {
+        const uint32_t rb = f - T_W6, k = kperm(0, h, t);
+        return k < 3 ? W.w6[k * 64 + 32 * rb + r] : 0.0f;
+    }
+    if (f < T_W4) {
+        const uint32_t i = f - T_W5, rb = i >> 2, kb = (i >> 1) & 1, s = i & 1;
+        return W.w5[(32 * kb + kperm(s, h, t)) * 64 + 32 * rb + r];
+    }
+    if (f < T_W3) {
+        const uint32_t i = f - T_W4, kb = i >> 1, s = i & 1;
+        return r >= 1 ? W.w4[(32 * kb + kperm(s, h, t)) * 31 + r - 1] : 0.0f;
+    }
+    if (f < T_W2) {
+        const uint32_t rb = f - T_W3, k = kperm(0, h, t);
+        return k < 16 ? W.w3[k * 64 + 32 * rb + r] : 0.0f;
+    }
+    if (f < T_W1) {
+        const uint32_t i = f - T_W2, rb = i >> 2, kb = (i >> 1) & 1, s = i & 1;
+        return W.w2[(32 * kb + kperm(s, h, t)) * 64 + 32 * rb + r];
+    }
+    const uint32_t i = f - T_W1, kb = i >> 1, s = i & 1;
+    return W.w1[(32 * kb + kperm(s, h, t)) * 32 + r];
+}
+
+__global__ __launch_bounds__(256) void mlp_prepare_kernel(MlpWeights W, _Float16 *__restrict__ image)
+{
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kMlpImageHalfs) return;
+    const uint32_t t = e & 7u, lane = (e >> 3) & 63u, f = e >> 9;
+    image[e] = (_Float16)frag_elem(f, lane & 31u, lane >> 5, t, W);
+}
+
+// ------------------------------------------------------------------ per-tile pieces shared with the backward kernels
+struct TileIn {
+    half8 x0[2];   // encoder features as B fragments (k-steps 0, 1)
+    half8 sh;      // SH16(dir) as the k-step-1 fragment of the view-MLP input
+};
+
+// lane (n, h): loads its half of the 32 encoder features of sample `row` and the SH basis of its direction
+__device__ __forceinline__ TileIn load_tile(const float *__restrict__ enc, size_t stride, const float *__restrict__ dirs,
+                                            uint32_t row, bool valid, uint32_t h)
+{
+    TileIn in;
+#pragma unroll
+    for (uint32_t s = 0; s < 2; s++)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {
+            // features 16s + 8q + 4h + {0..3} = levels 8s + 4q + 2h + {0, 1}, both channels
+            const uint32_t level = 8 * s + 4 * q + 2 * h;
+            float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+            if (valid) {
+                a = reinterpret_cast<const float2 *>(enc)[(size_t)level * stride + row];
+                b = reinterpret_cast<const float2 *>(enc)[(size_t)(level + 1) * stride + row];
+            }
+            in.x0[s][4 * q + 0] = (_Float16)a.x;
+            in.x0[s][4 * q + 1] = (_Float16)a.y;
+            in.x0[s][4 * q + 2] = (_Float16)b.x;
+            in.x0[s][4 * q + 3] = (_Float16)b.y;
+        }
+    float dx = 0.f, dy = 0.f, dz = 1.f;
+    if (valid) {
+        dx = dirs[(size_t)row * 3];
+        dy = dirs[(size_t)row * 3 + 1];
+        dz = dirs[(size_t)row * 3 + 2];
+    }
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    float sh[16], j0[1], j1[1], j2[1];
+    sh_eval<4, false>(dx * inv, dy * inv, dz * inv, sh, j0, j1, j2);
+    // element t of the k-step-1 fragment is SH index kperm(1, h, t) - 16 = 8 (t >> 2) + 4 h + (t & 3)
+#pragma unroll
+    for (uint32_t t = 0; t < 8; t++) {
+        const float lo = sh[8 * (t >> 2) + (t & 3)], hi = sh[8 * (t >> 2) + 4 + (t & 3)];
+        in.sh[t] = (_Float16)(h ? hi : lo);
+    }
+    return in;
+}
+
+// One 64-wide layer from a 64-feature input held as fragments xin[kb][s]:  acc[rb] = sum W[rb][kb][s] * xin[kb][s]
+#define NGP_LAYER64(acc, wf, base, xin)                                                   \
+    do {                                                                                  \
+        _Pragma("unroll") for (int rb = 0; rb < 2; rb++) {                                \
+            acc[rb] = zero16();                                                           \
+            _Pragma("unroll") for (int kb = 0; kb < 2; kb++)                              \
+                _Pragma("unroll") for (int s = 0; s < 2; s++)                             \
+                    acc[rb] = mfma(wf[(base) + rb * 4 + kb * 2 + s], xin[kb][s], acc[rb]); \
+        }                                                                                 \
+    } while (0)
+
+// ------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const float *__restrict__ enc, uint32_t stride,
+                                                            const float *__restrict__ dirs,
+                                                            const int32_t *__restrict__ M_dev, uint32_t M_host,
+                                                            const half8 *__restrict__ image,
+                                                            float *__restrict__ sigma, float *__restrict__ rgb)
+{
+    const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+    const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_host) : M_host;
+    const uint32_t n_tiles = (M + 31u) >> 5;
+
+    half8 wf[32];   // all forward fragments live in registers for the whole kernel
+#pragma unroll
+    for (int i = 0; i < 32; i++) wf[i] = image[(size_t)i * 64 + lane];
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t row = tile * 32u + n;
+        const bool valid = row < M;
+        const TileIn in = load_tile(enc, stride, dirs, row, valid, h);
+
+        f32x16 a[2];
+        half8 x[2][2];
+        // layer 1: 32 -> 64
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            a[rb] = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; s++) a[rb] = mfma(wf[F_W1 + rb * 2 + s], in.x0[s], a[rb]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            x[kb][0] = pack<0, true>(a[kb]);
+            x[kb][1] = pack<1, true>(a[kb]);
+        }
+        // layer 2: 64 -> 64
+        NGP_LAYER64(a, wf, F_W2, x);
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            x[kb][0] = pack<0, true>(a[kb]);
+            x[kb][1] = pack<1, true>(a[kb]);
+        }
+        // layer 3: 64 -> 16 (rows 0..15 of one tile): row 0 = raw density, rows 1..15 = geometry features
+        f32x16 o = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) o = mfma(wf[F_W3 + kb * 2 + s], x[kb][s], o);
+        const float sigma_raw = o[0];
+        // layer 4: [sigma row (zero weight), 15 features, SH16] -> 64
+        const half8 x3a = pack<0, false>(o);
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            a[rb] = zero16();
+            a[rb] = mfma(wf[F_W4 + rb * 2 + 0], x3a, a[rb]);
+            a[rb] = mfma(wf[F_W4 + rb * 2 + 1], in.sh, a[rb]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            x[kb][0] = pack<0, true>(a[kb]);
+            x[kb][1] = pack<1, true>(a[kb]);
+        }
+        // layer 5: 64 -> 64
+        NGP_LAYER64(a, wf, F_W5, x);
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            x[kb][0] = pack<0, true>(a[kb]);
+            x[kb][1] = pack<1, true>(a[kb]);
+        }
+        // layer 6: 64 -> 3
+        f32x16 c = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) c = mfma(wf[F_W6 + kb * 2 + s], x[kb][s], c);
+
+        if (valid && h == 0) {   // rows 0..3 of a tile live in registers 0..3 of the h = 0 lanes
+            sigma[row] = __expf(sigma_raw);
+            rgb[(size_t)row * 3 + 0] = fminf(__expf(c[0] - 5.0f), 5.0f);
+            rgb[(size_t)row * 3 + 1] = fminf(__expf(c[1] - 5.0f), 5.0f);
+            rgb[(size_t)row * 3 + 2] = fminf(__expf(c[2] - 5.0f), 5.0f);
+        }
+    }
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" size_t ngp_x_mlp_image_bytes(void) { return (size_t)kMlpImageHalfs * 2; }
+
+extern "C" int ngp_x_mlp_prepare(const float *w1, const float *w2, const float *w3, const float *w4, const float *w5,
+                                 const float *w6, void *image, ngp_stream_t stream)
+{
+    NGP_REQUIRE(w1 && w2 && w3 && w4 && w5 && w6 && image, "mlp_prepare: null tensor");
+    NGP_REQUIRE(((uintptr_t)image & 15u) == 0, "mlp_prepare: image must be 16-byte aligned");
+    MlpWeights W{w1, w2, w3, w4, w5, w6};
+    mlp_prepare_kernel<<<dim3(ceil_div(kMlpImageHalfs, 256u)), dim3(256), 0, as_stream(stream)>>>(
+        W, reinterpret_cast<_Float16 *>(image));
+    NGP_CHECK_LAUNCH("mlp_prepare");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
+                                 const void *image, float *sigma, float *rgb, ngp_stream_t stream)
+{
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(enc && dirs && image && sigma && rgb, "mlp_forward: null tensor");
+    NGP_REQUIRE(stride >= M, "mlp_forward: encoder slab stride smaller than M");
+    const uint32_t tiles = ceil_div(M, 32u);
+    const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * 2u);
+    mlp_forward_kernel<<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(enc, stride, dirs, M_dev, M,
+                                                                         reinterpret_cast<const half8 *>(image), sigma, rgb);
+    NGP_CHECK_LAUNCH("mlp_forward");
+    return NGP_OK;
+}

@@ -1,0 +1,535 @@
+// Backward of the fused tiny-MLP field: weight gradients and the gradient w.r.t. the encoder features.
+//
+// Replaces the autograd backward of the six nn.Linear layers + activations of nerf/network.py:74-143
+// (reference: cuBLAS/hipBLASLt GEMMs over [M, 64] activations stored in HBM).  Nothing is stored by the
+// forward pass: each kernel recomputes the activations of its 32-sample tile in registers, then runs the
+// delta chain with transposed weight fragments (mlp_common.hpp).  Weight gradients need the contraction
+// over SAMPLES, which live on the lanes of every tile; instead of a round trip through LDS the tiles are
+// transposed on the matrix cores themselves (tile^T = tile-as-A x identity-as-B, exact in f16), after
+// which  dW[o][c] += delta^T-as-A x act^T-as-B  is again a plain MFMA.  The MFMA work roughly doubles
+// (146 instead of ~70 per 32 samples); at 32 cycles each that is still ~20 us for 2^18 samples.
+//
+// Two kernels because 16 dW accumulator tiles (256 VGPRs) do not fit next to the chain:
+//   view kernel  recompute all six layers; deltas of the colour MLP; dW4, dW5, dW6; writes delta3 (the
+//                gradient at the 16 outputs of the density MLP, f16, operand order) to a scratch slab
+//   grid kernel  recompute layers 1-2; reads delta3; dW1, dW2, dW3; writes d(enc) in the [L, stride, 2] layout
+// Per-workgroup partial dW tiles go to a slab; ngp_x_mlp_backward's last kernel sums them, removes the
+// loss scale and emits the six fp32 gradients in torch layout.
+#include "mlp_common.hpp"
+#include "sh_eval.hpp"
+
+namespace ngp {
+
+constexpr uint32_t kAccFloats = 8 * 16 * 64;   // 8 accumulator tiles per kernel = 8192 floats per workgroup
+
+// ---- helpers -----------------------------------------------------------------------------------
+template <bool WANT_SH>
+struct TileInB {
+    half8 x0[2];
+    half8 sh;
+};
+
+template <bool WANT_SH>
+__device__ __forceinline__ TileInB<WANT_SH> load_tile_b(const float *__restrict__ enc, size_t stride,
+                                                       const float *__restrict__ dirs, uint32_t row, bool valid,
+                                                       uint32_t h)
+{
+    TileInB<WANT_SH> in;
+#pragma unroll
+    for (uint32_t s = 0; s < 2; s++)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {
+            const uint32_t level = 8 * s + 4 * q + 2 * h;
+            float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+            if (valid) {
+                a = reinterpret_cast<const float2 *>(enc)[(size_t)level * stride + row];
+                b = reinterpret_cast<const float2 *>(enc)[(size_t)(level + 1) * stride + row];
+            }
+            in.x0[s][4 * q + 0] = (_Float16)a.x;
+            in.x0[s][4 * q + 1] = (_Float16)a.y;
+            in.x0[s][4 * q + 2] = (_Float16)b.x;
+            in.x0[s][4 * q + 3] = (_Float16)b.y;
+        }
+    if constexpr (WANT_SH) {
+        float dx = 0.f, dy = 0.f, dz = 1.f;
+        if (valid) {
+            dx = dirs[(size_t)row * 3];
+            dy = dirs[(size_t)row * 3 + 1];
+            dz = dirs[(size_t)row * 3 + 2];
+        }
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        float sh[16], j0[1], j1[1], j2[1];
+        sh_eval<4, false>(dx * inv, dy * inv, dz * inv, sh, j0, j1, j2);
+#pragma unroll
+        for (uint32_t t = 0; t < 8; t++) {
+            const float lo = sh[8 * (t >> 2) + (t & 3)], hi = sh[8 * (t >> 2) + 4 + (t & 3)];
+            in.sh[t] = (_Float16)(h ? hi : lo);
+        }
+    }
+    return in;
+}
+
+// registers 8S..8S+7 of `a`, zeroed where the matching post-ReLU activation (same tile, same k-step) is 0
+template <int S>
+__device__ __forceinline__ half8 pack_masked(const f32x16 &a, const half8 &act)
+{
+    half8 o;
+#pragma unroll
+    for (int t = 0; t < 8; t++) o[t] = (_Float16)(act[t] > (_Float16)0.0f ? a[8 * S + t] : 0.0f);
+    return o;
+}
+
+__device__ __forceinline__ half8 identity_frag(uint32_t s, uint32_t lane)
+{
+    const uint32_t j = lane & 31u, h = lane >> 5;
+    half8 o;
+#pragma unroll
+    for (uint32_t t = 0; t < 8; t++) o[t] = (_Float16)(kperm(s, h, t) == j ? 1.0f : 0.0f);
+    return o;
+}
+
+// [32 features x 32 samples] (two operand fragments) -> [32 samples x 32 features]
+__device__ __forceinline__ f32x16 transpose_tile(half8 f0, half8 f1, half8 I0, half8 I1)
+{
+    f32x16 d = zero16();
+    d = mfma(f0, I0, d);
+    d = mfma(f1, I1, d);
+    return d;
+}
+
+#define NGP_FRAG(local_id) lds_w[(local_id) * 64 + lane]
+
+// sum the four waves' accumulator tiles in the workgroup's LDS image (wave after wave, so the order of
+// the additions is fixed and the result bitwise reproducible), then dump it to the partial slab
+__device__ __forceinline__ void flush_acc(float *lds_acc, const f32x16 (&g)[8], uint32_t lane, float *__restrict__ slab)
+{
+    const uint32_t wid = threadIdx.x >> 6;
+    __syncthreads();   // everyone is done reading weight fragments from this LDS
+    for (uint32_t turn = 0; turn < 4; turn++) {
+        if (wid == turn) {
+#pragma unroll
+            for (int b = 0; b < 8; b++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    float *p = &lds_acc[(b * 16 + v) * 64 + lane];
+                    *p = turn == 0 ? g[b][v] : *p + g[b][v];
+                }
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < kAccFloats; i += 256) slab[i] = lds_acc[i];
+}
+
+// ---- view kernel ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
+    const float *__restrict__ enc, uint32_t stride, const float *__restrict__ dirs, const float *__restrict__ dsigma,
+    const float *__restrict__ drgb, const int32_t *__restrict__ M_dev, uint32_t M_host,
+    const half8 *__restrict__ image, float loss_scale, half8 *__restrict__ d3buf, float *__restrict__ partial)
+{
+    extern __shared__ half8 lds_w[];   // fragments 0..45 (46 KiB); reused as the f32 reduction image at the end
+    const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+    const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_host) : M_host;
+    const uint32_t n_tiles = (M + 31u) >> 5;
+    for (uint32_t i = threadIdx.x; i < 46u * 64u; i += 256) lds_w[i] = image[i];
+    __syncthreads();
+    const half8 I0 = identity_frag(0, lane), I1 = identity_frag(1, lane);
+
+    f32x16 g[8];   // 0,1: dW4[rb]   2..5: dW5[rb][cb]   6,7: dW6[cb]
+#pragma unroll
+    for (int i = 0; i < 8; i++) g[i] = zero16();
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        asm volatile("" ::: "memory");   // keep the weight fragments in LDS: no hoisting of 46 KiB into VGPRs
+        const uint32_t row = tile * 32u + n;
+        const bool valid = row < M;
+        const TileInB<true> in = load_tile_b<true>(enc, stride, dirs, row, valid, h);
+
+        // ---------------- recompute the forward pass
+        f32x16 a[2];
+        half8 x[2][2], h3[2][2], h4[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            a[rb] = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; s++) a[rb] = mfma(NGP_FRAG(F_W1 + rb * 2 + s), in.x0[s], a[rb]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            x[kb][0] = pack<0, true>(a[kb]);
+            x[kb][1] = pack<1, true>(a[kb]);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            a[rb] = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) a[rb] = mfma(NGP_FRAG(F_W2 + rb * 4 + kb * 2 + s), x[kb][s], a[rb]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            x[kb][0] = pack<0, true>(a[kb]);
+            x[kb][1] = pack<1, true>(a[kb]);
+        }
+        f32x16 o = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) o = mfma(NGP_FRAG(F_W3 + kb * 2 + s), x[kb][s], o);
+        const float sigma_raw = o[0];
+        const half8 x3a = pack<0, false>(o);
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            a[rb] = zero16();
+            a[rb] = mfma(NGP_FRAG(F_W4 + rb * 2 + 0), x3a, a[rb]);
+            a[rb] = mfma(NGP_FRAG(F_W4 + rb * 2 + 1), in.sh, a[rb]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            h3[kb][0] = pack<0, true>(a[kb]);
+            h3[kb][1] = pack<1, true>(a[kb]);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            a[rb] = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) a[rb] = mfma(NGP_FRAG(F_W5 + rb * 4 + kb * 2 + s), h3[kb][s], a[rb]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            h4[kb][0] = pack<0, true>(a[kb]);
+            h4[kb][1] = pack<1, true>(a[kb]);
+        }
+        f32x16 c = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) c = mfma(NGP_FRAG(F_W6 + kb * 2 + s), h4[kb][s], c);
+
+        // ---------------- output deltas (scaled by loss_scale so that they survive f16)
+        float gs = 0.f, gr0 = 0.f, gr1 = 0.f, gr2 = 0.f;
+        if (valid) {
+            gs = dsigma[row];
+            gr0 = drgb[(size_t)row * 3];
+            gr1 = drgb[(size_t)row * 3 + 1];
+            gr2 = drgb[(size_t)row * 3 + 2];
+        }
+        f32x16 d6 = zero16();
+        if (h == 0) {   // rows 0..2 of the tile: d rgb / d raw = exp(raw - 5) where the clamp at 5 is inactive
+            const float e0 = __expf(c[0] - 5.0f), e1 = __expf(c[1] - 5.0f), e2 = __expf(c[2] - 5.0f);
+            d6[0] = e0 <= 5.0f ? gr0 * e0 * loss_scale : 0.0f;
+            d6[1] = e1 <= 5.0f ? gr1 * e1 * loss_scale : 0.0f;
+            d6[2] = e2 <= 5.0f ? gr2 * e2 * loss_scale : 0.0f;
+        }
+        const half8 p6 = pack<0, false>(d6);
+
+        // ---------------- layer 6: dW6 = delta6 x H4^T ; delta5 = W6^T delta6 (masked)
+        half8 aT[2], bT[2];
+        {
+            const f32x16 t6 = mfma(p6, I0, zero16());
+            aT[0] = pack<0, false>(t6);
+            aT[1] = pack<1, false>(t6);
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                const f32x16 tt = transpose_tile(h4[cb][0], h4[cb][1], I0, I1);
+                bT[0] = pack<0, false>(tt);
+                bT[1] = pack<1, false>(tt);
+                g[6 + cb] = mfma(aT[0], bT[0], g[6 + cb]);
+                g[6 + cb] = mfma(aT[1], bT[1], g[6 + cb]);
+            }
+        }
+        half8 p5[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            const f32x16 dh = mfma(NGP_FRAG(T_W6 + rb), p6, zero16());
+            p5[rb][0] = pack_masked<0>(dh, h4[rb][0]);
+            p5[rb][1] = pack_masked<1>(dh, h4[rb][1]);
+        }
+        // ---------------- layer 5: dW5 = delta5 x H3^T ; delta4 = W5^T delta5 (masked)
+        {
+            half8 a5[2][2];
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const f32x16 tt = transpose_tile(p5[rb][0], p5[rb][1], I0, I1);
+                a5[rb][0] = pack<0, false>(tt);
+                a5[rb][1] = pack<1, false>(tt);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                const f32x16 tt = transpose_tile(h3[cb][0], h3[cb][1], I0, I1);
+                bT[0] = pack<0, false>(tt);
+                bT[1] = pack<1, false>(tt);
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) {
+                    g[2 + rb * 2 + cb] = mfma(a5[rb][0], bT[0], g[2 + rb * 2 + cb]);
+                    g[2 + rb * 2 + cb] = mfma(a5[rb][1], bT[1], g[2 + rb * 2 + cb]);
+                }
+            }
+        }
+        half8 p4[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            f32x16 dh = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) dh = mfma(NGP_FRAG(T_W5 + rb * 4 + kb * 2 + s), p5[kb][s], dh);
+            p4[rb][0] = pack_masked<0>(dh, h3[rb][0]);
+            p4[rb][1] = pack_masked<1>(dh, h3[rb][1]);
+        }
+        // ---------------- layer 4: dW4 = delta4 x X3^T ; dX3 = W4^T delta4
+        {
+            const f32x16 tx = transpose_tile(x3a, in.sh, I0, I1);
+            bT[0] = pack<0, false>(tx);
+            bT[1] = pack<1, false>(tx);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const f32x16 tt = transpose_tile(p4[rb][0], p4[rb][1], I0, I1);
+                aT[0] = pack<0, false>(tt);
+                aT[1] = pack<1, false>(tt);
+                g[rb] = mfma(aT[0], bT[0], g[rb]);
+                g[rb] = mfma(aT[1], bT[1], g[rb]);
+            }
+        }
+        f32x16 dx3 = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) dx3 = mfma(NGP_FRAG(T_W4 + kb * 2 + s), p4[kb][s], dx3);
+        // delta3: rows 1..15 = d features, row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp)
+        if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
+        if (valid) d3buf[(size_t)row * 2 + h] = pack<0, false>(dx3);
+    }
+    flush_acc(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kAccFloats);
+}
+
+// ---- grid kernel ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
+    const float *__restrict__ enc, uint32_t stride, const int32_t *__restrict__ M_dev, uint32_t M_host,
+    const half8 *__restrict__ image, float inv_loss_scale, const half8 *__restrict__ d3buf,
+    float *__restrict__ denc, float *__restrict__ partial)
+{
+    extern __shared__ half8 lds_w[];   // local 0..11 = F_W1, F_W2 ; 12..25 = T_W3, T_W2, T_W1
+    const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+    const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_host) : M_host;
+    const uint32_t n_tiles = (M + 31u) >> 5;
+    for (uint32_t i = threadIdx.x; i < 12u * 64u; i += 256) lds_w[i] = image[i];
+    for (uint32_t i = threadIdx.x; i < 14u * 64u; i += 256) lds_w[12u * 64u + i] = image[(size_t)T_W3 * 64 + i];
+    __syncthreads();
+    constexpr uint32_t LT_W3 = 12, LT_W2 = 14, LT_W1 = 22;
+    const half8 I0 = identity_frag(0, lane), I1 = identity_frag(1, lane);
+
+    f32x16 g[8];   // 0,1: dW1[rb]   2..5: dW2[rb][cb]   6,7: dW3[cb]
+#pragma unroll
+    for (int i = 0; i < 8; i++) g[i] = zero16();
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        asm volatile("" ::: "memory");   // keep the weight fragments in LDS (see the view kernel)
+        const uint32_t row = tile * 32u + n;
+        const bool valid = row < M;
+        const TileInB<false> in = load_tile_b<false>(enc, stride, nullptr, row, valid, h);
+        half8 p3;
+#pragma unroll
+        for (int t = 0; t < 8; t++) p3[t] = (_Float16)0.0f;
+        if (valid) p3 = d3buf[(size_t)row * 2 + h];
+
+        f32x16 a[2];
+        half8 h1[2][2], h2[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            a[rb] = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; s++) a[rb] = mfma(NGP_FRAG(F_W1 + rb * 2 + s), in.x0[s], a[rb]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            h1[kb][0] = pack<0, true>(a[kb]);
+            h1[kb][1] = pack<1, true>(a[kb]);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            a[rb] = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) a[rb] = mfma(NGP_FRAG(F_W2 + rb * 4 + kb * 2 + s), h1[kb][s], a[rb]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            h2[kb][0] = pack<0, true>(a[kb]);
+            h2[kb][1] = pack<1, true>(a[kb]);
+        }
+
+        half8 aT[2], bT[2];
+        // ---------------- layer 3: dW3 = delta3 x H2^T ; delta2 = W3^T delta3 (masked)
+        {
+            const f32x16 t3 = mfma(p3, I0, zero16());
+            aT[0] = pack<0, false>(t3);
+            aT[1] = pack<1, false>(t3);
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                const f32x16 tt = transpose_tile(h2[cb][0], h2[cb][1], I0, I1);
+                bT[0] = pack<0, false>(tt);
+                bT[1] = pack<1, false>(tt);
+                g[6 + cb] = mfma(aT[0], bT[0], g[6 + cb]);
+                g[6 + cb] = mfma(aT[1], bT[1], g[6 + cb]);
+            }
+        }
+        half8 p2[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            const f32x16 dh = mfma(NGP_FRAG(LT_W3 + rb), p3, zero16());
+            p2[rb][0] = pack_masked<0>(dh, h2[rb][0]);
+            p2[rb][1] = pack_masked<1>(dh, h2[rb][1]);
+        }
+        // ---------------- layer 2: dW2 = delta2 x H1^T ; delta1 = W2^T delta2 (masked)
+        {
+            half8 a2[2][2];
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const f32x16 tt = transpose_tile(p2[rb][0], p2[rb][1], I0, I1);
+                a2[rb][0] = pack<0, false>(tt);
+                a2[rb][1] = pack<1, false>(tt);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                const f32x16 tt = transpose_tile(h1[cb][0], h1[cb][1], I0, I1);
+                bT[0] = pack<0, false>(tt);
+                bT[1] = pack<1, false>(tt);
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) {
+                    g[2 + rb * 2 + cb] = mfma(a2[rb][0], bT[0], g[2 + rb * 2 + cb]);
+                    g[2 + rb * 2 + cb] = mfma(a2[rb][1], bT[1], g[2 + rb * 2 + cb]);
+                }
+            }
+        }
+        half8 p1[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            f32x16 dh = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) dh = mfma(NGP_FRAG(LT_W2 + rb * 4 + kb * 2 + s), p2[kb][s], dh);
+            p1[rb][0] = pack_masked<0>(dh, h1[rb][0]);
+            p1[rb][1] = pack_masked<1>(dh, h1[rb][1]);
+        }
+        // ---------------- layer 1: dW1 = delta1 x X0^T ; d enc = W1^T delta1
+        {
+            const f32x16 tx = transpose_tile(in.x0[0], in.x0[1], I0, I1);
+            bT[0] = pack<0, false>(tx);
+            bT[1] = pack<1, false>(tx);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const f32x16 tt = transpose_tile(p1[rb][0], p1[rb][1], I0, I1);
+                aT[0] = pack<0, false>(tt);
+                aT[1] = pack<1, false>(tt);
+                g[rb] = mfma(aT[0], bT[0], g[rb]);
+                g[rb] = mfma(aT[1], bT[1], g[rb]);
+            }
+        }
+        f32x16 dx0 = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) dx0 = mfma(NGP_FRAG(LT_W1 + kb * 2 + s), p1[kb][s], dx0);
+        if (valid) {
+            // registers 4q..4q+3 = features 8q + 4h + {0..3} = levels 4q + 2h, 4q + 2h + 1 (both channels)
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t level = 4 * q + 2 * h;
+                float2 lo = make_float2(dx0[4 * q] * inv_loss_scale, dx0[4 * q + 1] * inv_loss_scale);
+                float2 hi = make_float2(dx0[4 * q + 2] * inv_loss_scale, dx0[4 * q + 3] * inv_loss_scale);
+                reinterpret_cast<float2 *>(denc)[(size_t)level * stride + row] = lo;
+                reinterpret_cast<float2 *>(denc)[(size_t)(level + 1) * stride + row] = hi;
+            }
+        }
+    }
+    flush_acc(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kAccFloats);
+}
+
+// ---- partial-slab reduction -----------------------------------------------------------------------
+// element e of a workgroup slab: tile b = e / 1024, register v = (e / 64) % 16, lane = e % 64
+// -> dW[32*rb + o][32*cb + j] with o = (v&3) + 8(v>>2) + 4(lane>>5), j = lane & 31
+__global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restrict__ part_view,
+                                                           const float *__restrict__ part_grid, uint32_t n_wg,
+                                                           float inv_loss_scale, float *__restrict__ dw1,
+                                                           float *__restrict__ dw2, float *__restrict__ dw3,
+                                                           float *__restrict__ dw4, float *__restrict__ dw5,
+                                                           float *__restrict__ dw6)
+{
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 2 * kAccFloats) return;
+    const bool view = e >= kAccFloats;
+    const uint32_t i = view ? e - kAccFloats : e;
+    const float *src = (view ? part_view : part_grid) + i;
+    float s = 0.0f;
+    for (uint32_t w = 0; w < n_wg; w++) s += src[(size_t)w * kAccFloats];
+    s *= inv_loss_scale;
+    const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
+    const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;
+    if (b < 2) {   // first-layer tiles: rb = b
+        if (view) {
+            if (j >= 1) dw4[(32 * b + o) * 31 + j - 1] = s;
+        } else {
+            dw1[(32 * b + o) * 32 + j] = s;
+        }
+    } else if (b < 6) {   // 64 x 64 tiles: rb = (b-2) >> 1, cb = (b-2) & 1
+        const uint32_t rb = (b - 2) >> 1, cb = (b - 2) & 1;
+        (view ? dw5 : dw2)[(32 * rb + o) * 64 + 32 * cb + j] = s;
+    } else {   // last-layer tiles: cb = b - 6
+        const uint32_t cb = b - 6;
+        if (view) {
+            if (o < 3) dw6[o * 64 + 32 * cb + j] = s;
+        } else {
+            if (o < 16) dw3[o * 64 + 32 * cb + j] = s;
+        }
+    }
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+static uint32_t mlp_bwd_blocks(uint32_t M)
+{
+    const uint32_t tiles = ceil_div(M, 32u);
+    return max(1u, min(ceil_div(tiles, 4u), 256u));
+}
+
+extern "C" size_t ngp_x_mlp_backward_workspace_bytes(uint32_t M)
+{
+    return (size_t)M * 32 + 2 * (size_t)256 * kAccFloats * 4 + 256;
+}
+
+extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float *dirs, const float *dsigma,
+                                  const float *drgb, const int32_t *M_dev, uint32_t M, const void *image,
+                                  float loss_scale, float *denc, float *dw1, float *dw2, float *dw3, float *dw4,
+                                  float *dw5, float *dw6, void *workspace, size_t workspace_bytes, ngp_stream_t stream)
+{
+    NGP_REQUIRE(dw1 && dw2 && dw3 && dw4 && dw5 && dw6 && image && workspace, "mlp_backward: null tensor");
+    NGP_REQUIRE(M == 0 || (enc && dirs && dsigma && drgb && denc), "mlp_backward: null sample tensor");
+    NGP_REQUIRE(stride >= M, "mlp_backward: encoder slab stride smaller than M");
+    NGP_REQUIRE(workspace_bytes >= ngp_x_mlp_backward_workspace_bytes(M), "mlp_backward: workspace too small");
+    NGP_REQUIRE(((uintptr_t)workspace & 15u) == 0, "mlp_backward: workspace must be 16-byte aligned");
+    NGP_REQUIRE(loss_scale > 0.0f, "mlp_backward: loss_scale must be positive");
+    hipStream_t st = as_stream(stream);
+    const uint32_t blocks = mlp_bwd_blocks(max(M, 1u));
+    half8 *d3buf = reinterpret_cast<half8 *>(workspace);
+    float *part_view = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (((size_t)M * 32 + 255) & ~(size_t)255));
+    float *part_grid = part_view + (size_t)256 * kAccFloats;
+    const half8 *img = reinterpret_cast<const half8 *>(image);
+    mlp_backward_view_kernel<<<dim3(blocks), dim3(256), 46 * 1024, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
+                                                                        loss_scale, d3buf, part_view);
+    mlp_backward_grid_kernel<<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
+                                                                        d3buf, denc, part_grid);
+    mlp_reduce_dw_kernel<<<dim3(ceil_div(2 * kAccFloats, 256u)), dim3(256), 0, st>>>(part_view, part_grid, blocks,
+                                                                                    1.0f / loss_scale, dw1, dw2, dw3, dw4,
+                                                                                    dw5, dw6);
+    NGP_CHECK_LAUNCH("mlp_backward");
+    return NGP_OK;
+}

@@ -1,0 +1,77 @@
+// Shared definitions of the fused tiny-MLP kernels (fused_mlp_*.hip): MFMA operand fragments.
+//
+// The field's two bias-free MLPs (nerf/network.py:49,56 of the reference: 32-64-64-16 and 31-64-64-3,
+// ReLU) are evaluated with v_mfma_f32_32x32x16_f16, activations as [feature rows x sample columns]
+// accumulator tiles: one wave = 32 samples (columns on lanes), features in registers.
+//
+// MFMA 32x32x16 register maps (lane l: r = l & 31, h = l >> 5):
+//   A operand   element t (0..7) = A[row r][k = 8h + t]
+//   B operand   element t        = B[k = 8h + t][col r]
+//   C / D       register v (0..15) = D[row (v&3) + 8(v>>2) + 4h][col r]
+// Feeding registers 8s..8s+7 of a D tile X as the next MFMA's B operand contracts over X's rows with
+//   logical k = kperm(s, h, t) = 16 s + 8 (t >> 2) + 4 h + (t & 3)           (s = k-step inside the 32-row tile)
+// and feeding them as the A operand gives X^T (rows = X's columns).  Every weight fragment below is
+// therefore stored as frag[lane (r, h)][t] = M[r][kperm(s, h, t)] for a 32 x 32 block M of the
+// (possibly transposed, zero-padded) weight matrix; the same bits serve as A-of-M or B-of-M^T.
+#pragma once
+#include "ngp_common.hpp"
+
+namespace ngp {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr uint32_t kperm(uint32_t s, uint32_t h, uint32_t t)
+{
+    return 16u * s + 8u * (t >> 2) + 4u * h + (t & 3u);
+}
+
+// Fragment ids inside the f16 weight image (each fragment = 64 lanes x 8 halfs = 1 KiB).
+enum MlpFrag : uint32_t {
+    F_W1 = 0,    // [rb 2][s 2]            W1[32rb + r][k]
+    F_W2 = 4,    // [rb 2][kb 2][s 2]      W2[32rb + r][32kb + k]
+    F_W3 = 12,   // [kb 2][s 2]            r < 16 ? W3[r][32kb + k] : 0
+    F_W4 = 16,   // [rb 2][s 2]            k >= 1 ? W4[32rb + r][k - 1] : 0     (k = 0 is the sigma row)
+    F_W5 = 20,   // [rb 2][kb 2][s 2]
+    F_W6 = 28,   // [kb 2][s 2]            r < 3 ? W6[r][32kb + k] : 0
+    T_W6 = 32,   // [rb 2]        (s = 0)  k < 3 ? W6[k][32rb + r] : 0
+    T_W5 = 34,   // [rb 2][kb 2][s 2]      W5[32kb + k][32rb + r]
+    T_W4 = 42,   // [kb 2][s 2]            r >= 1 ? W4[32kb + k][r - 1] : 0
+    T_W3 = 46,   // [rb 2]        (s = 0)  k < 16 ? W3[k][32rb + r] : 0
+    T_W2 = 48,   // [rb 2][kb 2][s 2]      W2[32kb + k][32rb + r]
+    T_W1 = 56,   // [kb 2][s 2]            W1[32kb + k][r]
+    kMlpFrags = 60,
+};
+constexpr uint32_t kMlpImageHalfs = kMlpFrags * 64 * 8;   // 30720 halfs = 60 KiB
+
+// weight matrix shapes (torch layout [out][in], fp32)
+constexpr uint32_t kW1 = 64 * 32, kW2 = 64 * 64, kW3 = 16 * 64, kW4 = 64 * 31, kW5 = 64 * 64, kW6 = 3 * 64;
+constexpr uint32_t kMlpParams = kW1 + kW2 + kW3 + kW4 + kW5 + kW6;   // 13440
+
+__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16()
+{
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0f;
+    return z;
+}
+
+// registers 8S..8S+7 of an accumulator tile as an f16 operand fragment
+template <int S, bool RELU>
+__device__ __forceinline__ half8 pack(const f32x16 &a)
+{
+    half8 o;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float v = a[8 * S + t];
+        o[t] = (_Float16)(RELU ? fmaxf(v, 0.0f) : v);
+    }
+    return o;
+}
+
+}  // namespace ngp

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Train the field on the procedural Lego-style scene and report PSNR on held-out views.
+Usage: python tools/train_synthetic.py --iters 5000 [--res 800] [--views 100] [--fused-mlp]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raw_ngp_amd.nerf.network import NeRFNetwork  # noqa: E402
+from raw_ngp_amd.nerf.options import Options  # noqa: E402
+from raw_ngp_amd.nerf.scene import SyntheticDataset  # noqa: E402
+from raw_ngp_amd.nerf.trainer import Trainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=5000)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--views", type=int, default=100)
+    ap.add_argument("--val-views", type=int, default=4)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--log-every", type=int, default=250)
+    ap.add_argument("--fp16", action="store_true")
+    ap.add_argument("--fused-mlp", action="store_true")
+    ap.add_argument("--arena", type=int, default=0)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=args.rays, iters=args.iters, fp16=args.fp16, fused_mlp=args.fused_mlp,
+                  arena_capacity=args.arena)
+    t0 = time.time()
+    data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
+    val = SyntheticDataset(opt, dev, "val", n_views=args.val_views, H=args.res, W=args.res)
+    print(f"scene rendered in {time.time() - t0:.1f}s", flush=True)
+    model = NeRFNetwork(opt)
+    trainer = Trainer(opt, model, data, device=dev)
+    hist = []
+    done = 0
+    while done < args.iters:
+        n = min(args.log_every, args.iters - done)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        trainer.train(n)
+        torch.cuda.synchronize()
+        dt = time.time() - t1
+        done += n
+        row = {"iter": done, "loss": float(trainer.last_loss), "samples": int(trainer.last_num_points),
+               "ms_per_step": round(dt / n * 1e3, 3), "mean_density": round(float(model.mean_density), 4)}
+        hist.append(row)
+        print(json.dumps(row), flush=True)
+    psnr = trainer.evaluate(val)
+    print(json.dumps({"psnr": round(float(psnr), 3), "iters": args.iters, "val_views": args.val_views,
+                      "total_s": round(time.time() - t0, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
