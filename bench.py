@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--psnr-iters", type=int, default=0, help="if > 0: keep training to this many iterations and report PSNR")
     ap.add_argument("--arena", type=int, default=0, help="sample arena capacity (0 = reference two-pass march)")
+    ap.add_argument("--torch-mlp", action="store_true", help="fp32 nn.Linear MLPs instead of the fused f16 MFMA field")
     args = ap.parse_args()
 
     rank, world, local = parallel.init_from_env("cuda")
@@ -147,7 +148,8 @@ def main():
     _lib.load()
     torch.manual_seed(0)
 
-    opt = Options(bound=1.0, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena)
+    opt = Options(bound=1.0, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena,
+                  fused_mlp=not args.torch_mlp)
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
     trainer = Trainer(opt, model, data, device=dev)
@@ -198,9 +200,11 @@ def main():
         line = {
             "metric": METRIC, "value": round(world * args.rays * args.steps / dt, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.torch_mlp else "f32 (grid/SH/march/composite) + f16-MFMA/f32-acc MLP", "data": "synthetic",
             "config": {"workload": "configs[1]: Lego-style 800x800 procedural scene, hashgrid L=16 F=2 T=2^19, "
-                                   "density-grid march (cuda_ray path), 4096 rays/batch/GPU, fp32 MLPs",
+                                   "density-grid march (cuda_ray path), 4096 rays/batch/GPU, "
+                                   + ("fp32 nn.Linear MLPs" if args.torch_mlp else "fused tiny-MLP (configs[2])"),
                        "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
                        "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
                        "parallelism": f"dp{world}", "arena": args.arena},

@@ -202,7 +202,7 @@ int ngp_x_grid_input_backward(const float *grad, const float *dy_dx, float *grad
 size_t ngp_x_mlp_image_bytes(void);
 int ngp_x_mlp_prepare(const float *w1, const float *w2, const float *w3, const float *w4, const float *w5,
                       const float *w6, void *image, ngp_stream_t stream);
-/* sigma [M], rgb [M,3] */
+/* sigma [M], rgb [M,3]; rgb == NULL (then dirs may be NULL too) evaluates the density only */
 int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
                       const void *image, float *sigma, float *rgb, ngp_stream_t stream);
 

@@ -314,8 +314,9 @@ class _MlpBackend:
 
     @staticmethod
     def forward(enc, stride, dirs, M_dev, M, image, sigma, rgb):
-        _call("ngp_x_mlp_forward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"),
-              _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb"))
+        _call("ngp_x_mlp_forward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs", True),
+              _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), _ptr(sigma, "f", "sigma"),
+              _ptr(rgb, "f", "rgb", True))
 
 
     @staticmethod

@@ -105,7 +105,7 @@ __device__ __forceinline__ TileIn load_tile(const float *__restrict__ enc, size_
             in.x0[s][4 * q + 3] = (_Float16)b.y;
         }
     float dx = 0.f, dy = 0.f, dz = 1.f;
-    if (valid) {
+    if (valid && dirs) {
         dx = dirs[(size_t)row * 3];
         dy = dirs[(size_t)row * 3 + 1];
         dz = dirs[(size_t)row * 3 + 2];
@@ -182,6 +182,10 @@ __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const float *__rest
 #pragma unroll
             for (int s = 0; s < 2; s++) o = mfma(wf[F_W3 + kb * 2 + s], x[kb][s], o);
         const float sigma_raw = o[0];
+        if (rgb == nullptr) {   // density-only query (density-grid refresh): skip the colour MLP
+            if (valid && h == 0) sigma[row] = __expf(sigma_raw);
+            continue;
+        }
         // layer 4: [sigma row (zero weight), 15 features, SH16] -> 64
         const half8 x3a = pack<0, false>(o);
 #pragma unroll
@@ -240,7 +244,8 @@ extern "C" int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float 
                                  const void *image, float *sigma, float *rgb, ngp_stream_t stream)
 {
     if (M == 0) return NGP_OK;
-    NGP_REQUIRE(enc && dirs && image && sigma && rgb, "mlp_forward: null tensor");
+    NGP_REQUIRE(enc && image && sigma, "mlp_forward: null tensor");
+    NGP_REQUIRE(rgb == nullptr || dirs != nullptr, "mlp_forward: dirs missing");
     NGP_REQUIRE(stride >= M, "mlp_forward: encoder slab stride smaller than M");
     const uint32_t tiles = ceil_div(M, 32u);
     const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * 2u);

@@ -23,7 +23,7 @@ class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
-                gridtype=0, align_corners=False, interpolation=0, max_level=None):
+                gridtype=0, align_corners=False, interpolation=0, max_level=None, slab=False):
         inputs = inputs.contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -43,6 +43,9 @@ class _grid_encode(Function):
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = (B, D, C, L, S, H, gridtype, interpolation, max_level)
         ctx.align_corners = align_corners
+        ctx.slab = slab
+        if slab:        # level-major [L, B, C] exactly as the kernel wrote it (consumed by the fused MLP)
+            return outputs
         # feature f[:, l*C:(l+1)*C] belongs to level l (the BARF / BAA windows rely on it)
         return outputs.permute(1, 0, 2).reshape(B, L * C)
 
@@ -52,7 +55,10 @@ class _grid_encode(Function):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H, gridtype, interpolation, max_level = ctx.dims
 
-        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()            # [L, B, C]
+        if ctx.slab:
+            grad = grad.contiguous()                                        # already [L, B, C]
+        else:
+            grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()        # [B, L*C] -> [L, B, C]
         grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
 
@@ -61,7 +67,7 @@ class _grid_encode(Function):
 
         if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None, None
 
 
 grid_encode = _grid_encode.apply
@@ -119,14 +125,15 @@ class GridEncoder(nn.Module):
                 f"align_corners={self.align_corners} interpolation={self.interpolation}")
 
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(self, inputs, bound=1, max_level=None):
-        """inputs [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]."""
+    def forward(self, inputs, bound=1, max_level=None, slab=False):
+        """inputs [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]
+        (slab=True: the kernel's own level-major [num_levels, B, level_dim] layout, no permute copy)."""
         inputs = (inputs + bound) / (2 * bound)
         lead = list(inputs.shape[:-1])
         flat = inputs.view(-1, self.input_dim)
         out = grid_encode(flat, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                          flat.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
-        return out.view(lead + [self.output_dim])
+                          flat.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level, slab)
+        return out if slab else out.view(lead + [self.output_dim])
 
     def _grad_or_raise(self):
         if self.embeddings.grad is None:

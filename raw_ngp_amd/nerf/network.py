@@ -93,6 +93,16 @@ class NeRFNetwork(NeRFRenderer):
             return f * weights
         return f
 
+    # -- fused MFMA path (extension; Options.fused_mlp) ------------------------------------------
+    def _fused(self):
+        o = self.opt
+        return (getattr(o, "fused_mlp", False) and not o.rfield and o.pose_opt == "none"
+                and o.internal_activation == "relu" and o.density_activation == "clamped_exp"
+                and o.color_activation == "clamped_exp" and self.grid_encoder.embeddings.is_cuda)
+
+    def _mlp_weights(self):
+        return [l.weight for l in self.grid_mlp.net] + [l.weight for l in self.view_mlp.net]
+
     # -- field ------------------------------------------------------------------------------
     def common_forward(self, x):
         f = self._apply_level_window(self.grid_encoder(x, bound=self.bound))
@@ -105,6 +115,12 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward(self, x, d, ld=None, **kwargs):
         """x [N,3] in [-bound, bound], d [N,3] unit view dirs, ld [N,3] light dirs (rfield)."""
+        if self._fused() and not d.requires_grad:
+            from .fused_field import fused_field
+            enc = self.grid_encoder(x.reshape(-1, 3), bound=self.bound, slab=True)
+            sigma, color = fused_field(enc, d.reshape(-1, 3), self._mlp_weights(),
+                                       getattr(self.opt, "loss_scale", 1024.0))
+            return {"sigma": sigma.view(x.shape[:-1]), "color": color.view(*x.shape[:-1], 3)}
         sigma, feat = self.common_forward(x)
         parts = [feat, self.view_encoder(d)]
         if self.opt.rfield:
@@ -120,6 +136,10 @@ class NeRFNetwork(NeRFRenderer):
         return {"sigma": sigma, "color": color}
 
     def density(self, x, proposal=-1):
+        if self._fused() and not torch.is_grad_enabled() and not (0 <= proposal < len(getattr(self, "prop_encoders", ()))):
+            from .fused_field import fused_density
+            enc = self.grid_encoder(x.reshape(-1, 3), bound=self.bound, slab=True)
+            return {"sigma": fused_density(enc, self._mlp_weights()).view(x.shape[:-1])}
         if 0 <= proposal < len(getattr(self, "prop_encoders", ())):
             h = self.prop_encoders[proposal](x, bound=self.bound)
             sigma = trunc_exp(self.prop_mlp[proposal](h).squeeze(-1))

@@ -55,4 +55,5 @@ class Options:
     device: str = "cuda"
     # --- extensions of this implementation (no reference counterpart) -----------------------------
     fused_mlp: bool = False       # hand-written MFMA tiny-MLP instead of nn.Linear stacks
+    loss_scale: float = 1024.0    # static loss scale of the fused MLP backward (f16 deltas)
     arena_capacity: int = 0       # > 0: sample arena (no host sync per step); 0 = reference 2-pass protocol
