@@ -467,8 +467,17 @@ __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restr
     const bool view = e >= kAccFloats;
     const uint32_t i = view ? e - kAccFloats : e;
     const float *src = (view ? part_view : part_grid) + i;
+    // fixed order (slab 0, 1, 2, ...) but eight loads in flight: the sum is latency-bound otherwise
     float s = 0.0f;
-    for (uint32_t w = 0; w < n_wg; w++) s += src[(size_t)w * kAccFloats];
+    uint32_t w = 0;
+    for (; w + 8 <= n_wg; w += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = src[(size_t)(w + k) * kAccFloats];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += t[k];
+    }
+    for (; w < n_wg; w++) s += src[(size_t)w * kAccFloats];
     s *= inv_loss_scale;
     const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
     const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;

@@ -1,47 +1,46 @@
-// Hash-grid table gradient without global float atomics (D = 3, C = 2: the field's encoder).
+// Hash-grid table gradient without scattered global float atomics (D = 3, C = 2: the field's encoder).
 //
 // Why: the reference's kernel_grid_backward (gridencoder/src/gridencoder.cu:252-349) issues one float
 // atomicAdd per (sample, level, corner, channel).  On MI355X global float atomics execute memory-side
 // at ~21 G requests/s when lanes hit different 64-B lines (measured: tools/ubench/atomics.hip), i.e.
 // 3.3 ms for 2^18 samples -- 8x the whole step budget.  Plain stores and LDS atomics are ~50x faster,
-// so the scatter is turned into "bin, then reduce in LDS":
+// so the scatter becomes "keep small levels in LDS, bin the rest, reduce bins in LDS":
 //
-//   plan    chunk = 4096 consecutive rows of one level (32 KiB of float2 accumulators); per-level chunk
-//           bases come from `offsets` on the device
-//   count   every (sample, level) computes its 8 corner rows; a per-workgroup LDS histogram over that
-//           level's chunks is added to the global per-chunk counts (one atomic per workgroup and chunk)
-//   scan    exclusive prefix of the counts -> record offsets; chunks heavier than kSeg records are
-//           split into segments (coarse dense levels concentrate millions of records in a few chunks)
-//   fill    same traversal; records {row-in-chunk, w*g.x, w*g.y} (12 B) are stored into their chunk's
-//           range, positions handed out by LDS atomics + one global atomic per workgroup and chunk
-//   reduce  one workgroup per (chunk, segment): stream the records (coalesced), ds_add into a 32 KiB
-//           LDS image of the chunk, then grad_table[chunk] += image (plain read-modify-write when the
-//           chunk has one segment, well-shaped contiguous atomics otherwise)
+//   private  the leading levels whose tables fit one workgroup's LDS together (<= 18432 rows: levels 0-1 of
+//            the default encoder) are accumulated directly: every workgroup adds its share of the samples
+//            into an LDS copy of those tables and flushes the non-zero entries with contiguous atomics
+//   count    chunk = 4096 consecutive rows of one level (32 KiB of float2 accumulators).  Every (sample,
+//            level) of the remaining levels computes its 8 corner rows; a per-workgroup LDS histogram over
+//            the level's chunks is added to the global per-chunk counts
+//   scan     exclusive prefix of the counts (4-record aligned) -> record offsets; chunks heavier than kSeg
+//            records are split into segments
+//   fill     same traversal; records {row-in-chunk, w*g.x, w*g.y} (12 B) are first sorted by chunk inside
+//            the workgroup (LDS), then written so that consecutive lanes store consecutive records
+//   reduce   one workgroup per (chunk, segment): stream the records (16-byte loads, 8 records in flight per
+//            lane), ds_add into a 32 KiB LDS image of the chunk, then grad_table[chunk] += image (plain
+//            read-modify-write when the chunk has one segment, contiguous atomics otherwise)
 //
-// Result: the same sums as the reference in a different (also unspecified) order.  HBM traffic is
-// 2 x 12 B x 8 x L per sample of plain coalesced traffic instead of 16 x L scattered atomic requests.
+// Result: the same sums as the reference in a different (also unspecified) order.
 #include "grid_common.hpp"
 
 namespace ngp {
 
-constexpr uint32_t kChunkRows = 4096;   // rows per chunk: 4096 x float2 = 32 KiB of LDS
+constexpr uint32_t kChunkRows = 4096;    // rows per chunk: 4096 x float2 = 32 KiB of LDS
 constexpr uint32_t kChunkShift = 12;
-constexpr uint32_t kSeg = 32768;        // records per reduce work item
-constexpr uint32_t kMaxChunks = 12288;    // LDS histogram bound (48 KiB): tables up to 50 M rows
-
-struct Record {
-    uint32_t row;   // row inside the chunk
-    float gx, gy;
-};
+constexpr uint32_t kSeg = 32768;         // records per reduce work item
+constexpr uint32_t kMaxChunks = 2048;    // LDS histogram bound of the binned path (tables up to 8 M rows)
+constexpr uint32_t kPrivRows = 18432;    // rows of the leading levels kept in one workgroup's LDS (144 KiB)
+constexpr uint32_t kFillTile = 512;      // samples per fill workgroup (2 per lane)
+constexpr uint32_t kCountTile = 2048;    // samples per count workgroup (8 per lane)
 
 // workspace header (uint32 words); arrays sized for n_chunks_max
 struct WsLayout {
-    uint32_t *chunk_base;   // [kMaxLevels + 1] first chunk of each level; [L] = total chunks
+    uint32_t *chunk_base;   // [kMaxLevels + 1] first chunk of each level; [L] = total chunks; [kMaxLevels + 1] = private levels
     uint32_t *count;        // [n_chunks_max]
     uint32_t *cursor;       // [n_chunks_max]
-    uint32_t *offset;       // [n_chunks_max + 1] record offsets
+    uint32_t *offset;       // [n_chunks_max + 1] record offsets (multiples of 4)
     uint32_t *seg_base;     // [n_chunks_max + 1] first reduce work item of each chunk
-    Record *records;
+    uint32_t *records;      // 3 words per record
 };
 
 __host__ __device__ inline WsLayout ws_layout(void *ws, uint32_t n_chunks_max)
@@ -49,7 +48,7 @@ __host__ __device__ inline WsLayout ws_layout(void *ws, uint32_t n_chunks_max)
     WsLayout w;
     uint32_t *p = reinterpret_cast<uint32_t *>(ws);
     w.chunk_base = p;
-    p += kMaxLevels + 1 + 3;   // keep 16-byte alignment below
+    p += kMaxLevels + 4;
     w.count = p;
     p += n_chunks_max;
     w.cursor = p;
@@ -59,14 +58,14 @@ __host__ __device__ inline WsLayout ws_layout(void *ws, uint32_t n_chunks_max)
     w.seg_base = p;
     p += n_chunks_max + 1;
     p += (4 - ((uintptr_t)(p - reinterpret_cast<uint32_t *>(ws)) & 3)) & 3;
-    w.records = reinterpret_cast<Record *>(p);
+    w.records = p;
     return w;
 }
 
 static inline size_t ws_bytes(uint32_t B, uint32_t L, uint32_t n_chunks_max)
 {
     const size_t head = (size_t)(kMaxLevels + 4 + 4 * (size_t)n_chunks_max + 2 + 4) * 4;
-    return head + (size_t)B * L * 8 * sizeof(Record) + 64;
+    return head + ((size_t)B * L * 8 + 4 * (size_t)n_chunks_max + 8) * 12 + 64;
 }
 
 // ------------------------------------------------------------------ plan
@@ -75,13 +74,18 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const int32_t *__restric
 {
     __shared__ uint32_t total;
     if (threadIdx.x == 0) {
-        uint32_t run = 0;
+        uint32_t run = 0, priv = 0;
         for (uint32_t l = 0; l < L; l++) {
             w.chunk_base[l] = run;
             const uint32_t T = (uint32_t)(offsets[l + 1] - offsets[l]);
-            run += (T + kChunkRows - 1) >> kChunkShift;
+            if (priv == l && (uint32_t)offsets[l + 1] <= kPrivRows) {
+                priv = l + 1;   // level l is accumulated privately: it owns no chunks
+            } else {
+                run += (T + kChunkRows - 1) >> kChunkShift;
+            }
         }
         w.chunk_base[L] = run;
+        w.chunk_base[kMaxLevels + 1] = priv;
         total = run;
     }
     __syncthreads();
@@ -92,68 +96,102 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const int32_t *__restric
     }
 }
 
-// ------------------------------------------------------------------ count / fill
-// One workgroup = 256 samples of one level.  FILL = false: histogram only.
-template <bool FILL>
-__global__ __launch_bounds__(kBlock) void bin_traverse_kernel(
-    const float *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, uint32_t B,
-    uint32_t ntiles, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w)
+// ------------------------------------------------------------------ private levels
+__global__ __launch_bounds__(512) void bin_private_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                          const int32_t *__restrict__ offsets,
+                                                          float *__restrict__ grad_table, uint32_t B, uint32_t max_level,
+                                                          LevelRes lv, uint32_t gridtype, bool align_corners,
+                                                          uint32_t interp, WsLayout w)
 {
-    extern __shared__ uint32_t hist[];   // [bins of this level] counts, then (FILL) global bases
+    extern __shared__ float tab[];   // [rows of the private levels][2]
+    const uint32_t n_priv = min(w.chunk_base[kMaxLevels + 1], max_level);
+    if (n_priv == 0) return;
+    const uint32_t n_rows = (uint32_t)offsets[n_priv];
+    for (uint32_t i = threadIdx.x; i < n_rows * 2; i += 512) tab[i] = 0.0f;
+    __syncthreads();
+    const uint32_t per = (B + gridDim.x - 1) / gridDim.x;
+    const uint32_t b0 = blockIdx.x * per, b1 = min(B, b0 + per);
+    for (uint32_t level = 0; level < n_priv; level++) {
+        const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
+        float *t = tab + (size_t)(uint32_t)offsets[level] * 2;
+        for (uint32_t b = b0 + threadIdx.x; b < b1; b += 512) {
+            float x[3];
+#pragma unroll
+            for (uint32_t d = 0; d < 3; d++) x[d] = inputs[(size_t)b * 3 + d];
+            Cell<3> cl;
+            if (!locate<3>(x, g.res, align_corners, interp, cl)) continue;
+            const float2 gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * B + b];
+#pragma unroll
+            for (uint32_t corner = 0; corner < 8; corner++) {
+                float wgt = 1.0f;
+                uint32_t c[3];
+#pragma unroll
+                for (uint32_t d = 0; d < 3; d++) {
+                    const bool up = corner & (1u << d);
+                    wgt *= up ? cl.f[d] : 1.0f - cl.f[d];
+                    c[d] = up ? min(cl.c[d] + 1u, g.res - 1u) : cl.c[d];
+                }
+                uint32_t row = row_of<3>(g, c);
+                atomicAdd(&t[row * 2], wgt * gr.x);
+                atomicAdd(&t[row * 2 + 1], wgt * gr.y);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_rows * 2; i += 512) {
+        const float v = tab[i];
+        if (v != 0.0f) unsafeAtomicAdd(grad_table + i, v);
+    }
+}
+
+// ------------------------------------------------------------------ shared traversal piece
+// rows of the 8 corners of sample b at one level; false when the sample is outside [0,1]^3
+__device__ __forceinline__ bool corner_rows(const float *__restrict__ inputs, uint32_t b, const Geom<3> &g,
+                                            bool align_corners, uint32_t interp, Cell<3> &cl, uint32_t (&rows)[8])
+{
+    float x[3];
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++) x[d] = inputs[(size_t)b * 3 + d];
+    if (!locate<3>(x, g.res, align_corners, interp, cl)) return false;
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; corner++) {
+        uint32_t c[3];
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) c[d] = (corner & (1u << d)) ? min(cl.c[d] + 1u, g.res - 1u) : cl.c[d];
+        rows[corner] = row_of<3>(g, c);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ count
+__global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restrict__ inputs,
+                                                          const int32_t *__restrict__ offsets, uint32_t B,
+                                                          uint32_t ntiles, LevelRes lv, uint32_t gridtype,
+                                                          bool align_corners, uint32_t interp, WsLayout w)
+{
+    extern __shared__ uint32_t hist[];
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t level = item / ntiles;
-    const uint32_t b = (item - level * ntiles) * kBlock + threadIdx.x;
-
+    if (level < w.chunk_base[kMaxLevels + 1]) return;   // private level
+    const uint32_t b0 = (item - level * ntiles) * kCountTile;
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
     const uint32_t first = w.chunk_base[level];
     const uint32_t nbins = w.chunk_base[level + 1] - first;
     for (uint32_t i = threadIdx.x; i < nbins; i += kBlock) hist[i] = 0;
     __syncthreads();
-
-    bool live = b < B;
-    Cell<3> cl;
-    if (live) {
-        float x[3];
+#pragma unroll 2
+    for (uint32_t k = 0; k < kCountTile / kBlock; k++) {
+        const uint32_t b = b0 + k * kBlock + threadIdx.x;
+        if (b >= B) break;
+        Cell<3> cl;
+        uint32_t rows[8];
+        if (!corner_rows(inputs, b, g, align_corners, interp, cl, rows)) continue;
 #pragma unroll
-        for (uint32_t d = 0; d < 3; d++) x[d] = inputs[(size_t)b * 3 + d];
-        live = locate<3>(x, g.res, align_corners, interp, cl);
-    }
-    uint32_t rows[8], pos[8];
-    if (live) {
-#pragma unroll
-        for (uint32_t corner = 0; corner < 8; corner++) {
-            uint32_t c[3];
-#pragma unroll
-            for (uint32_t d = 0; d < 3; d++) c[d] = (corner & (1u << d)) ? min(cl.c[d] + 1u, g.res - 1u) : cl.c[d];
-            rows[corner] = row_of<3>(g, c);
-            pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
-        }
+        for (uint32_t corner = 0; corner < 8; corner++) atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
     }
     __syncthreads();
-    if (!FILL) {
-        for (uint32_t i = threadIdx.x; i < nbins; i += kBlock)
-            if (hist[i]) atomicAdd(&w.count[first + i], hist[i]);
-        return;
-    }
-    // reserve this workgroup's range in every chunk it touches; hist[i] becomes the global base
-    for (uint32_t i = threadIdx.x; i < nbins; i += kBlock) {
-        const uint32_t n = hist[i];
-        hist[i] = n ? w.offset[first + i] + atomicAdd(&w.cursor[first + i], n) : 0u;
-    }
-    __syncthreads();
-    if (!live) return;
-    const float2 gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * B + b];
-#pragma unroll
-    for (uint32_t corner = 0; corner < 8; corner++) {
-        float wgt = 1.0f;
-#pragma unroll
-        for (uint32_t d = 0; d < 3; d++) wgt *= (corner & (1u << d)) ? cl.f[d] : 1.0f - cl.f[d];
-        Record r;
-        r.row = rows[corner] & (kChunkRows - 1u);
-        r.gx = wgt * gr.x;
-        r.gy = wgt * gr.y;
-        w.records[hist[rows[corner] >> kChunkShift] + pos[corner]] = r;
-    }
+    for (uint32_t i = threadIdx.x; i < nbins; i += kBlock)
+        if (hist[i]) atomicAdd(&w.count[first + i], hist[i]);
 }
 
 // ------------------------------------------------------------------ scan
@@ -168,8 +206,9 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w)
     for (uint32_t base = 0; base < n; base += 1024u) {
         const uint32_t i = base + tid;
         const uint32_t cnt = i < n ? w.count[i] : 0u;
+        const uint32_t cnt4 = (cnt + 3u) & ~3u;   // 4-record alignment: 16-byte loads in the reduce kernel
         const uint32_t seg = i < n ? max(1u, (cnt + kSeg - 1) / kSeg) : 0u;
-        uint32_t a = cnt, s = seg;
+        uint32_t a = cnt4, s = seg;
 #pragma unroll
         for (uint32_t d = 1; d < 64u; d <<= 1) {
             const uint32_t ua = __shfl_up(a, d, 64), us = __shfl_up(s, d, 64);
@@ -194,7 +233,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w)
         }
         const uint32_t ca = carry_a, cb = carry_b;
         if (i < n) {
-            w.offset[i] = ca + oa + a - cnt;
+            w.offset[i] = ca + oa + a - cnt4;
             w.seg_base[i] = cb + ob + s - seg;
         }
         __syncthreads();
@@ -207,6 +246,103 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w)
     if (tid == 0) {
         w.offset[n] = carry_a;
         w.seg_base[n] = carry_b;
+    }
+}
+
+// ------------------------------------------------------------------ fill
+// LDS: hist[nbins] | lbase[nbins] | gbase[nbins] | stage[8 * kFillTile] x 16 B
+__global__ __launch_bounds__(kBlock) void bin_fill_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                         const int32_t *__restrict__ offsets, uint32_t B,
+                                                         uint32_t ntiles, uint32_t nbins_cap, LevelRes lv,
+                                                         uint32_t gridtype, bool align_corners, uint32_t interp,
+                                                         WsLayout w)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *hist = lds, *lbase = lds + nbins_cap, *gbase = lds + 2 * nbins_cap;
+    uint4 *stage = reinterpret_cast<uint4 *>(lds + 3 * nbins_cap);
+    __shared__ uint32_t wave_tot[4];
+
+    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t level = item / ntiles;
+    if (level < w.chunk_base[kMaxLevels + 1]) return;   // private level
+    const uint32_t b0 = (item - level * ntiles) * kFillTile;
+    const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
+    const uint32_t first = w.chunk_base[level];
+    const uint32_t nbins = w.chunk_base[level + 1] - first;
+    for (uint32_t i = threadIdx.x; i < nbins; i += kBlock) hist[i] = 0;
+    __syncthreads();
+
+    constexpr uint32_t S = kFillTile / kBlock;   // samples per lane
+    uint32_t rows[S][8], pos[S][8];
+    Cell<3> cl[S];
+    bool live[S];
+#pragma unroll
+    for (uint32_t k = 0; k < S; k++) {
+        const uint32_t b = b0 + k * kBlock + threadIdx.x;
+        live[k] = b < B && corner_rows(inputs, b, g, align_corners, interp, cl[k], rows[k]);
+        if (live[k]) {
+#pragma unroll
+            for (uint32_t corner = 0; corner < 8; corner++)
+                pos[k][corner] = atomicAdd(&hist[rows[k][corner] >> kChunkShift], 1u);
+        }
+    }
+    __syncthreads();
+
+    // exclusive scan of hist -> staging offsets; reserve the global ranges
+    {
+        const uint32_t per = (nbins + kBlock - 1) / kBlock;   // consecutive bins per lane
+        const uint32_t lo = threadIdx.x * per, hi = min(nbins, lo + per);
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; i++) sum += hist[i];
+        const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+        uint32_t inc = sum;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        if (lane == 63u) wave_tot[wid] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (uint32_t k = 0; k < wid; k++) run += wave_tot[k];
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t n = hist[i];
+            lbase[i] = run;
+            gbase[i] = n ? w.offset[first + i] + atomicAdd(&w.cursor[first + i], n) : 0u;
+            run += n;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+
+    // stage the records sorted by chunk
+#pragma unroll
+    for (uint32_t k = 0; k < S; k++) {
+        if (!live[k]) continue;
+        const uint32_t b = b0 + k * kBlock + threadIdx.x;
+        const float2 gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * B + b];
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; corner++) {
+            float wgt = 1.0f;
+#pragma unroll
+            for (uint32_t d = 0; d < 3; d++) wgt *= (corner & (1u << d)) ? cl[k].f[d] : 1.0f - cl[k].f[d];
+            const uint32_t bin = rows[k][corner] >> kChunkShift;
+            uint4 r;
+            r.x = gbase[bin] + pos[k][corner];
+            r.y = rows[k][corner] & (kChunkRows - 1u);
+            r.z = __float_as_uint(wgt * gr.x);
+            r.w = __float_as_uint(wgt * gr.y);
+            stage[lbase[bin] + pos[k][corner]] = r;
+        }
+    }
+    __syncthreads();
+    // consecutive lanes -> consecutive records of one chunk (until the chunk changes)
+    for (uint32_t j = threadIdx.x; j < total; j += kBlock) {
+        const uint4 r = stage[j];
+        uint32_t *dst = w.records + (size_t)r.x * 3;
+        dst[0] = r.y;
+        dst[1] = r.z;
+        dst[2] = r.w;
     }
 }
 
@@ -236,17 +372,35 @@ __global__ __launch_bounds__(kBlock) void bin_reduce_kernel(const int32_t *__res
     const uint32_t chunk = s_chunk;
     const uint32_t seg = item - w.seg_base[chunk];
     const uint32_t n_seg = w.seg_base[chunk + 1] - w.seg_base[chunk];
-    const uint32_t beg = w.offset[chunk] + seg * kSeg;
-    const uint32_t end = min(w.offset[chunk + 1], beg + kSeg);
+    const uint32_t beg = w.offset[chunk] + seg * kSeg;                      // multiple of 4 records
+    const uint32_t end = min(w.offset[chunk] + w.count[chunk], beg + kSeg);
     if (beg >= end) return;   // empty chunk: nothing to add
 
-    const uint32_t *rec = reinterpret_cast<const uint32_t *>(w.records);
-    for (uint32_t i = beg + threadIdx.x; i < end; i += kBlock) {
-        const uint32_t row = __builtin_nontemporal_load(rec + (size_t)i * 3);
-        const float gx = __uint_as_float(__builtin_nontemporal_load(rec + (size_t)i * 3 + 1));
-        const float gy = __uint_as_float(__builtin_nontemporal_load(rec + (size_t)i * 3 + 2));
-        atomicAdd(&acc[row * 2], gx);
-        atomicAdd(&acc[row * 2 + 1], gy);
+    const uint4 *rec4 = reinterpret_cast<const uint4 *>(w.records);   // 4 records = 3 x 16 bytes
+    auto apply = [&](uint32_t row, uint32_t gx, uint32_t gy) {
+        atomicAdd(&acc[row * 2], __uint_as_float(gx));
+        atomicAdd(&acc[row * 2 + 1], __uint_as_float(gy));
+    };
+    for (uint32_t i0 = beg + threadIdx.x * 4; i0 < end; i0 += kBlock * 8) {
+        // two groups of 4 records per lane in flight
+        const uint32_t i1 = i0 + kBlock * 4;
+        const size_t q0 = (size_t)(i0 >> 2) * 3;
+        const uint4 a0 = rec4[q0], a1 = rec4[q0 + 1], a2 = rec4[q0 + 2];
+        uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0;
+        if (i1 < end) {
+            const size_t q1 = (size_t)(i1 >> 2) * 3;
+            b0 = rec4[q1];
+            b1 = rec4[q1 + 1];
+            b2 = rec4[q1 + 2];
+        }
+        apply(a0.x, a0.y, a0.z);
+        if (i0 + 1 < end) apply(a0.w, a1.x, a1.y);
+        if (i0 + 2 < end) apply(a1.z, a1.w, a2.x);
+        if (i0 + 3 < end) apply(a2.y, a2.z, a2.w);
+        if (i1 < end) apply(b0.x, b0.y, b0.z);
+        if (i1 + 1 < end) apply(b0.w, b1.x, b1.y);
+        if (i1 + 2 < end) apply(b1.z, b1.w, b2.x);
+        if (i1 + 3 < end) apply(b2.y, b2.z, b2.w);
     }
     __syncthreads();
 
@@ -296,20 +450,32 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
     NGP_REQUIRE(((uintptr_t)workspace & 15u) == 0, "grid_encode_backward_binned: workspace must be 16-byte aligned");
     const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
     NGP_REQUIRE(workspace_bytes >= ws_bytes(B, L, n_chunks_max), "grid_encode_backward_binned: workspace too small");
-    NGP_REQUIRE((uint64_t)B * L * 8 < (1ull << 32), "grid_encode_backward_binned: B * L too large");
-    // the per-workgroup LDS histogram must hold the chunks of the largest level
+    NGP_REQUIRE((uint64_t)B * L * 8 + 4ull * n_chunks_max < (1ull << 32), "grid_encode_backward_binned: B * L too large");
     NGP_REQUIRE(n_chunks_max <= kMaxChunks, "grid_encode_backward_binned: table too large (> %u chunks)", kMaxChunks);
     hipStream_t st = as_stream(stream);
     const WsLayout w = ws_layout(workspace, n_chunks_max);
-    const uint32_t ntiles = ceil_div(B, kBlock);
-    const size_t hist_bytes = (size_t)n_chunks_max * 4;
+    const bool align = align_corners != 0;
+    const uint32_t nbins_cap = (n_chunks_max + 3u) & ~3u;
+    const size_t fill_lds = (size_t)nbins_cap * 12 + (size_t)kFillTile * 8 * 16;
+    static const bool lds_ok = [] {   // both kernels want more than the default 64 KiB of dynamic LDS
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(bin_private_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kPrivRows * 8) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void *>(bin_fill_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxChunks * 12 + kFillTile * 8 * 16) ==
+                   hipSuccess;
+    }();
+    NGP_REQUIRE(lds_ok, "grid_encode_backward_binned: cannot raise the dynamic LDS limit");
 
     bin_plan_kernel<<<1, 1024, 0, st>>>(offsets, L, n_chunks_max, w);
-    bin_traverse_kernel<false><<<ntiles * max_level, kBlock, hist_bytes, st>>>(grad, inputs, offsets, B, ntiles, lv,
-                                                                               gridtype, align_corners != 0, interp, w);
+    bin_private_kernel<<<256, 512, kPrivRows * 8, st>>>(grad, inputs, offsets, grad_embeddings, B, max_level, lv,
+                                                       gridtype, align, interp, w);
+    const uint32_t ct = ceil_div(B, kCountTile);
+    bin_count_kernel<<<ct * max_level, kBlock, (size_t)n_chunks_max * 4, st>>>(inputs, offsets, B, ct, lv, gridtype, align,
+                                                                              interp, w);
     bin_scan_kernel<<<1, 1024, 0, st>>>(L, w);
-    bin_traverse_kernel<true><<<ntiles * max_level, kBlock, hist_bytes, st>>>(grad, inputs, offsets, B, ntiles, lv,
-                                                                              gridtype, align_corners != 0, interp, w);
+    const uint32_t ft = ceil_div(B, kFillTile);
+    bin_fill_kernel<<<ft * max_level, kBlock, fill_lds, st>>>(grad, inputs, offsets, B, ft, nbins_cap, lv, gridtype,
+                                                             align, interp, w);
     const uint32_t n_items_max = n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
     bin_reduce_kernel<<<n_items_max, kBlock, 0, st>>>(offsets, grad_embeddings, L, w);
     NGP_CHECK_LAUNCH("grid_encode_backward_binned");

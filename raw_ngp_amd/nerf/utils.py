@@ -42,7 +42,9 @@ def get_rays(poses, intrinsics, H, W, N=-1, coords=None, ldirs=None, generator=N
                               torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
         i, j = i.reshape(-1) + 0.5, j.reshape(-1) + 0.5
     directions = torch.stack(((i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)), dim=-1)
-    rays_d = (directions.unsqueeze(1) @ poses[:, :3, :3].transpose(-1, -2)).squeeze(1)
+    # rays_d = R @ directions per ray; written as a broadcast multiply-sum: the batched [N,1,3] x [N,3,3]
+    # matmul the reference uses (train_utils.py:159) dispatches one tiny GEMM per ray on ROCm (0.3 ms)
+    rays_d = (directions.unsqueeze(1) * poses[:, :3, :3]).sum(-1)
     results["rays_o"] = poses[:, :3, 3].expand_as(rays_d)
     results["rays_d"] = rays_d
     results["rays_ldir"] = ldirs.expand_as(rays_d) if ldirs is not None else None
