@@ -173,14 +173,17 @@ int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const
  * ngp_grid_encode_backward's scatter (grad_embeddings += ...; different summation order), computed as
  * bin -> LDS reduce (csrc/grid_backward_binned.hip).  Needs caller-owned scratch:
  *   workspace_bytes >= ngp_x_grid_backward_workspace_bytes(B, L, n_rows_total), 16-byte aligned,
- *   n_rows_total = rows of `embeddings` (= offsets[L], known to the host from the tensor shape).
+ *   n_rows_total = rows of `embeddings` (= offsets[L], known to the host from the tensor shape);
+ *   max_level_rows = rows of the largest level (max_l offsets[l+1] - offsets[l]) or 0 if the host does
+ *   not know it (it sizes the per-workgroup LDS histograms; a correct value is faster, never required...
+ *   but a value SMALLER than the truth is an error the kernels cannot detect).
  * Does not compute grad_inputs (call ngp_grid_encode_backward's input part separately if needed). */
 size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, uint32_t n_rows_total);
 int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,
                                       float *grad_embeddings, uint32_t B, uint32_t L, uint32_t max_level,
                                       float S, uint32_t H, uint32_t gridtype, int align_corners,
-                                      uint32_t interp, uint32_t n_rows_total, void *workspace,
-                                      size_t workspace_bytes, ngp_stream_t stream);
+                                      uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
+                                      void *workspace, size_t workspace_bytes, ngp_stream_t stream);
 
 /* grad_inputs[b, d] = sum_{l, ch} grad[l, b, ch] * dy_dx[b, l, d, ch] -- the second half of
  * ngp_grid_encode_backward (gridencoder.cu:352-378) on its own. */

@@ -41,7 +41,8 @@ _SIGNATURES = {
     "ngp_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
     "ngp_march_rays": [_u, _u, _p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _p, _p, _p, _p, _p, _p, _p],
     "ngp_composite_rays": [_u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _p],
-    "ngp_x_grid_encode_backward_binned": [_p, _p, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _p, ctypes.c_size_t],
+    "ngp_x_grid_encode_backward_binned": [_p, _p, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
+                                          ctypes.c_size_t],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
@@ -148,6 +149,17 @@ class _GridBackend:
     # D = 3, C = 2 (the field's encoder) takes the atomic-free binned scatter; everything else, or
     # use_binned_backward = False, takes the reference-shaped float-atomic kernel.
     use_binned_backward = True
+    _level_rows = {}   # (data_ptr, numel) of an offsets tensor -> rows of its largest level (one host read, cached)
+
+    @staticmethod
+    def _max_level_rows(offsets):
+        key = (offsets.data_ptr(), offsets.numel())
+        val = _GridBackend._level_rows.get(key)
+        if val is None:
+            o = offsets.detach().cpu()
+            val = int((o[1:] - o[:-1]).max())
+            _GridBackend._level_rows[key] = val
+        return val
 
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S, H, dy_dx,
@@ -158,7 +170,8 @@ class _GridBackend:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=grad.device)
             _call("ngp_x_grid_encode_backward_binned", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
                   _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings"), B, L, max_level,
-                  float(S), H, gridtype, int(bool(align_corners)), interp, rows, ws.data_ptr(), nbytes)
+                  float(S), H, gridtype, int(bool(align_corners)), interp, rows,
+                  _GridBackend._max_level_rows(offsets), ws.data_ptr(), nbytes)
             if dy_dx is not None and grad_inputs is not None:
                 _call("ngp_x_grid_input_backward", grad, _ptr(grad, "f", "grad"), _ptr(dy_dx, "f", "dy_dx"),
                       _ptr(grad_inputs, "f", "grad_inputs"), B, D, C, L)

@@ -4,11 +4,9 @@
 // atomicAdd per (sample, level, corner, channel).  On MI355X global float atomics execute memory-side
 // at ~21 G requests/s when lanes hit different 64-B lines (measured: tools/ubench/atomics.hip), i.e.
 // 3.3 ms for 2^18 samples -- 8x the whole step budget.  Plain stores and LDS atomics are ~50x faster,
-// so the scatter becomes "keep small levels in LDS, bin the rest, reduce bins in LDS":
+// (and LDS *float* atomics turn out to be slow too: 0.19 row updates/clk/CU against 5.1 for ds_add_u64,
+// tools/ubench/lds_atomics.hip), so the scatter becomes "bin, then reduce each bin in LDS in 64-bit fixed point":
 //
-//   private  the leading levels whose tables fit one workgroup's LDS together (<= 18432 rows: levels 0-1 of
-//            the default encoder) are accumulated directly: every workgroup adds its share of the samples
-//            into an LDS copy of those tables and flushes the non-zero entries with contiguous atomics
 //   count    chunk = 4096 consecutive rows of one level (32 KiB of float2 accumulators).  Every (sample,
 //            level) of the remaining levels computes its 8 corner rows; a per-workgroup LDS histogram over
 //            the level's chunks is added to the global per-chunk counts
@@ -17,10 +15,13 @@
 //   fill     same traversal; records {row-in-chunk, w*g.x, w*g.y} (12 B) are first sorted by chunk inside
 //            the workgroup (LDS), then written so that consecutive lanes store consecutive records
 //   reduce   one workgroup per (chunk, segment): stream the records (16-byte loads, 8 records in flight per
-//            lane), ds_add into a 32 KiB LDS image of the chunk, then grad_table[chunk] += image (plain
-//            read-modify-write when the chunk has one segment, contiguous atomics otherwise)
+//            lane), convert each value to 64-bit fixed point (scale 2^k, k from the largest |gradient| of the
+//            call so that 2^25 records per row cannot overflow) and ds_add_u64 into a 64 KiB LDS image of the
+//            chunk; integer sums are exact and order-independent.  Then grad_table[chunk] += image (plain
+//            read-modify-write when the chunk has one segment, contiguous float atomics otherwise)
 //
-// Result: the same sums as the reference in a different (also unspecified) order.
+// Result: the reference's sums, each rounded once (resolution 2^-37 of the largest contribution) instead of
+// once per atomic in hardware order; bitwise reproducible except for the few multi-segment chunks.
 #include "grid_common.hpp"
 
 namespace ngp {
@@ -29,13 +30,16 @@ constexpr uint32_t kChunkRows = 4096;    // rows per chunk: 4096 x float2 = 32 K
 constexpr uint32_t kChunkShift = 12;
 constexpr uint32_t kSeg = 32768;         // records per reduce work item
 constexpr uint32_t kMaxChunks = 2048;    // LDS histogram bound of the binned path (tables up to 8 M rows)
-constexpr uint32_t kPrivRows = 18432;    // rows of the leading levels kept in one workgroup's LDS (144 KiB)
-constexpr uint32_t kFillTile = 512;      // samples per fill workgroup (2 per lane)
+constexpr uint32_t kSegBig = 8 * kSeg;   // ... of a heavy chunk (coarse dense levels): fewer, longer items
+constexpr uint32_t kReduceBlock = 512;
+constexpr int kHeadroomBits = 25;        // records that may land on one row without overflowing the int64 sum
+constexpr uint32_t kFillTile = 512;      // samples per fill workgroup
+constexpr uint32_t kFillBlock = 512;     // ... one per lane
 constexpr uint32_t kCountTile = 2048;    // samples per count workgroup (8 per lane)
 
 // workspace header (uint32 words); arrays sized for n_chunks_max
 struct WsLayout {
-    uint32_t *chunk_base;   // [kMaxLevels + 1] first chunk of each level; [L] = total chunks; [kMaxLevels + 1] = private levels
+    uint32_t *chunk_base;   // [kMaxLevels + 1] first chunk of each level; [L] = total chunks; [kMaxLevels + 1] = max |grad| bits
     uint32_t *count;        // [n_chunks_max]
     uint32_t *cursor;       // [n_chunks_max]
     uint32_t *offset;       // [n_chunks_max + 1] record offsets (multiples of 4)
@@ -74,18 +78,14 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const int32_t *__restric
 {
     __shared__ uint32_t total;
     if (threadIdx.x == 0) {
-        uint32_t run = 0, priv = 0;
+        uint32_t run = 0;
         for (uint32_t l = 0; l < L; l++) {
             w.chunk_base[l] = run;
             const uint32_t T = (uint32_t)(offsets[l + 1] - offsets[l]);
-            if (priv == l && (uint32_t)offsets[l + 1] <= kPrivRows) {
-                priv = l + 1;   // level l is accumulated privately: it owns no chunks
-            } else {
-                run += (T + kChunkRows - 1) >> kChunkShift;
-            }
+            run += (T + kChunkRows - 1) >> kChunkShift;
         }
         w.chunk_base[L] = run;
-        w.chunk_base[kMaxLevels + 1] = priv;
+        w.chunk_base[kMaxLevels + 1] = 0;   // max |grad| of this call, as float bits
         total = run;
     }
     __syncthreads();
@@ -93,54 +93,6 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const int32_t *__restric
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         w.count[i] = 0;
         w.cursor[i] = 0;
-    }
-}
-
-// ------------------------------------------------------------------ private levels
-__global__ __launch_bounds__(512) void bin_private_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
-                                                          const int32_t *__restrict__ offsets,
-                                                          float *__restrict__ grad_table, uint32_t B, uint32_t max_level,
-                                                          LevelRes lv, uint32_t gridtype, bool align_corners,
-                                                          uint32_t interp, WsLayout w)
-{
-    extern __shared__ float tab[];   // [rows of the private levels][2]
-    const uint32_t n_priv = min(w.chunk_base[kMaxLevels + 1], max_level);
-    if (n_priv == 0) return;
-    const uint32_t n_rows = (uint32_t)offsets[n_priv];
-    for (uint32_t i = threadIdx.x; i < n_rows * 2; i += 512) tab[i] = 0.0f;
-    __syncthreads();
-    const uint32_t per = (B + gridDim.x - 1) / gridDim.x;
-    const uint32_t b0 = blockIdx.x * per, b1 = min(B, b0 + per);
-    for (uint32_t level = 0; level < n_priv; level++) {
-        const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
-        float *t = tab + (size_t)(uint32_t)offsets[level] * 2;
-        for (uint32_t b = b0 + threadIdx.x; b < b1; b += 512) {
-            float x[3];
-#pragma unroll
-            for (uint32_t d = 0; d < 3; d++) x[d] = inputs[(size_t)b * 3 + d];
-            Cell<3> cl;
-            if (!locate<3>(x, g.res, align_corners, interp, cl)) continue;
-            const float2 gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * B + b];
-#pragma unroll
-            for (uint32_t corner = 0; corner < 8; corner++) {
-                float wgt = 1.0f;
-                uint32_t c[3];
-#pragma unroll
-                for (uint32_t d = 0; d < 3; d++) {
-                    const bool up = corner & (1u << d);
-                    wgt *= up ? cl.f[d] : 1.0f - cl.f[d];
-                    c[d] = up ? min(cl.c[d] + 1u, g.res - 1u) : cl.c[d];
-                }
-                uint32_t row = row_of<3>(g, c);
-                atomicAdd(&t[row * 2], wgt * gr.x);
-                atomicAdd(&t[row * 2 + 1], wgt * gr.y);
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_rows * 2; i += 512) {
-        const float v = tab[i];
-        if (v != 0.0f) unsafeAtomicAdd(grad_table + i, v);
     }
 }
 
@@ -172,7 +124,6 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restri
     extern __shared__ uint32_t hist[];
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t level = item / ntiles;
-    if (level < w.chunk_base[kMaxLevels + 1]) return;   // private level
     const uint32_t b0 = (item - level * ntiles) * kCountTile;
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
     const uint32_t first = w.chunk_base[level];
@@ -207,7 +158,8 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w)
         const uint32_t i = base + tid;
         const uint32_t cnt = i < n ? w.count[i] : 0u;
         const uint32_t cnt4 = (cnt + 3u) & ~3u;   // 4-record alignment: 16-byte loads in the reduce kernel
-        const uint32_t seg = i < n ? max(1u, (cnt + kSeg - 1) / kSeg) : 0u;
+        const uint32_t seg_len = cnt > kSegBig ? kSegBig : kSeg;   // heavy chunks: 8x longer work items
+        const uint32_t seg = i < n ? max(1u, (cnt + seg_len - 1) / seg_len) : 0u;
         uint32_t a = cnt4, s = seg;
 #pragma unroll
         for (uint32_t d = 1; d < 64u; d <<= 1) {
@@ -251,7 +203,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w)
 
 // ------------------------------------------------------------------ fill
 // LDS: hist[nbins] | lbase[nbins] | gbase[nbins] | stage[8 * kFillTile] x 16 B
-__global__ __launch_bounds__(kBlock) void bin_fill_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
+__global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
                                                          const int32_t *__restrict__ offsets, uint32_t B,
                                                          uint32_t ntiles, uint32_t nbins_cap, LevelRes lv,
                                                          uint32_t gridtype, bool align_corners, uint32_t interp,
@@ -260,25 +212,24 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(const float *__restric
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds, *lbase = lds + nbins_cap, *gbase = lds + 2 * nbins_cap;
     uint4 *stage = reinterpret_cast<uint4 *>(lds + 3 * nbins_cap);
-    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t wave_tot[kFillBlock / 64];
 
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t level = item / ntiles;
-    if (level < w.chunk_base[kMaxLevels + 1]) return;   // private level
     const uint32_t b0 = (item - level * ntiles) * kFillTile;
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
     const uint32_t first = w.chunk_base[level];
     const uint32_t nbins = w.chunk_base[level + 1] - first;
-    for (uint32_t i = threadIdx.x; i < nbins; i += kBlock) hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < nbins; i += kFillBlock) hist[i] = 0;
     __syncthreads();
 
-    constexpr uint32_t S = kFillTile / kBlock;   // samples per lane
+    constexpr uint32_t S = kFillTile / kFillBlock;   // samples per lane
     uint32_t rows[S][8], pos[S][8];
     Cell<3> cl[S];
     bool live[S];
 #pragma unroll
     for (uint32_t k = 0; k < S; k++) {
-        const uint32_t b = b0 + k * kBlock + threadIdx.x;
+        const uint32_t b = b0 + k * kFillBlock + threadIdx.x;
         live[k] = b < B && corner_rows(inputs, b, g, align_corners, interp, cl[k], rows[k]);
         if (live[k]) {
 #pragma unroll
@@ -290,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(const float *__restric
 
     // exclusive scan of hist -> staging offsets; reserve the global ranges
     {
-        const uint32_t per = (nbins + kBlock - 1) / kBlock;   // consecutive bins per lane
+        const uint32_t per = (nbins + kFillBlock - 1) / kFillBlock;   // consecutive bins per lane
         const uint32_t lo = threadIdx.x * per, hi = min(nbins, lo + per);
         uint32_t sum = 0;
         for (uint32_t i = lo; i < hi; i++) sum += hist[i];
@@ -313,14 +264,18 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(const float *__restric
         }
     }
     __syncthreads();
-    const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < kFillBlock / 64; k++) total += wave_tot[k];
 
     // stage the records sorted by chunk
+    float gmax = 0.0f;
 #pragma unroll
     for (uint32_t k = 0; k < S; k++) {
         if (!live[k]) continue;
-        const uint32_t b = b0 + k * kBlock + threadIdx.x;
+        const uint32_t b = b0 + k * kFillBlock + threadIdx.x;
         const float2 gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * B + b];
+        gmax = fmaxf(gmax, fmaxf(fabsf(gr.x), fabsf(gr.y)));
+        if (!(gr.x == gr.x && gr.y == gr.y)) gmax = __uint_as_float(0x7f800000u);   // NaN -> inf
 #pragma unroll
         for (uint32_t corner = 0; corner < 8; corner++) {
             float wgt = 1.0f;
@@ -335,9 +290,15 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(const float *__restric
             stage[lbase[bin] + pos[k][corner]] = r;
         }
     }
+    // largest |gradient| of the call -> fixed-point scale of the reduce kernel; one word for the whole grid,
+    // only waves that would raise it touch it
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, d, 64));
+    if ((threadIdx.x & 63u) == 0 && __float_as_uint(gmax) > __builtin_nontemporal_load(&w.chunk_base[kMaxLevels + 1]))
+        atomicMax(&w.chunk_base[kMaxLevels + 1], __float_as_uint(gmax));
     __syncthreads();
     // consecutive lanes -> consecutive records of one chunk (until the chunk changes)
-    for (uint32_t j = threadIdx.x; j < total; j += kBlock) {
+    for (uint32_t j = threadIdx.x; j < total; j += kFillBlock) {
         const uint4 r = stage[j];
         uint32_t *dst = w.records + (size_t)r.x * 3;
         dst[0] = r.y;
@@ -347,10 +308,10 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(const float *__restric
 }
 
 // ------------------------------------------------------------------ reduce
-__global__ __launch_bounds__(kBlock) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
-                                                           float *__restrict__ grad_table, uint32_t L, WsLayout w)
+__global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
+                                                                 float *__restrict__ grad_table, uint32_t L, WsLayout w)
 {
-    __shared__ float acc[kChunkRows * 2];
+    __shared__ unsigned long long acc[kChunkRows * 2];   // 64 KiB: int64 fixed-point sums, [row][channel]
     __shared__ uint32_t s_chunk;
     const uint32_t n_chunks = w.chunk_base[L];
     const uint32_t n_items = w.seg_base[n_chunks];
@@ -367,23 +328,32 @@ __global__ __launch_bounds__(kBlock) void bin_reduce_kernel(const int32_t *__res
         }
         s_chunk = lo;
     }
-    for (uint32_t i = threadIdx.x; i < kChunkRows * 2; i += kBlock) acc[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < kChunkRows * 2; i += kReduceBlock) acc[i] = 0ull;
     __syncthreads();
     const uint32_t chunk = s_chunk;
+    const uint32_t cnt = w.count[chunk];
+    const uint32_t seg_len = cnt > kSegBig ? kSegBig : kSeg;
     const uint32_t seg = item - w.seg_base[chunk];
     const uint32_t n_seg = w.seg_base[chunk + 1] - w.seg_base[chunk];
-    const uint32_t beg = w.offset[chunk] + seg * kSeg;                      // multiple of 4 records
-    const uint32_t end = min(w.offset[chunk] + w.count[chunk], beg + kSeg);
+    const uint32_t beg = w.offset[chunk] + seg * seg_len;                  // multiple of 4 records
+    const uint32_t end = min(w.offset[chunk] + cnt, beg + seg_len);
     if (beg >= end) return;   // empty chunk: nothing to add
+
+    // fixed-point scale: max |g| < 2^e  ->  |g * 2^k| < 2^(62 - headroom) with k = 62 - headroom - e
+    int e;
+    frexpf(__uint_as_float(w.chunk_base[kMaxLevels + 1]), &e);
+    const int k = 62 - kHeadroomBits - e;
 
     const uint4 *rec4 = reinterpret_cast<const uint4 *>(w.records);   // 4 records = 3 x 16 bytes
     auto apply = [&](uint32_t row, uint32_t gx, uint32_t gy) {
-        atomicAdd(&acc[row * 2], __uint_as_float(gx));
-        atomicAdd(&acc[row * 2 + 1], __uint_as_float(gy));
+        const long long qx = __double2ll_rn(scalbn((double)__uint_as_float(gx), k));
+        const long long qy = __double2ll_rn(scalbn((double)__uint_as_float(gy), k));
+        atomicAdd(&acc[row * 2], (unsigned long long)qx);
+        atomicAdd(&acc[row * 2 + 1], (unsigned long long)qy);
     };
-    for (uint32_t i0 = beg + threadIdx.x * 4; i0 < end; i0 += kBlock * 8) {
+    for (uint32_t i0 = beg + threadIdx.x * 4; i0 < end; i0 += kReduceBlock * 8) {
         // two groups of 4 records per lane in flight
-        const uint32_t i1 = i0 + kBlock * 4;
+        const uint32_t i1 = i0 + kReduceBlock * 4;
         const size_t q0 = (size_t)(i0 >> 2) * 3;
         const uint4 a0 = rec4[q0], a1 = rec4[q0 + 1], a2 = rec4[q0 + 2];
         uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0;
@@ -411,18 +381,18 @@ __global__ __launch_bounds__(kBlock) void bin_reduce_kernel(const int32_t *__res
     const uint32_t T = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t rows_here = min(kChunkRows, T - row0);
     float *dst = grad_table + ((size_t)(uint32_t)offsets[level] + row0) * 2;
+    auto to_float = [&](unsigned long long q) { return (float)scalbn((double)(long long)q, -k); };
     if (n_seg == 1) {
         float2 *d2 = reinterpret_cast<float2 *>(dst);
-        const float2 *a2 = reinterpret_cast<const float2 *>(acc);
-        for (uint32_t i = threadIdx.x; i < rows_here; i += kBlock) {
+        for (uint32_t i = threadIdx.x; i < rows_here; i += kReduceBlock) {
             float2 v = d2[i];
-            v.x += a2[i].x;
-            v.y += a2[i].y;
+            v.x += to_float(acc[i * 2]);
+            v.y += to_float(acc[i * 2 + 1]);
             d2[i] = v;
         }
     } else {
-        for (uint32_t i = threadIdx.x; i < rows_here * 2; i += kBlock)
-            if (acc[i] != 0.0f) unsafeAtomicAdd(dst + i, acc[i]);
+        for (uint32_t i = threadIdx.x; i < rows_here * 2; i += kReduceBlock)
+            if (acc[i] != 0ull) unsafeAtomicAdd(dst + i, to_float(acc[i]));
     }
 }
 
@@ -439,8 +409,8 @@ extern "C" size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, ui
 extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,
                                                  float *grad_embeddings, uint32_t B, uint32_t L, uint32_t max_level,
                                                  float S, uint32_t H, uint32_t gridtype, int align_corners,
-                                                 uint32_t interp, uint32_t n_rows_total, void *workspace,
-                                                 size_t workspace_bytes, ngp_stream_t stream)
+                                                 uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
+                                                 void *workspace, size_t workspace_bytes, ngp_stream_t stream)
 {
     if (B == 0 || max_level == 0) return NGP_OK;
     NGP_REQUIRE(grad && inputs && offsets && grad_embeddings && workspace, "grid_encode_backward_binned: null tensor");
@@ -455,29 +425,28 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
     hipStream_t st = as_stream(stream);
     const WsLayout w = ws_layout(workspace, n_chunks_max);
     const bool align = align_corners != 0;
-    const uint32_t nbins_cap = (n_chunks_max + 3u) & ~3u;
+    // LDS histograms are per level: the caller may tell us the largest level (rows); 0 = unknown
+    NGP_REQUIRE(max_level_rows <= n_rows_total, "grid_encode_backward_binned: max_level_rows > n_rows_total");
+    const uint32_t level_chunks = max_level_rows ? ceil_div(max_level_rows, kChunkRows) : n_chunks_max;
+    const uint32_t nbins_cap = (level_chunks + 3u) & ~3u;
     const size_t fill_lds = (size_t)nbins_cap * 12 + (size_t)kFillTile * 8 * 16;
-    static const bool lds_ok = [] {   // both kernels want more than the default 64 KiB of dynamic LDS
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(bin_private_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kPrivRows * 8) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void *>(bin_fill_kernel),
+    static const bool lds_ok = [] {   // the fill kernel wants more than the default 64 KiB of dynamic LDS
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(bin_fill_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kMaxChunks * 12 + kFillTile * 8 * 16) ==
-                   hipSuccess;
+               hipSuccess;
     }();
     NGP_REQUIRE(lds_ok, "grid_encode_backward_binned: cannot raise the dynamic LDS limit");
 
     bin_plan_kernel<<<1, 1024, 0, st>>>(offsets, L, n_chunks_max, w);
-    bin_private_kernel<<<256, 512, kPrivRows * 8, st>>>(grad, inputs, offsets, grad_embeddings, B, max_level, lv,
-                                                       gridtype, align, interp, w);
     const uint32_t ct = ceil_div(B, kCountTile);
-    bin_count_kernel<<<ct * max_level, kBlock, (size_t)n_chunks_max * 4, st>>>(inputs, offsets, B, ct, lv, gridtype, align,
-                                                                              interp, w);
+    bin_count_kernel<<<ct * max_level, kBlock, (size_t)nbins_cap * 4, st>>>(inputs, offsets, B, ct, lv, gridtype,
+                                                                              align, interp, w);
     bin_scan_kernel<<<1, 1024, 0, st>>>(L, w);
     const uint32_t ft = ceil_div(B, kFillTile);
-    bin_fill_kernel<<<ft * max_level, kBlock, fill_lds, st>>>(grad, inputs, offsets, B, ft, nbins_cap, lv, gridtype,
+    bin_fill_kernel<<<ft * max_level, kFillBlock, fill_lds, st>>>(grad, inputs, offsets, B, ft, nbins_cap, lv, gridtype,
                                                              align, interp, w);
     const uint32_t n_items_max = n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
-    bin_reduce_kernel<<<n_items_max, kBlock, 0, st>>>(offsets, grad_embeddings, L, w);
+    bin_reduce_kernel<<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, w);
     NGP_CHECK_LAUNCH("grid_encode_backward_binned");
     return NGP_OK;
 }
