@@ -34,6 +34,7 @@ from raw_ngp_amd import _lib, parallel  # noqa: E402
 from raw_ngp_amd.nerf.network import NeRFNetwork  # noqa: E402
 from raw_ngp_amd.nerf.options import Options  # noqa: E402
 from raw_ngp_amd.nerf.scene import SyntheticDataset  # noqa: E402
+from raw_ngp_amd.nerf.engine import FusedTrainer  # noqa: E402
 from raw_ngp_amd.nerf.trainer import Trainer  # noqa: E402
 
 METRIC = "training rays/sec + PSNR@5k-iters, NeRF-synthetic Lego 800², 1/2/4/8 MI355X"
@@ -41,8 +42,9 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29
 
 # dominant-kernel candidates: C symbol -> (index of the sample-count argument, algorithmic bytes/sample)
 ROOFLINE_KERNELS = {
-    "ngp_grid_encode_backward": (5, 12 + 16 * (8 + 64)),      # 1164 B/sample, SURVEY.md section 8d
-    "ngp_grid_encode_forward": (4, 12 + 16 * (64 + 8)),       # 1164 B/sample
+    "ngp_x_grid_encode_backward_binned": (4, 12 + 16 * (8 + 64)),   # 1164 B/sample, SURVEY.md section 8d
+    "ngp_grid_encode_backward": (5, 12 + 16 * (8 + 64)),             # the reference-shaped float-atomic scatter
+    "ngp_grid_encode_forward": (4, 12 + 16 * (64 + 8)),              # 1164 B/sample
 }
 
 
@@ -132,13 +134,14 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--views", type=int, default=100)
     ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--roofline-kernel", default="ngp_grid_encode_backward", choices=sorted(ROOFLINE_KERNELS))
+    ap.add_argument("--roofline-kernel", default="ngp_x_grid_encode_backward_binned", choices=sorted(ROOFLINE_KERNELS))
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--psnr-iters", type=int, default=0, help="if > 0: keep training to this many iterations and report PSNR")
     ap.add_argument("--arena", type=int, default=0, help="sample arena capacity (0 = reference two-pass march)")
     ap.add_argument("--torch-mlp", action="store_true", help="fp32 nn.Linear MLPs instead of the fused f16 MFMA field")
+    ap.add_argument("--autograd", action="store_true", help="per-op autograd path (Trainer) instead of the fused step")
     args = ap.parse_args()
 
     rank, world, local = parallel.init_from_env("cuda")
@@ -152,7 +155,11 @@ def main():
                   fused_mlp=not args.torch_mlp)
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
-    trainer = Trainer(opt, model, data, device=dev)
+    fused = not (args.autograd or args.torch_mlp)
+    if fused:
+        trainer = FusedTrainer(opt, model, data, device=dev, capacity=args.arena or args.rays * 160)
+    else:
+        trainer = Trainer(opt, model, data, device=dev)
 
     trainer.train(args.burnin)
     trainer.train(args.warmup)
@@ -162,16 +169,22 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     _lib.set_probe(args.roofline_kernel, arg_idx)
+    seen0 = int(trainer.samples_seen) if fused else 0
     t0 = time.perf_counter()
     samples = 0
     for _ in range(args.steps):
         trainer.train_step()
-        samples += trainer.last_num_points
+        if not fused:
+            samples += trainer.last_num_points      # (host value of the per-op path; the fused step never syncs)
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
     probe = _lib.probe_results()
     _lib.set_probe(None)
+    if fused:
+        samples = int(trainer.samples_seen) - seen0
+        overflow = int(trainer.arena.counter[1]) > trainer.cap
+        probe = (probe[0], samples, probe[2])       # live samples, not the launch capacity
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -207,7 +220,8 @@ def main():
                                    + ("fp32 nn.Linear MLPs" if args.torch_mlp else "fused tiny-MLP (configs[2])"),
                        "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
                        "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
-                       "parallelism": f"dp{world}", "arena": args.arena},
+                       "parallelism": f"dp{world}", "step": "fused" if fused else "autograd",
+                       "arena_capacity": trainer.cap if fused else 0, "arena_overflow": bool(fused and overflow)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if psnr is not None:

@@ -177,10 +177,13 @@ int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const
  *   max_level_rows = rows of the largest level (max_l offsets[l+1] - offsets[l]) or 0 if the host does
  *   not know it (it sizes the per-workgroup LDS histograms; a correct value is faster, never required...
  *   but a value SMALLER than the truth is an error the kernels cannot detect).
- * Does not compute grad_inputs (call ngp_grid_encode_backward's input part separately if needed). */
+ * grad is [L][grad_stride][2] (grad_stride = B for the reference layout); B_dev: optional device int32 with
+ * the number of live points (clamped to B; launch geometry and workspace are sized by B).
+ * Does not compute grad_inputs (ngp_x_grid_input_backward does). */
 size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, uint32_t n_rows_total);
 int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,
-                                      float *grad_embeddings, uint32_t B, uint32_t L, uint32_t max_level,
+                                      float *grad_embeddings, const int32_t *B_dev, uint32_t B,
+                                      uint32_t grad_stride, uint32_t L, uint32_t max_level,
                                       float S, uint32_t H, uint32_t gridtype, int align_corners,
                                       uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
                                       void *workspace, size_t workspace_bytes, ngp_stream_t stream);
@@ -220,6 +223,52 @@ int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float *dirs, con
                        const float *drgb, const int32_t *M_dev, uint32_t M, const void *image, float loss_scale,
                        float *denc, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6,
                        void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Kernels of the fused training step (csrc/engine_kernels.hip; host side raw_ngp_amd/nerf/engine.py).
+ * ---------------------------------------------------------------------------------- */
+
+/* ngp_grid_encode_forward for D = 3, C = 2 on WORLD-space points: applies GridEncoder.forward's map
+ * x01 = (x + bound) / (2 bound) (gridencoder/grid.py:161) on load, writes out[L][stride][2] and, if
+ * inputs01 != NULL, the mapped points [B,3] (what the backward kernels take as `inputs`).
+ * B_dev: optional device int32 with the number of live points (clamped to B_cap). */
+int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, const float *embeddings, const int32_t *offsets,
+                                   float *out, float *inputs01, const int32_t *B_dev, uint32_t B_cap, uint32_t stride,
+                                   uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                   int align_corners, uint32_t interp, ngp_stream_t stream);
+
+/* ngp_composite_rays_train_forward / _backward with one wave per ray (prefix product / scans instead of the
+ * serial walk).  Same arguments and results, except that EVERY sample of a live ray is written (zeros after
+ * the early stop), so weights / grad_sigmas / grad_rgbs need no zero-initialisation. */
+int ngp_x_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *ts,
+                                       const int32_t *rays, uint32_t M, uint32_t N, float T_thresh, float *weights,
+                                       float *weights_sum, float *depth, float *image, ngp_stream_t stream);
+int ngp_x_composite_rays_train_backward(const float *grad_weights, const float *grad_weights_sum,
+                                        const float *grad_depth, const float *grad_image, const float *sigmas,
+                                        const float *rgbs, const float *ts, const int32_t *rays,
+                                        const float *weights_sum, const float *depth, const float *image, uint32_t M,
+                                        uint32_t N, float T_thresh, float *grad_sigmas, float *grad_rgbs,
+                                        ngp_stream_t stream);
+
+/* Backward of the harness loss through the compositor in one kernel:
+ *   pred = image + (1 - weights_sum) * bg            (nerf/renderer.py:672)
+ *   gt   = rgb * a + bg * (1 - a)                    (nerf/train_utils.py:503-506), gt_rgba [N,4]
+ *   loss = mean over rays and channels of (pred - gt)^2   (:540-541; added to loss_out[0])
+ * bg_rgb [N,3] or NULL (then bg_const for all channels).  Writes d loss / d sigma, d loss / d rgb. */
+int ngp_x_composite_mse_backward(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *sigmas,
+                                 const float *rgbs, const float *ts, const int32_t *rays, const float *weights_sum,
+                                 const float *depth, const float *image, uint32_t M, uint32_t N, float T_thresh,
+                                 float *grad_sigmas, float *grad_rgbs, float *loss_out, ngp_stream_t stream);
+
+/* One torch.optim.Adam step (no amsgrad, no weight decay; main.py:245 uses eps 1e-15) over a flat fp32
+ * tensor in a single pass; `step` counts from 1; zero_grad != 0 clears `grad` afterwards. */
+int ngp_x_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr, float beta1,
+                    float beta2, float eps, uint32_t step, int zero_grad, ngp_stream_t stream);
+
+/* The slab test NeRFRenderer.run_cuda actually uses (the torch function, nerf/renderer.py:139-158, not the
+ * CUDA kernel): divides by (d + 1e-15), marks a miss with near = far = 1e9. */
+int ngp_x_near_far_from_aabb_v2(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
+                                float min_near, float *nears, float *fars, ngp_stream_t stream);
 
 #ifdef __cplusplus
 }

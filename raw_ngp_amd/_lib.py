@@ -41,12 +41,18 @@ _SIGNATURES = {
     "ngp_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
     "ngp_march_rays": [_u, _u, _p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _p, _p, _p, _p, _p, _p, _p],
     "ngp_composite_rays": [_u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _p],
-    "ngp_x_grid_encode_backward_binned": [_p, _p, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
+    "ngp_x_grid_encode_backward_binned": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
                                           ctypes.c_size_t],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
+    "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u],
+    "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
+    "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
+    "ngp_x_composite_mse_backward": [_p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p],
+    "ngp_x_adam_step": [_p, _p, _p, _p, ctypes.c_uint64, _f, _f, _f, _f, _u, _i],
+    "ngp_x_near_far_from_aabb_v2": [_p, _p, _p, _u, _f, _p, _p],
     "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_march_rays_train_arena": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _u, _p, _p, _p,
                                      _p, _p, _p, _p],
@@ -169,7 +175,7 @@ class _GridBackend:
             nbytes = load().ngp_x_grid_backward_workspace_bytes(B, L, rows)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=grad.device)
             _call("ngp_x_grid_encode_backward_binned", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
-                  _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings"), B, L, max_level,
+                  _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings"), None, B, B, L, max_level,
                   float(S), H, gridtype, int(bool(align_corners)), interp, rows,
                   _GridBackend._max_level_rows(offsets), ws.data_ptr(), nbytes)
             if dy_dx is not None and grad_inputs is not None:
@@ -181,6 +187,20 @@ class _GridBackend:
               _ptr(grad_embeddings, "f", "grad_embeddings"), B, D, C, L, max_level, float(S), H,
               _ptr(dy_dx, "f", "dy_dx", True), _ptr(grad_inputs, "f", "grad_inputs", True), gridtype,
               int(bool(align_corners)), interp)
+
+    @staticmethod
+    def grid_backward_binned(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
+                             workspace, gridtype=0, align_corners=False, interp=0):
+        """Extension entry for the fused step: caller-owned workspace, live count read from the device."""
+        _call("ngp_x_grid_encode_backward_binned", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
+              _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings"),
+              _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
+              int(bool(align_corners)), interp, grad_embeddings.shape[0], _GridBackend._max_level_rows(offsets),
+              workspace.data_ptr(), workspace.numel())
+
+    @staticmethod
+    def backward_workspace_bytes(B, L, rows):
+        return int(load().ngp_x_grid_backward_workspace_bytes(B, L, rows))
 
     @staticmethod
     def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
@@ -343,7 +363,56 @@ class _MlpBackend:
               *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], ws.data_ptr(), nbytes)
 
 
+class _EngineBackend:
+    """Kernels of the fused training step (extensions)."""
+
+    @staticmethod
+    def grid_encode_forward_slab(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L, max_level, S,
+                                 H, gridtype=0, align_corners=False, interp=0):
+        _call("ngp_x_grid_encode_forward_slab", xyzs, _ptr(xyzs, "f", "xyzs"), float(bound),
+              _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"), _ptr(out, "f", "out"),
+              _ptr(inputs01, "f", "inputs01", True), _ptr(B_dev, "i", "B_dev", True), B_cap, stride, L, max_level,
+              float(S), H, gridtype, int(bool(align_corners)), interp)
+
+    @staticmethod
+    def composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum, depth, image):
+        _call("ngp_x_composite_rays_train_forward", rays, _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"),
+              _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights, "f", "weights"),
+              _ptr(weights_sum, "f", "weights_sum"), _ptr(depth, "f", "depth"), _ptr(image, "f", "image"))
+
+    @staticmethod
+    def composite_rays_train_backward(grad_weights, grad_weights_sum, grad_depth, grad_image, sigmas, rgbs, ts, rays,
+                                      weights_sum, depth, image, M, N, T_thresh, grad_sigmas, grad_rgbs):
+        _call("ngp_x_composite_rays_train_backward", rays, _ptr(grad_weights, "f", "grad_weights"),
+              _ptr(grad_weights_sum, "f", "grad_weights_sum"), _ptr(grad_depth, "f", "grad_depth"),
+              _ptr(grad_image, "f", "grad_image"), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"),
+              _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), _ptr(weights_sum, "f", "weights_sum"),
+              _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), M, N, float(T_thresh),
+              _ptr(grad_sigmas, "f", "grad_sigmas"), _ptr(grad_rgbs, "f", "grad_rgbs"))
+
+    @staticmethod
+    def composite_mse_backward(gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, weights_sum, depth, image, M, N,
+                               T_thresh, grad_sigmas, grad_rgbs, loss_out):
+        _call("ngp_x_composite_mse_backward", rays, _ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
+              float(bg_const), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"),
+              _ptr(rays, "i", "rays"), _ptr(weights_sum, "f", "weights_sum"), _ptr(depth, "f", "depth"),
+              _ptr(image, "f", "image"), M, N, float(T_thresh), _ptr(grad_sigmas, "f", "grad_sigmas"),
+              _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
+
+    @staticmethod
+    def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, zero_grad=False):
+        _call("ngp_x_adam_step", param, _ptr(param, "f", "param"), _ptr(grad, "f", "grad"),
+              _ptr(exp_avg, "f", "exp_avg"), _ptr(exp_avg_sq, "f", "exp_avg_sq"), param.numel(), float(lr),
+              float(beta1), float(beta2), float(eps), int(step), int(bool(zero_grad)))
+
+    @staticmethod
+    def near_far_from_aabb_v2(rays_o, rays_d, aabb, N, min_near, nears, fars):
+        _call("ngp_x_near_far_from_aabb_v2", rays_o, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
+              _ptr(aabb, "f", "aabb"), N, float(min_near), _ptr(nears, "f", "nears"), _ptr(fars, "f", "fars"))
+
+
 gridencoder_backend = _GridBackend()
+engine_backend = _EngineBackend()
 mlp_backend = _MlpBackend()
 shencoder_backend = _SHBackend()
 freqencoder_backend = _FreqBackend()

@@ -1,0 +1,416 @@
+// Kernels of the fused training step (raw_ngp_amd/nerf/engine.py): the same arithmetic as the reference's
+// per-op path, arranged so that one optimiser step needs ~20 launches, no host synchronisation and no
+// intermediate layout copies.  Every kernel reads the number of live samples from device memory (the arena
+// march's counter), so launch geometry is fixed by the arena capacity and the step can be graph-captured.
+//
+//   grid_forward_slab     gridencoder.cu:82-249 on world-space points: folds GridEncoder.forward's
+//                         (x + bound) / (2 bound) map (grid.py:161) into the load and writes the [L, stride, 2]
+//                         slab the fused MLP consumes
+//   composite_* (wave)    raymarching.cu:519-597 / :623-712 with one WAVE per ray: transmittance by a
+//                         wave-wide exclusive prefix product, running sums by wave scans (the reference walks
+//                         each ray serially from one lane); the loss variant also folds in the harness'
+//                         MSE against gt*alpha + bg*(1-alpha) (train_utils.py:503-541) and bg mixing
+//                         (renderer.py:672), producing d sigma / d rgb directly
+//   adam                  torch.optim.Adam (main.py:245: eps 1e-15, no weight decay) in one pass
+//   near_far_v2           the torch slab test run_cuda really uses (renderer.py:139-158): /(d + 1e-15), miss -> 1e9
+#include "grid_common.hpp"
+
+namespace ngp {
+
+// ------------------------------------------------------------------ hash-grid forward into the slab
+__global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
+    const float *__restrict__ xyzs, float bound, const float *__restrict__ table, const int32_t *__restrict__ offsets,
+    float *__restrict__ out, float *__restrict__ inputs01, const int32_t *__restrict__ B_dev, uint32_t B_cap,
+    uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp)
+{
+    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t level = item / nchunks;
+    const uint32_t b = (item - level * nchunks) * kBlock + threadIdx.x;
+    const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
+    if (b >= B) return;
+
+    const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
+    const float *__restrict__ tab = table + (size_t)(uint32_t)offsets[level] * 2;
+    float x[3];
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++) x[d] = (xyzs[(size_t)b * 3 + d] + bound) / (2.0f * bound);
+    if (level == 0 && inputs01) {
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) inputs01[(size_t)b * 3 + d] = x[d];
+    }
+    float2 *dst = reinterpret_cast<float2 *>(out) + (size_t)level * stride + b;
+    Cell<3> cl;
+    if (!locate<3>(x, g.res, align_corners, interp, cl)) {
+        *dst = make_float2(0.f, 0.f);
+        return;
+    }
+    Row<2> rows[8];
+    float wts[8];
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; corner++) {
+        float w = 1.0f;
+        uint32_t c[3];
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) {
+            if (corner & (1u << d)) {
+                w *= cl.f[d];
+                c[d] = min(cl.c[d] + 1u, g.res - 1u);
+            } else {
+                w *= 1.0f - cl.f[d];
+                c[d] = cl.c[d];
+            }
+        }
+        wts[corner] = w;
+        rows[corner].load(tab + (size_t)row_of<3>(g, c) * 2);
+    }
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; corner++) {
+        ax = fmaf(wts[corner], rows[corner].v[0], ax);
+        ay = fmaf(wts[corner], rows[corner].v[1], ay);
+    }
+    *dst = make_float2(ax, ay);
+}
+
+// ------------------------------------------------------------------ wave scans
+__device__ __forceinline__ float wave_excl_prod(float v, uint32_t lane)
+{   // exclusive prefix product over the 64 lanes
+    float inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const float up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc *= up;
+    }
+    const float ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 1.0f : ex;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const float up = __shfl_up(v, d, 64);
+        if (lane >= d) v += up;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ compositing, one wave per ray
+// writes weights for every sample of the ray (0 after the early stop), so the caller need not pre-zero
+__global__ __launch_bounds__(256) void composite_forward_wave_kernel(
+    const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ ts,
+    const int32_t *__restrict__ rays, uint32_t M, uint32_t N, float T_thresh, float *__restrict__ weights,
+    float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image)
+{
+    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[(size_t)n * 2], cnt = (uint32_t)rays[(size_t)n * 2 + 1];
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0;
+    bool stopped = false;
+    if (cnt != 0 && off + cnt <= M) {
+        for (uint32_t base = 0; base < cnt; base += 64u) {
+            const uint32_t i = off + base + lane;
+            const bool have = base + lane < cnt;
+            if (stopped) {   // wave-uniform
+                if (have) weights[i] = 0.0f;
+                continue;
+            }
+            float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f;
+            if (have) {
+                const float2 tt = reinterpret_cast<const float2 *>(ts)[i];
+                alpha = 1.0f - __expf(-sigmas[i] * tt.y);
+                t = tt.x;
+                c0 = rgbs[(size_t)i * 3];
+                c1 = rgbs[(size_t)i * 3 + 1];
+                c2 = rgbs[(size_t)i * 3 + 2];
+            }
+            const float Tb = T * wave_excl_prod(1.0f - alpha, lane);   // transmittance in front of the sample
+            const float Ta = Tb * (1.0f - alpha);
+            // the reference keeps the sample that drives T below the threshold and drops everything after it
+            const unsigned long long hit = __ballot(have && Ta < T_thresh);
+            const uint32_t last = hit ? (uint32_t)__ffsll((long long)hit) - 1u : 63u;
+            const bool use = have && lane <= last;
+            const float w = use ? alpha * Tb : 0.0f;
+            if (have) weights[i] = w;
+            r += wave_sum(w * c0);
+            g += wave_sum(w * c1);
+            b += wave_sum(w * c2);
+            ws += wave_sum(w);
+            d += wave_sum(w * t);
+            T = __shfl(Ta, min(last, 63u), 64);
+            stopped = hit != 0ull;
+        }
+    }
+    if (lane == 0) {
+        weights_sum[n] = ws;
+        depth[n] = d;
+        image[(size_t)n * 3] = r;
+        image[(size_t)n * 3 + 1] = g;
+        image[(size_t)n * 3 + 2] = b;
+    }
+}
+
+// MODE 0: plain backward with caller-provided gradients (same contract as ngp_composite_rays_train_backward,
+//         but every sample of the ray is written: zeros after the early stop)
+// MODE 1: gradients of the MSE loss  mean_{n,c} ((image + (1 - ws) bg - gt)^2)  with gt = rgb*a + bg*(1-a);
+//         also accumulates the loss value into loss_out[0]
+template <int MODE>
+__global__ __launch_bounds__(256) void composite_backward_wave_kernel(
+    const float *__restrict__ grad_weights, const float *__restrict__ grad_weights_sum,
+    const float *__restrict__ grad_depth, const float *__restrict__ grad_image, const float *__restrict__ gt_rgba,
+    const float *__restrict__ bg_rgb, float bg_const, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+    const float *__restrict__ ts, const int32_t *__restrict__ rays, const float *__restrict__ weights_sum,
+    const float *__restrict__ depth, const float *__restrict__ image, uint32_t M, uint32_t N, float T_thresh,
+    float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs, float *__restrict__ loss_out)
+{
+    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[(size_t)n * 2], cnt = (uint32_t)rays[(size_t)n * 2 + 1];
+    const bool live = cnt != 0 && off + cnt <= M;
+    const float rF = image[(size_t)n * 3], gF = image[(size_t)n * 3 + 1], bF = image[(size_t)n * 3 + 2];
+    const float wsF = weights_sum[n], dF = depth[n];
+    float gr, gg, gb, gws, gd;
+    if (MODE == 1) {
+        const float4 px = reinterpret_cast<const float4 *>(gt_rgba)[n];
+        const float b0 = bg_rgb ? bg_rgb[(size_t)n * 3] : bg_const, b1 = bg_rgb ? bg_rgb[(size_t)n * 3 + 1] : bg_const,
+                    b2 = bg_rgb ? bg_rgb[(size_t)n * 3 + 2] : bg_const;
+        const float e0 = (rF + (1.0f - wsF) * b0) - (px.x * px.w + b0 * (1.0f - px.w));
+        const float e1 = (gF + (1.0f - wsF) * b1) - (px.y * px.w + b1 * (1.0f - px.w));
+        const float e2 = (bF + (1.0f - wsF) * b2) - (px.z * px.w + b2 * (1.0f - px.w));
+        const float k = 2.0f / (3.0f * (float)N);
+        gr = k * e0;
+        gg = k * e1;
+        gb = k * e2;
+        gws = -(gr * b0 + gg * b1 + gb * b2);
+        gd = 0.0f;
+        if (lane == 0) atomicAdd(loss_out, (e0 * e0 + e1 * e1 + e2 * e2) / (3.0f * (float)N));
+    } else {
+        gr = grad_image[(size_t)n * 3];
+        gg = grad_image[(size_t)n * 3 + 1];
+        gb = grad_image[(size_t)n * 3 + 2];
+        gws = grad_weights_sum[n];
+        gd = grad_depth[n];
+    }
+    if (!live) return;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0;
+    bool stopped = false;
+    for (uint32_t base = 0; base < cnt; base += 64u) {
+        const uint32_t i = off + base + lane;
+        const bool have = base + lane < cnt;
+        if (stopped) {
+            if (have) {
+                grad_sigmas[i] = 0.0f;
+                grad_rgbs[(size_t)i * 3] = grad_rgbs[(size_t)i * 3 + 1] = grad_rgbs[(size_t)i * 3 + 2] = 0.0f;
+            }
+            continue;
+        }
+        float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f, dt = 0.f, gw = 0.f;
+        if (have) {
+            const float2 tt = reinterpret_cast<const float2 *>(ts)[i];
+            t = tt.x;
+            dt = tt.y;
+            alpha = 1.0f - __expf(-sigmas[i] * dt);
+            c0 = rgbs[(size_t)i * 3];
+            c1 = rgbs[(size_t)i * 3 + 1];
+            c2 = rgbs[(size_t)i * 3 + 2];
+            if (MODE == 0) gw = grad_weights[i];
+        }
+        const float Tb = T * wave_excl_prod(1.0f - alpha, lane);
+        const float Ta = Tb * (1.0f - alpha);
+        const unsigned long long hit = __ballot(have && Ta < T_thresh);
+        const uint32_t last = hit ? (uint32_t)__ffsll((long long)hit) - 1u : 63u;
+        const bool use = have && lane <= last;
+        const float w = use ? alpha * Tb : 0.0f;
+        // running sums up to and including this sample
+        const float ri = r + wave_incl_sum(w * c0, lane), gi = g + wave_incl_sum(w * c1, lane),
+                    bi = b + wave_incl_sum(w * c2, lane), wi = ws + wave_incl_sum(w, lane),
+                    di = d + wave_incl_sum(w * t, lane);
+        if (have) {
+            float s = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+            if (use) {
+                q0 = gr * w;
+                q1 = gg * w;
+                q2 = gb * w;
+                s = gr * fmaf(Ta, c0, -(rF - ri));
+                s = fmaf(gg, fmaf(Ta, c1, -(gF - gi)), s);
+                s = fmaf(gb, fmaf(Ta, c2, -(bF - bi)), s);
+                s = fmaf(gws + gw, Ta - (wsF - wi), s);
+                s = fmaf(gd, fmaf(Ta, t, -(dF - di)), s);
+                s *= dt;
+            }
+            grad_sigmas[i] = s;
+            grad_rgbs[(size_t)i * 3] = q0;
+            grad_rgbs[(size_t)i * 3 + 1] = q1;
+            grad_rgbs[(size_t)i * 3 + 2] = q2;
+        }
+        r = __shfl(ri, 63, 64);
+        g = __shfl(gi, 63, 64);
+        b = __shfl(bi, 63, 64);
+        ws = __shfl(wi, 63, 64);
+        d = __shfl(di, 63, 64);
+        T = __shfl(Ta, min(last, 63u), 64);
+        stopped = hit != 0ull;
+    }
+}
+
+// ------------------------------------------------------------------ Adam
+// torch.optim.Adam(step): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+//                         p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),  bc_i = 1 - b_i^step
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *g, float *__restrict__ m,
+                                                   float *__restrict__ v, size_t n4, size_t n, float lr, float b1,
+                                                   float b2, float eps, float bc1, float rsqrt_bc2, bool zero_grad,
+                                                   float *g_mut)
+{
+    const float step_size = lr / bc1;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+    for (size_t i = tid; i < n4; i += nthreads) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i];
+        const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+#define NGP_ADAM1(c)                                                       \
+    mm.c = b1 * mm.c + (1.0f - b1) * gg.c;                                 \
+    vv.c = b2 * vv.c + (1.0f - b2) * gg.c * gg.c;                          \
+    pp.c -= step_size * (mm.c / (sqrtf(vv.c) * rsqrt_bc2 + eps));
+        NGP_ADAM1(x) NGP_ADAM1(y) NGP_ADAM1(z) NGP_ADAM1(w)
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<float4 *>(g_mut)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (size_t i = n4 * 4 + tid; i < n; i += nthreads) {   // tail
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi, vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + eps));
+        if (zero_grad) g_mut[i] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------ near / far (torch semantics of run_cuda)
+__global__ void near_far_v2_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                   const float *__restrict__ aabb, uint32_t N, float min_near, float *__restrict__ nears,
+                                   float *__restrict__ fars)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float near = -3.402823466e+38f, far = 3.402823466e+38f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float o = rays_o[(size_t)n * 3 + a], dd = rays_d[(size_t)n * 3 + a] + 1e-15f;
+        const float t0 = (aabb[a] - o) / dd, t1 = (aabb[3 + a] - o) / dd;
+        near = fmaxf(near, t0 < t1 ? t0 : t1);
+        far = fminf(far, t0 > t1 ? t0 : t1);
+    }
+    if (far < near) near = far = 1e9f;
+    nears[n] = fmaxf(near, min_near);
+    fars[n] = far;
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, const float *embeddings,
+                                              const int32_t *offsets, float *out, float *inputs01, const int32_t *B_dev,
+                                              uint32_t B_cap, uint32_t stride, uint32_t L, uint32_t max_level, float S,
+                                              uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                              ngp_stream_t stream)
+{
+    if (B_cap == 0 || max_level == 0) return NGP_OK;
+    NGP_REQUIRE(xyzs && embeddings && offsets && out, "grid_encode_forward_slab: null tensor");
+    NGP_REQUIRE(stride >= B_cap, "grid_encode_forward_slab: stride smaller than B_cap");
+    NGP_REQUIRE(bound > 0.0f, "grid_encode_forward_slab: bound must be positive");
+    LevelRes lv;
+    NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_forward_slab: L must be in [1, %u]", kMaxLevels);
+    NGP_REQUIRE(max_level <= L, "grid_encode_forward_slab: max_level > L");
+    const uint32_t nchunks = ceil_div(B_cap, kBlock);
+    grid_forward_slab_kernel<<<dim3(nchunks * max_level), dim3(kBlock), 0, as_stream(stream)>>>(
+        xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype, align_corners != 0,
+        interp);
+    NGP_CHECK_LAUNCH("grid_encode_forward_slab");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *ts,
+                                                  const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                                  float *weights, float *weights_sum, float *depth, float *image,
+                                                  ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays && weights_sum && depth && image, "x_composite_rays_train_forward: null tensor");
+    NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && weights), "x_composite_rays_train_forward: null sample tensor");
+    composite_forward_wave_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
+        sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum, depth, image);
+    NGP_CHECK_LAUNCH("x_composite_rays_train_forward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_composite_rays_train_backward(const float *grad_weights, const float *grad_weights_sum,
+                                                   const float *grad_depth, const float *grad_image,
+                                                   const float *sigmas, const float *rgbs, const float *ts,
+                                                   const int32_t *rays, const float *weights_sum, const float *depth,
+                                                   const float *image, uint32_t M, uint32_t N, float T_thresh,
+                                                   float *grad_sigmas, float *grad_rgbs, ngp_stream_t stream)
+{
+    if (N == 0 || M == 0) return NGP_OK;
+    NGP_REQUIRE(grad_weights && grad_weights_sum && grad_depth && grad_image && sigmas && rgbs && ts && rays &&
+                    weights_sum && depth && image && grad_sigmas && grad_rgbs,
+                "x_composite_rays_train_backward: null tensor");
+    composite_backward_wave_kernel<0><<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
+        grad_weights, grad_weights_sum, grad_depth, grad_image, nullptr, nullptr, 0.0f, sigmas, rgbs, ts, rays,
+        weights_sum, depth, image, M, N, T_thresh, grad_sigmas, grad_rgbs, nullptr);
+    NGP_CHECK_LAUNCH("x_composite_rays_train_backward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_composite_mse_backward(const float *gt_rgba, const float *bg_rgb, float bg_const,
+                                            const float *sigmas, const float *rgbs, const float *ts,
+                                            const int32_t *rays, const float *weights_sum, const float *depth,
+                                            const float *image, uint32_t M, uint32_t N, float T_thresh,
+                                            float *grad_sigmas, float *grad_rgbs, float *loss_out, ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(gt_rgba && rays && weights_sum && depth && image && loss_out, "composite_mse_backward: null tensor");
+    NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && grad_sigmas && grad_rgbs), "composite_mse_backward: null sample tensor");
+    NGP_REQUIRE(((uintptr_t)gt_rgba & 15u) == 0, "composite_mse_backward: gt_rgba must be 16-byte aligned");
+    composite_backward_wave_kernel<1><<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
+        nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, weights_sum, depth, image, M,
+        N, T_thresh, grad_sigmas, grad_rgbs, loss_out);
+    NGP_CHECK_LAUNCH("composite_mse_backward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr,
+                               float beta1, float beta2, float eps, uint32_t step, int zero_grad, ngp_stream_t stream)
+{
+    if (n == 0) return NGP_OK;
+    NGP_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adam_step: null tensor");
+    NGP_REQUIRE(step >= 1, "adam_step: step counts from 1");
+    NGP_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) == 0,
+                "adam_step: tensors must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const size_t n4 = n / 4;
+    const uint32_t blocks = (uint32_t)min((size_t)256 * 8, (n4 + 255) / 256 + 1);
+    adam_kernel<<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n4, n, lr, beta1, beta2,
+                                                                  eps, (float)bc1, (float)(1.0 / sqrt(bc2)), zero_grad != 0,
+                                                                  grad);
+    NGP_CHECK_LAUNCH("adam_step");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_near_far_from_aabb_v2(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
+                                           float min_near, float *nears, float *fars, ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb_v2: null tensor");
+    near_far_v2_kernel<<<dim3(ceil_div(N, 256u)), dim3(256), 0, as_stream(stream)>>>(rays_o, rays_d, aabb, N, min_near,
+                                                                                    nears, fars);
+    NGP_CHECK_LAUNCH("near_far_from_aabb_v2");
+    return NGP_OK;
+}

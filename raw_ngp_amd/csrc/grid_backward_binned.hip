@@ -117,14 +117,17 @@ __device__ __forceinline__ bool corner_rows(const float *__restrict__ inputs, ui
 
 // ------------------------------------------------------------------ count
 __global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restrict__ inputs,
-                                                          const int32_t *__restrict__ offsets, uint32_t B,
+                                                          const int32_t *__restrict__ offsets,
+                                                          const int32_t *__restrict__ B_dev, uint32_t B_cap,
                                                           uint32_t ntiles, LevelRes lv, uint32_t gridtype,
                                                           bool align_corners, uint32_t interp, WsLayout w)
 {
     extern __shared__ uint32_t hist[];
+    const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t level = item / ntiles;
     const uint32_t b0 = (item - level * ntiles) * kCountTile;
+    if (b0 >= B) return;
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
     const uint32_t first = w.chunk_base[level];
     const uint32_t nbins = w.chunk_base[level + 1] - first;
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w)
 // ------------------------------------------------------------------ fill
 // LDS: hist[nbins] | lbase[nbins] | gbase[nbins] | stage[8 * kFillTile] x 16 B
 __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
-                                                         const int32_t *__restrict__ offsets, uint32_t B,
+                                                         const int32_t *__restrict__ offsets,
+                                                         const int32_t *__restrict__ B_dev, uint32_t B_cap, uint32_t gstride,
                                                          uint32_t ntiles, uint32_t nbins_cap, LevelRes lv,
                                                          uint32_t gridtype, bool align_corners, uint32_t interp,
                                                          WsLayout w)
@@ -214,9 +218,11 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     uint4 *stage = reinterpret_cast<uint4 *>(lds + 3 * nbins_cap);
     __shared__ uint32_t wave_tot[kFillBlock / 64];
 
+    const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t level = item / ntiles;
     const uint32_t b0 = (item - level * ntiles) * kFillTile;
+    if (b0 >= B) return;
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
     const uint32_t first = w.chunk_base[level];
     const uint32_t nbins = w.chunk_base[level + 1] - first;
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     for (uint32_t k = 0; k < S; k++) {
         if (!live[k]) continue;
         const uint32_t b = b0 + k * kFillBlock + threadIdx.x;
-        const float2 gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * B + b];
+        const float2 gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * gstride + b];
         gmax = fmaxf(gmax, fmaxf(fabsf(gr.x), fabsf(gr.y)));
         if (!(gr.x == gr.x && gr.y == gr.y)) gmax = __uint_as_float(0x7f800000u);   // NaN -> inf
 #pragma unroll
@@ -407,7 +413,8 @@ extern "C" size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, ui
 }
 
 extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,
-                                                 float *grad_embeddings, uint32_t B, uint32_t L, uint32_t max_level,
+                                                 float *grad_embeddings, const int32_t *B_dev, uint32_t B,
+                                                 uint32_t grad_stride, uint32_t L, uint32_t max_level,
                                                  float S, uint32_t H, uint32_t gridtype, int align_corners,
                                                  uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
                                                  void *workspace, size_t workspace_bytes, ngp_stream_t stream)
@@ -417,6 +424,7 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
     LevelRes lv;
     NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_backward_binned: L must be in [1, %u]", kMaxLevels);
     NGP_REQUIRE(max_level <= L, "grid_encode_backward_binned: max_level > L");
+    NGP_REQUIRE(grad_stride >= B, "grid_encode_backward_binned: grad_stride smaller than B");
     NGP_REQUIRE(((uintptr_t)workspace & 15u) == 0, "grid_encode_backward_binned: workspace must be 16-byte aligned");
     const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
     NGP_REQUIRE(workspace_bytes >= ws_bytes(B, L, n_chunks_max), "grid_encode_backward_binned: workspace too small");
@@ -439,11 +447,11 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
 
     bin_plan_kernel<<<1, 1024, 0, st>>>(offsets, L, n_chunks_max, w);
     const uint32_t ct = ceil_div(B, kCountTile);
-    bin_count_kernel<<<ct * max_level, kBlock, (size_t)nbins_cap * 4, st>>>(inputs, offsets, B, ct, lv, gridtype,
+    bin_count_kernel<<<ct * max_level, kBlock, (size_t)nbins_cap * 4, st>>>(inputs, offsets, B_dev, B, ct, lv, gridtype,
                                                                               align, interp, w);
     bin_scan_kernel<<<1, 1024, 0, st>>>(L, w);
     const uint32_t ft = ceil_div(B, kFillTile);
-    bin_fill_kernel<<<ft * max_level, kFillBlock, fill_lds, st>>>(grad, inputs, offsets, B, ft, nbins_cap, lv, gridtype,
+    bin_fill_kernel<<<ft * max_level, kFillBlock, fill_lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft, nbins_cap, lv, gridtype,
                                                              align, interp, w);
     const uint32_t n_items_max = n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
     bin_reduce_kernel<<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, w);

@@ -1,0 +1,172 @@
+"""Fused training step of the density-grid path: the reference's train_step + backward + optimiser
+(nerf/train_utils.py:481-568, :890-907; nerf/renderer.py:515-556; main.py:245,261) as one fixed sequence of
+~20 HIP kernel launches on pre-allocated buffers.
+
+Compared with the per-op autograd path (raw_ngp_amd.nerf.trainer.Trainer, which mirrors the reference op by op)
+the arithmetic is the same and the plumbing is not:
+  * rays are marched ONCE into a sample arena (count + scan + coalesced expand); nothing waits for the sample
+    count on the host -- every later kernel reads it from the arena's device counter
+  * the hash-grid encoder writes the level-major slab the fused MFMA MLP reads; no permutes, no concatenations
+  * compositing runs one wave per ray; the MSE loss, the background mix and its gradient are folded into the
+    compositing backward kernel
+  * the table gradient is binned and reduced in LDS (64-bit fixed point), Adam is one pass per parameter buffer
+  * autograd, GradScaler, zeros_like and the foreach optimiser are gone (their work is in the kernels)
+The density-grid refresh (every `update_extra_interval` steps) still goes through NeRFRenderer.update_extra_state.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import parallel, raymarching
+from .._lib import engine_backend as eb
+from .._lib import gridencoder_backend as gb
+from .._lib import mlp_backend as mb
+from .._lib import raymarching_backend as rb
+
+
+class FusedTrainer:
+    """Drop-in for Trainer.train_step / train on models that satisfy NeRFNetwork._fused()."""
+
+    def __init__(self, opt, model, dataset, device="cuda", seed=0, capacity=None, betas=(0.9, 0.999), eps=1e-15):
+        assert opt.cuda_ray and not opt.rfield and opt.pose_opt == "none", "fused step: density-grid path only"
+        self.opt, self.model, self.data, self.device = opt, model.to(device), dataset, torch.device(device)
+        opt.fused_mlp = True
+        assert model._fused(), "fused step needs the default field configuration"
+        self.rank, self.world_size = parallel.rank(), parallel.world_size()
+        self.N = N = opt.num_rays
+        self.cap = cap = int(capacity or max(opt.arena_capacity, N * 128))
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        enc = model.grid_encoder
+        self.L = enc.num_levels
+        self.S = float(np.log2(enc.per_level_scale))
+        self.H = enc.base_resolution
+        self.table = enc.embeddings.data
+        self.rows = self.table.shape[0]
+        # the six MLP matrices become views of one flat buffer (one Adam launch, one all-reduce)
+        layers = list(model.grid_mlp.net) + list(model.view_mlp.net)
+        sizes = [l.weight.numel() for l in layers]
+        self.w_flat = torch.empty(sum(sizes), **f32)
+        self.w_grad = torch.zeros(sum(sizes), **f32)
+        self.weights, self.dws, off = [], [], 0
+        for l, n in zip(layers, sizes):
+            view = self.w_flat[off:off + n].view_as(l.weight)
+            view.copy_(l.weight.data)
+            l.weight.data = view
+            self.weights.append(view)
+            self.dws.append(self.w_grad[off:off + n].view_as(l.weight))
+            off += n
+        # optimiser state
+        self.betas, self.eps, self.lr0 = betas, eps, opt.lr
+        self.t_m, self.t_v = torch.zeros_like(self.table), torch.zeros_like(self.table)
+        self.w_m, self.w_v = torch.zeros_like(self.w_flat), torch.zeros_like(self.w_flat)
+        self.table_grad = torch.zeros_like(self.table)
+        # per-ray and per-sample buffers
+        self.arena = raymarching.MarchArena(N, opt.max_steps, cap, dev)
+        self.nears, self.fars = torch.empty(N, **f32), torch.empty(N, **f32)
+        self.enc = torch.empty(self.L, cap, 2, **f32)
+        self.denc = torch.empty(self.L, cap, 2, **f32)
+        self.x01 = torch.empty(cap, 3, **f32)
+        self.sigma, self.rgb = torch.empty(cap, **f32), torch.empty(cap, 3, **f32)
+        self.dsigma, self.drgb = torch.empty(cap, **f32), torch.empty(cap, 3, **f32)
+        self.weights_buf = torch.empty(cap, **f32)
+        self.ws, self.depth, self.image = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, 3, **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.mlp_image = torch.empty(mb.image_bytes(), dtype=torch.uint8, device=dev)
+        self.ws_grid = torch.empty(gb.backward_workspace_bytes(cap, self.L, self.rows), dtype=torch.uint8, device=dev)
+        self.global_step = 0
+        self.samples_seen = torch.zeros(1, dtype=torch.int64, device=dev)     # running total, never read per step
+        self.ray_gen = torch.Generator(device=dev).manual_seed(seed * 1000 + self.rank)
+        self.last_loss = None
+        if self.world_size > 1:
+            parallel.broadcast_module(self.model)
+
+    # ------------------------------------------------------------------ pieces
+    def lr(self):
+        return self.lr0 * 0.1 ** min(self.global_step / self.opt.iters, 1)
+
+    def _bg(self, n):
+        mode = self.opt.background
+        if mode == "random":
+            return torch.rand(n, 3, device=self.device, generator=self.ray_gen), 0.0
+        return None, (1.0 if mode in ("white", "last_sample") else 0.0)
+
+    def forward_backward(self, rays_o, rays_d, gt_rgba, noises, bg_rgb=None, bg_const=0.0):
+        """march -> encode -> MLP -> composite -> loss -> backward into self.table_grad / self.w_grad."""
+        opt, m, ar, N, cap = self.opt, self.model, self.arena, self.N, self.cap
+        cnt = ar.counter
+        eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train, N, m.min_near, self.nears, self.fars)
+        rb.march_rays_train_arena(rays_o, rays_d, None, m.density_bitfield, m.real_bound, opt.contract, opt.dt_gamma,
+                                  opt.max_steps, N, m.cascade, m.grid_size, self.nears, self.fars, noises, ar.t_scratch,
+                                  cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, cnt, None)
+        eb.grid_encode_forward_slab(ar.xyzs, m.bound, self.table, m.grid_encoder.offsets, self.enc, self.x01, cnt, cap,
+                                    cap, self.L, self.L, self.S, self.H)
+        mb.prepare(self.weights, self.mlp_image)
+        mb.forward(self.enc, cap, ar.dirs, cnt, cap, self.mlp_image, self.sigma, self.rgb)
+        eb.composite_rays_train_forward(self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.weights_buf,
+                                        self.ws, self.depth, self.image)
+        self.loss.zero_()
+        eb.composite_mse_backward(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, self.ws, self.depth,
+                                  self.image, cap, N, opt.T_thresh, self.dsigma, self.drgb, self.loss)
+        mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap, self.mlp_image, opt.loss_scale, self.denc,
+                    self.dws)
+        gb.grid_backward_binned(self.denc, self.x01, m.grid_encoder.offsets, self.table_grad, cnt, cap, cap, self.L,
+                                self.L, self.S, self.H, self.ws_grid)
+
+    def optimizer_step(self):
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.table_grad)
+            torch.distributed.all_reduce(self.w_grad)
+            self.table_grad.div_(self.world_size)
+            self.w_grad.div_(self.world_size)
+        if self.opt.lambda_tv > 0:
+            self.model.grid_encoder.embeddings.grad = self.table_grad
+            self.model.apply_total_variation(self.opt.lambda_tv)
+        if self.opt.lambda_wd > 0:
+            self.model.grid_encoder.embeddings.grad = self.table_grad
+            self.model.apply_weight_decay(self.opt.lambda_wd)
+        step, lr = self.global_step + 1, self.lr()
+        eb.adam_step(self.table, self.table_grad, self.t_m, self.t_v, lr, *self.betas, self.eps, step, zero_grad=True)
+        eb.adam_step(self.w_flat, self.w_grad, self.w_m, self.w_v, lr, *self.betas, self.eps, step, zero_grad=False)
+
+    # ------------------------------------------------------------------ one optimiser step
+    def train_step(self, batch=None, noises=None):
+        opt, model = self.opt, self.model
+        model.train()
+        if self.global_step % opt.update_extra_interval == 0:
+            if self.world_size > 1:
+                torch.manual_seed(1234567 + self.global_step)
+            model.update_extra_state()
+        if batch is None:
+            batch = self.data.sample_rays(self.N, self.ray_gen)
+        gt = batch["images"]
+        if gt.shape[-1] == 3:
+            gt = torch.cat([gt, torch.ones_like(gt[:, :1])], -1)
+        bg_rgb, bg_const = self._bg(self.N)
+        if noises is None:
+            noises = torch.rand(self.N, device=self.device, generator=self.ray_gen)
+        self.forward_backward(batch["rays_o"].contiguous(), batch["rays_d"].contiguous(), gt.contiguous(), noises,
+                              bg_rgb, bg_const)
+        self.optimizer_step()
+        self.samples_seen += self.arena.counter[:1]
+        self.global_step += 1
+        self.last_loss = self.loss
+        return self.loss
+
+    @property
+    def last_num_points(self):
+        return int(self.arena.counter[0])          # host read: only for logging
+
+    def train(self, steps, log_every=0):
+        for _ in range(steps):
+            self.train_step()
+            if log_every and self.rank == 0 and self.global_step % log_every == 0:
+                needed = int(self.arena.counter[1])
+                print(f"[step {self.global_step}] loss {float(self.loss):.5f} samples {self.last_num_points}"
+                      + (f" (ARENA OVERFLOW: {needed} > {self.cap})" if needed > self.cap else ""), flush=True)
+
+    @torch.no_grad()
+    def evaluate(self, dataset, max_views=None, chunk=1 << 16):
+        from .trainer import Trainer
+        return Trainer.evaluate(self, dataset, max_views, chunk)

@@ -1,0 +1,191 @@
+"""Kernels of the fused training step (csrc/engine_kernels.hip) and the step itself (nerf/engine.py).
+
+Each kernel is checked against the CPU oracle (or the reference-generated fixture / torch for the pieces the
+reference does in torch); the whole step is checked against the per-op autograd path on identical rays."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_oracle_raymarching import synth_samples  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from raw_ngp_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def test_near_far_v2_matches_reference_fixture(lib, golden_dir):
+    g = np.load(os.path.join(golden_dir, "near_far_torch.npz"))
+    N = g["rays_o"].shape[0]
+    nears, fars = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    lib.engine_backend.near_far_from_aabb_v2(dev(g["rays_o"]), dev(g["rays_d"]), dev(g["aabb"]), N, float(g["min_near"]),
+                                             nears, fars)
+    # same IEEE operations as the torch function the reference calls (renderer.py:139-158)
+    np.testing.assert_array_equal(host(nears), g["nears"][:, 0])
+    np.testing.assert_array_equal(host(fars), g["fars"][:, 0])
+
+
+def test_grid_forward_slab_matches_oracle(lib, orc):
+    rng = np.random.default_rng(0)
+    B, cap, L, H = 5000, 6000, 16, 16
+    bound = 2.0
+    offsets, scale = orc.grid_offsets(desired_resolution=2048 * bound)
+    S = float(np.log2(scale))
+    table = rng.uniform(-1, 1, (offsets[-1], 2)).astype(np.float32)
+    xyz = rng.uniform(-bound * 1.02, bound * 1.02, (cap, 3)).astype(np.float32)
+    x01 = ((xyz + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)
+    ref, _ = orc.grid_encode_forward(x01[:B], table, offsets, B, 3, 2, L, L, S, H)
+    out = torch.full((L, cap, 2), 7.0, device="cuda")
+    inp = torch.full((cap, 3), 7.0, device="cuda")
+    cnt = torch.tensor([B, 0], dtype=torch.int32, device="cuda")
+    lib.engine_backend.grid_encode_forward_slab(dev(xyz), bound, dev(table), dev(offsets), out, inp, cnt, cap, cap, L, L, S, H)
+    np.testing.assert_allclose(host(out)[:, :B], ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(host(inp)[:B], x01[:B])
+    assert torch.all(out[:, B:] == 7.0) and torch.all(inp[B:] == 7.0)
+
+
+@pytest.mark.parametrize("T_thresh", [0.0, 1e-8, 1e-4])
+def test_wave_compositing_matches_oracle(lib, orc, T_thresh):
+    rng = np.random.default_rng(11)
+    N = 3000
+    sig, rgb, ts, rays, M = synth_samples(rng, N, max_cnt=300)
+    rays[5] = [M - 3, 10]          # overflowing ray -> ignored
+    rw, rws, rdep, rimg = orc.composite_rays_train_forward(sig, rgb, ts, rays, M, N, T_thresh)
+    w = torch.full((M,), 7.0, device="cuda")
+    ws, dep, img = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 3, device="cuda")
+    e = lib.engine_backend
+    e.composite_rays_train_forward(dev(sig), dev(rgb), dev(ts), dev(rays), M, N, T_thresh, w, ws, dep, img)
+    tol = dict(rtol=3e-4, atol=3e-6 + 2 * T_thresh)      # prefix products instead of the serial walk, __expf
+    live = np.ones(M, bool)
+    live[M - 3:] = rays[5, 0] + np.arange(3) >= M          # samples only the overflowing ray refers to
+    covered = np.zeros(M, bool)
+    for n in range(N):
+        if rays[n, 1] and rays[n, 0] + rays[n, 1] <= M:
+            covered[rays[n, 0]:rays[n, 0] + rays[n, 1]] = True
+    np.testing.assert_allclose(host(w)[covered], rw[covered], **tol)
+    np.testing.assert_allclose(host(ws), rws, **tol)
+    np.testing.assert_allclose(host(dep), rdep, rtol=3e-4, atol=2e-5 + 8 * T_thresh)
+    np.testing.assert_allclose(host(img), rimg, **tol)
+
+    gw = rng.normal(size=M).astype(np.float32)
+    gws = rng.normal(size=N).astype(np.float32)
+    gdep = rng.normal(size=N).astype(np.float32)
+    gimg = rng.normal(size=(N, 3)).astype(np.float32)
+    rgs, rgc = orc.composite_rays_train_backward(gw, gws, gdep, gimg, sig, rgb, ts, rays, rws, rdep, rimg, M, N, T_thresh)
+    gs, gc = torch.full((M,), 7.0, device="cuda"), torch.full((M, 3), 7.0, device="cuda")
+    e.composite_rays_train_backward(dev(gw), dev(gws), dev(gdep), dev(gimg), dev(sig), dev(rgb), dev(ts), dev(rays),
+                                    dev(rws), dev(rdep), dev(rimg), M, N, T_thresh, gs, gc)
+    np.testing.assert_allclose(host(gc)[covered], rgc[covered], rtol=3e-4, atol=1e-5 + 8 * T_thresh)
+    err = np.abs(host(gs) - rgs)[covered]
+    assert np.all(err <= 3e-3 * np.abs(rgs[covered]) + 1e-3 * np.abs(ts[covered, 1]) * 50 + 1e-6)
+
+
+def test_mse_backward_matches_autograd(lib, orc):
+    rng = np.random.default_rng(12)
+    N = 1500
+    sig, rgb, ts, rays, M = synth_samples(rng, N)
+    gt = rng.uniform(0, 1, (N, 4)).astype(np.float32)
+    bg = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+    e = lib.engine_backend
+    from raw_ngp_amd import raymarching
+    tsig, trgb = dev(sig).requires_grad_(True), dev(rgb).requires_grad_(True)
+    w, ws, dep, img = raymarching.composite_rays_train(tsig, trgb, dev(ts), dev(rays), 1e-4)
+    pred = img + (1 - ws).unsqueeze(-1) * dev(bg)
+    tgt = dev(gt)[:, :3] * dev(gt)[:, 3:] + dev(bg) * (1 - dev(gt)[:, 3:])
+    loss = ((pred - tgt) ** 2).mean(-1).mean()
+    loss.backward()
+    gs, gc = torch.empty(M, device="cuda"), torch.empty(M, 3, device="cuda")
+    lo = torch.zeros(1, device="cuda")
+    e.composite_mse_backward(dev(gt), dev(bg), 0.0, tsig.detach(), trgb.detach(), dev(ts), dev(rays), ws.detach(),
+                             dep.detach(), img.detach(), M, N, 1e-4, gs, gc, lo)
+    np.testing.assert_allclose(float(lo), float(loss), rtol=1e-5)
+    covered = np.zeros(M, bool)
+    for n in range(N):
+        covered[rays[n, 0]:rays[n, 0] + rays[n, 1]] = True
+    np.testing.assert_allclose(host(gc)[covered], host(trgb.grad)[covered], rtol=1e-3, atol=1e-8)
+    ref = host(tsig.grad)[covered]
+    assert np.all(np.abs(host(gs)[covered] - ref) <= 3e-3 * np.abs(ref) + 1e-7)
+
+
+def test_adam_matches_torch(lib):
+    torch.manual_seed(0)
+    n = 100003                                   # exercises the scalar tail
+    p0 = torch.randn(n, device="cuda")
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-2, eps=1e-15)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        g = torch.randn(n, device="cuda") * (10.0 ** -step)
+        g[::3] = 0.0
+        lr = 1e-2 * 0.9 ** step
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        ref.grad = g.clone()
+        opt.step()
+        gg = g.clone()
+        lib.engine_backend.adam_step(p, gg, m, v, lr, 0.9, 0.999, 1e-15, step, zero_grad=(step % 2 == 0))
+        assert torch.all(gg == 0) if step % 2 == 0 else torch.equal(gg, g)
+        np.testing.assert_allclose(host(p), host(ref), rtol=2e-6, atol=1e-7)
+
+
+def test_fused_step_matches_autograd_path(lib):
+    """Same rays, no jitter: loss and gradients of the fused step vs the per-op autograd path (both with the
+    fused MLP; differences: wave vs serial compositing, fused loss)."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=1024, iters=100, fused_mlp=True)
+    data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=4, H=64, W=64)
+    model = NeRFNetwork(opt).cuda()
+    with torch.no_grad():                                     # make the field non-trivial
+        model.grid_encoder.embeddings.uniform_(-0.5, 0.5)
+    eng = FusedTrainer(opt, model, data, device="cuda", capacity=1024 * 256)
+    model.train()
+    model.update_extra_state()
+    batch = data.sample_rays(opt.num_rays, torch.Generator(device="cuda").manual_seed(1))
+    gt = batch["images"]
+    eng.forward_backward(batch["rays_o"].contiguous(), batch["rays_d"].contiguous(), gt.contiguous(),
+                         torch.zeros(opt.num_rays, device="cuda"))
+    M = int(eng.arena.counter[0])
+    assert 0 < M <= eng.cap and int(eng.arena.counter[1]) == M
+
+    model.zero_grad()
+    out = model.render(batch["rays_o"], batch["rays_d"], bg_color=0, perturb=False)
+    assert out["num_points"] == M
+    tgt = gt[:, :3] * gt[:, 3:]
+    loss = ((out["image"] - tgt) ** 2).mean(-1).mean()
+    loss.backward()
+    np.testing.assert_allclose(float(eng.loss), float(loss), rtol=2e-4)
+    ref_t = model.grid_encoder.embeddings.grad
+    ref_w = torch.cat([l.weight.grad.reshape(-1) for l in list(model.grid_mlp.net) + list(model.view_mlp.net)])
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-30))
+    assert rel(eng.table_grad, ref_t) < 2e-3
+    assert rel(eng.w_grad, ref_w) < 2e-3
+    # and the step itself moves the parameters like torch.optim.Adam does
+    p_before = eng.table.clone()
+    eng.optimizer_step()
+    ref_p = torch.nn.Parameter(p_before.clone())
+    ref_p.grad = ref_t.clone()
+    torch.optim.Adam([ref_p], lr=eng.lr(), eps=1e-15).step()
+    changed = ref_t != 0
+    np.testing.assert_allclose(host(eng.table[changed]), host(ref_p.detach()[changed]), rtol=0, atol=2.1 * eng.lr())
+    assert float((eng.table - ref_p.detach()).abs().mean()) < 0.05 * eng.lr()
+    assert torch.all(eng.table_grad == 0)

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Summarise the LAST `--steps` training steps of a rocprofv3 --kernel-trace CSV: per kernel name the
+launches per step and the average duration, i.e. the steady-state profile without the burn-in.
+Usage: python tools/trace_tail.py <kernel_trace.csv> --anchor composite_train_forward --steps 100 [--out summary.csv]"""
+import argparse
+import collections
+import csv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--anchor", default="composite_train_forward", help="kernel launched exactly once per step")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    rows = []
+    with open(args.trace) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    anchors = [i for i, r in enumerate(rows) if args.anchor in r[2]]
+    if len(anchors) <= args.steps:
+        raise SystemExit("not enough steps in the trace")
+    first = anchors[-args.steps - 1]
+    last = anchors[-1]
+    sel = rows[first:last]
+    agg = collections.defaultdict(lambda: [0, 0])
+    for s, e, n in sel:
+        agg[n][0] += 1
+        agg[n][1] += e - s
+    wall = (rows[last][0] - rows[first][0]) / args.steps / 1e3
+    busy = sum(v[1] for v in agg.values()) / args.steps / 1e3
+    out = [("kernel", "launches_per_step", "avg_us", "us_per_step")]
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        out.append((n[:110], round(c / args.steps, 2), round(t / c / 1e3, 2), round(t / args.steps / 1e3, 2)))
+    print(f"steps {args.steps}: wall {wall:.1f} us/step, kernel-busy {busy:.1f} us/step, "
+          f"{sum(v[0] for v in agg.values()) / args.steps:.0f} launches/step")
+    for row in out[:40]:
+        print(*row, sep=" | ")
+    if args.out:
+        with open(args.out, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow([f"# last {args.steps} steps: wall {wall:.1f} us/step, kernel-busy {busy:.1f} us/step"])
+            w.writerows(out)
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raw_ngp_amd.nerf.network import NeRFNetwork  # noqa: E402
 from raw_ngp_amd.nerf.options import Options  # noqa: E402
 from raw_ngp_amd.nerf.scene import SyntheticDataset  # noqa: E402
+from raw_ngp_amd.nerf.engine import FusedTrainer  # noqa: E402
 from raw_ngp_amd.nerf.trainer import Trainer  # noqa: E402
 
 
@@ -27,6 +28,7 @@ def main():
     ap.add_argument("--fp16", action="store_true")
     ap.add_argument("--fused-mlp", action="store_true")
     ap.add_argument("--arena", type=int, default=0)
+    ap.add_argument("--engine", action="store_true", help="fused training step (nerf/engine.py)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -37,7 +39,8 @@ def main():
     val = SyntheticDataset(opt, dev, "val", n_views=args.val_views, H=args.res, W=args.res)
     print(f"scene rendered in {time.time() - t0:.1f}s", flush=True)
     model = NeRFNetwork(opt)
-    trainer = Trainer(opt, model, data, device=dev)
+    trainer = FusedTrainer(opt, model, data, device=dev, capacity=args.arena or args.rays * 160) if args.engine \
+        else Trainer(opt, model, data, device=dev)
     hist = []
     done = 0
     while done < args.iters:
