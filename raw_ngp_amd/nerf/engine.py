@@ -25,6 +25,22 @@ from .._lib import mlp_backend as mb
 from .._lib import raymarching_backend as rb
 
 
+class _Slot:
+    """One ray batch and everything derived from it before the field is evaluated."""
+
+    def __init__(self, N, max_steps, cap, dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.arena = raymarching.MarchArena(N, max_steps, cap, dev)
+        self.rays_o, self.rays_d = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32)
+        self.gt, self.bg = torch.empty(N, 4, **f32), torch.empty(N, 3, **f32)
+        self.noises = torch.empty(N, **f32)
+        self.nears, self.fars = torch.empty(N, **f32), torch.empty(N, **f32)
+        self.step = -1
+        if dev.type == "cuda":
+            self.ready, self.free = torch.cuda.Event(), torch.cuda.Event()
+            self.free.record()
+
+
 class FusedTrainer:
     """Drop-in for Trainer.train_step / train on models that satisfy NeRFNetwork._fused()."""
 
@@ -63,8 +79,13 @@ class FusedTrainer:
         self.w_m, self.w_v = torch.zeros_like(self.w_flat), torch.zeros_like(self.w_flat)
         self.table_grad = torch.zeros_like(self.table)
         # per-ray and per-sample buffers
-        self.arena = raymarching.MarchArena(N, opt.max_steps, cap, dev)
-        self.nears, self.fars = torch.empty(N, **f32), torch.empty(N, **f32)
+        # two ray-batch slots: while step i trains out of one, step i+1's rays are drawn and marched into the
+        # other on a second stream (the march is a long, narrow kernel -- 64 waves -- that hides under backward)
+        self.prefetch = bool(getattr(opt, "prefetch_march", True)) and dev.type == "cuda"
+        self.slots = [_Slot(N, opt.max_steps, cap, dev) for _ in range(2 if self.prefetch else 1)]
+        self.arena = self.slots[0].arena
+        self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
+        self.ev_params = torch.cuda.Event() if self.prefetch else None
         self.enc = torch.empty(self.L, cap, 2, **f32)
         self.denc = torch.empty(self.L, cap, 2, **f32)
         self.x01 = torch.empty(cap, 3, **f32)
@@ -86,20 +107,24 @@ class FusedTrainer:
     def lr(self):
         return self.lr0 * 0.1 ** min(self.global_step / self.opt.iters, 1)
 
-    def _bg(self, n):
-        mode = self.opt.background
-        if mode == "random":
-            return torch.rand(n, 3, device=self.device, generator=self.ray_gen), 0.0
-        return None, (1.0 if mode in ("white", "last_sample") else 0.0)
+    def march(self, slot, rays_o, rays_d, noises):
+        """rays -> sample arena of `slot` (near/far, count, scan, expand); runs on the current stream."""
+        opt, m, ar, N = self.opt, self.model, slot.arena, self.N
+        eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train, N, m.min_near, slot.nears, slot.fars)
+        rb.march_rays_train_arena(rays_o, rays_d, None, m.density_bitfield, m.real_bound, opt.contract, opt.dt_gamma,
+                                  opt.max_steps, N, m.cascade, m.grid_size, slot.nears, slot.fars, noises, ar.t_scratch,
+                                  self.cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None)
 
     def forward_backward(self, rays_o, rays_d, gt_rgba, noises, bg_rgb=None, bg_const=0.0):
         """march -> encode -> MLP -> composite -> loss -> backward into self.table_grad / self.w_grad."""
-        opt, m, ar, N, cap = self.opt, self.model, self.arena, self.N, self.cap
+        slot = self.slots[0]
+        self.march(slot, rays_o, rays_d, noises)
+        self.field_forward_backward(slot, gt_rgba, bg_rgb, bg_const)
+
+    def field_forward_backward(self, slot, gt_rgba, bg_rgb=None, bg_const=0.0):
+        opt, m, ar, N, cap = self.opt, self.model, slot.arena, self.N, self.cap
+        self.arena = ar
         cnt = ar.counter
-        eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train, N, m.min_near, self.nears, self.fars)
-        rb.march_rays_train_arena(rays_o, rays_d, None, m.density_bitfield, m.real_bound, opt.contract, opt.dt_gamma,
-                                  opt.max_steps, N, m.cascade, m.grid_size, self.nears, self.fars, noises, ar.t_scratch,
-                                  cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, cnt, None)
         eb.grid_encode_forward_slab(ar.xyzs, m.bound, self.table, m.grid_encoder.offsets, self.enc, self.x01, cnt, cap,
                                     cap, self.L, self.L, self.S, self.H)
         mb.prepare(self.weights, self.mlp_image)
@@ -131,25 +156,65 @@ class FusedTrainer:
         eb.adam_step(self.w_flat, self.w_grad, self.w_m, self.w_v, lr, *self.betas, self.eps, step, zero_grad=False)
 
     # ------------------------------------------------------------------ one optimiser step
-    def train_step(self, batch=None, noises=None):
-        opt, model = self.opt, self.model
-        model.train()
-        if self.global_step % opt.update_extra_interval == 0:
-            if self.world_size > 1:
-                torch.manual_seed(1234567 + self.global_step)
-            model.update_extra_state()
+    def _load_slot(self, slot, step, batch=None, noises=None):
+        """Draw (or take) the ray batch of `step`, copy it into the slot's buffers and march it -- on the
+        current stream.  The slot's buffers are fixed allocations, so nothing here outlives its stream."""
         if batch is None:
             batch = self.data.sample_rays(self.N, self.ray_gen)
         gt = batch["images"]
+        slot.gt[:, :gt.shape[-1]].copy_(gt)
         if gt.shape[-1] == 3:
-            gt = torch.cat([gt, torch.ones_like(gt[:, :1])], -1)
-        bg_rgb, bg_const = self._bg(self.N)
+            slot.gt[:, 3] = 1.0
+        slot.rays_o.copy_(batch["rays_o"])
+        slot.rays_d.copy_(batch["rays_d"])
+        if self.opt.background == "random":
+            torch.rand(slot.bg.shape, out=slot.bg, generator=self.ray_gen)
         if noises is None:
-            noises = torch.rand(self.N, device=self.device, generator=self.ray_gen)
-        self.forward_backward(batch["rays_o"].contiguous(), batch["rays_d"].contiguous(), gt.contiguous(), noises,
-                              bg_rgb, bg_const)
+            torch.rand(slot.noises.shape, out=slot.noises, generator=self.ray_gen)
+        else:
+            slot.noises.copy_(noises)
+        self.march(slot, slot.rays_o, slot.rays_d, slot.noises)
+        slot.step = step
+
+    def _prefetch(self, step):
+        """Queue step `step`'s rays + march on the side stream, behind (a) everything the main stream has queued
+        up to now that it could depend on -- the occupancy bitfield -- and (b) the slot's previous user."""
+        slot = self.slots[step % 2]
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_params)
+            self.side.wait_event(slot.free)
+            self._load_slot(slot, step)
+            slot.ready.record(self.side)
+
+    def train_step(self, batch=None, noises=None):
+        opt, model = self.opt, self.model
+        model.train()
+        step = self.global_step
+        if step % opt.update_extra_interval == 0:
+            if self.world_size > 1:
+                torch.manual_seed(1234567 + step)
+            model.update_extra_state()
+        main = torch.cuda.current_stream(self.device) if self.prefetch else None
+        if self.prefetch and batch is None:
+            slot = self.slots[step % 2]
+            self.ev_params.record(main)                 # the bitfield is final for this step and the next
+            if slot.step != step:                       # first step, or the step of a bitfield refresh
+                self._prefetch(step)
+            main.wait_event(slot.ready)
+        else:
+            slot = self.slots[0]
+            if self.prefetch:
+                main.wait_stream(self.side)             # an earlier prefetch may still be writing the slot
+            self._load_slot(slot, step, batch, noises)
+        bg_const = 1.0 if opt.background in ("white", "last_sample") else 0.0
+        self.field_forward_backward(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const)
+        self.samples_seen += slot.arena.counter[:1]
+        if self.prefetch:
+            slot.free.record(main)
+            nxt = step + 1
+            if batch is None and nxt % opt.update_extra_interval != 0:
+                self._prefetch(nxt)                     # overlaps this step's backward + optimiser
         self.optimizer_step()
-        self.samples_seen += self.arena.counter[:1]
         self.global_step += 1
         self.last_loss = self.loss
         return self.loss

@@ -57,3 +57,4 @@ class Options:
     fused_mlp: bool = False       # hand-written MFMA tiny-MLP instead of nn.Linear stacks
     loss_scale: float = 1024.0    # static loss scale of the fused MLP backward (f16 deltas)
     arena_capacity: int = 0       # > 0: sample arena (no host sync per step); 0 = reference 2-pass protocol
+    prefetch_march: bool = True   # fused engine: march step i+1's rays on a second stream during step i's backward
