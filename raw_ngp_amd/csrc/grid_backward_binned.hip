@@ -115,6 +115,52 @@ __device__ __forceinline__ bool corner_rows(const float *__restrict__ inputs, ui
     return true;
 }
 
+// ------------------------------------------------------------------ run merging
+// Samples are ray-ordered, so up to level ~10 consecutive samples fall into the same cell and would emit records
+// for the same 8 rows.  Inside each row of 16 lanes (DPP reach: no LDS traffic) consecutive lanes with the same
+// cell form a run; the run's contributions are summed with a segmented scan and only its last lane emits records.
+// At 4096 rays x ~70 samples this halves the record count and removes the same-address pile-ups of the coarse levels
+// in the LDS histogram and in the reduce kernel's ds_add_u64.  Count and fill use the same lane <-> sample mapping
+// (tiles start at multiples of 16), hence see the same runs.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, 0xf, 0xf, false);
+}
+template <int N>
+__device__ __forceinline__ float row_shr_f(float x)   // lane i <- lane i - N of its 16-lane row, 0 if none
+{
+    return __uint_as_float(dpp_u32<0x110 | N>(0u, __float_as_uint(x)));
+}
+
+constexpr uint32_t kDeadKey = 0xffffffffu;
+__device__ __forceinline__ bool mergeable(const Geom<3> &g) { return g.res <= 1024u; }
+__device__ __forceinline__ uint32_t cell_key(const Cell<3> &cl) { return cl.c[0] | (cl.c[1] << 10) | (cl.c[2] << 20); }
+
+// must be called by all lanes of the wave.  dist = lanes back to the head of my run; returns "I am the run's tail"
+__device__ __forceinline__ bool run_shape(uint32_t key, bool live, uint32_t &dist)
+{
+    const uint32_t l16 = threadIdx.x & 15u;
+    const uint32_t prev = dpp_u32<0x111>(0xfffffffeu, key), next = dpp_u32<0x101>(0xfffffffeu, key);
+    uint32_t s = (l16 == 0u || prev != key) ? l16 : 0u;
+    s = max(s, dpp_u32<0x111>(0u, s));
+    s = max(s, dpp_u32<0x112>(0u, s));
+    s = max(s, dpp_u32<0x114>(0u, s));
+    s = max(s, dpp_u32<0x118>(0u, s));
+    dist = l16 - s;
+    return live && (l16 == 15u || next != key);
+}
+
+__device__ __forceinline__ float run_sum(float v, uint32_t dist)
+{
+    float t;
+    t = row_shr_f<1>(v); v += dist >= 1u ? t : 0.0f;
+    t = row_shr_f<2>(v); v += dist >= 2u ? t : 0.0f;
+    t = row_shr_f<4>(v); v += dist >= 4u ? t : 0.0f;
+    t = row_shr_f<8>(v); v += dist >= 8u ? t : 0.0f;
+    return v;
+}
+
 // ------------------------------------------------------------------ count
 __global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restrict__ inputs,
                                                           const int32_t *__restrict__ offsets,
@@ -133,13 +179,20 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restri
     const uint32_t nbins = w.chunk_base[level + 1] - first;
     for (uint32_t i = threadIdx.x; i < nbins; i += kBlock) hist[i] = 0;
     __syncthreads();
+    const bool merge = mergeable(g);
 #pragma unroll 2
     for (uint32_t k = 0; k < kCountTile / kBlock; k++) {
         const uint32_t b = b0 + k * kBlock + threadIdx.x;
-        if (b >= B) break;
+        if (b0 + k * kBlock >= B) break;                 // uniform
         Cell<3> cl;
         uint32_t rows[8];
-        if (!corner_rows(inputs, b, g, align_corners, interp, cl, rows)) continue;
+        const bool live = b < B && corner_rows(inputs, b, g, align_corners, interp, cl, rows);
+        bool emit = live;
+        if (merge) {
+            uint32_t dist;
+            emit = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
+        }
+        if (!emit) continue;
 #pragma unroll
         for (uint32_t corner = 0; corner < 8; corner++) atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
     }
@@ -229,19 +282,36 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     for (uint32_t i = threadIdx.x; i < nbins; i += kFillBlock) hist[i] = 0;
     __syncthreads();
 
-    constexpr uint32_t S = kFillTile / kFillBlock;   // samples per lane
-    uint32_t rows[S][8], pos[S][8];
-    Cell<3> cl[S];
-    bool live[S];
+    static_assert(kFillTile == kFillBlock, "one sample per lane");
+    const uint32_t b = b0 + threadIdx.x;
+    uint32_t rows[8], pos[8];
+    float vx[8], vy[8];
+    Cell<3> cl = {};
+    const bool live = b < B && corner_rows(inputs, b, g, align_corners, interp, cl, rows);
+    float2 gr = make_float2(0.0f, 0.0f);
+    if (live) gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * gstride + b];
+    bool nan = !(gr.x == gr.x && gr.y == gr.y);
 #pragma unroll
-    for (uint32_t k = 0; k < S; k++) {
-        const uint32_t b = b0 + k * kFillBlock + threadIdx.x;
-        live[k] = b < B && corner_rows(inputs, b, g, align_corners, interp, cl[k], rows[k]);
-        if (live[k]) {
+    for (uint32_t corner = 0; corner < 8; corner++) {
+        float wgt = 1.0f;
 #pragma unroll
-            for (uint32_t corner = 0; corner < 8; corner++)
-                pos[k][corner] = atomicAdd(&hist[rows[k][corner] >> kChunkShift], 1u);
+        for (uint32_t d = 0; d < 3; d++) wgt *= (corner & (1u << d)) ? cl.f[d] : 1.0f - cl.f[d];
+        vx[corner] = live ? wgt * gr.x : 0.0f;
+        vy[corner] = live ? wgt * gr.y : 0.0f;
+    }
+    bool emit = live;
+    if (mergeable(g)) {
+        uint32_t dist;
+        emit = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; corner++) {
+            vx[corner] = run_sum(vx[corner], dist);
+            vy[corner] = run_sum(vy[corner], dist);
         }
+    }
+    if (emit) {
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; corner++) pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
     }
     __syncthreads();
 
@@ -274,26 +344,18 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     for (uint32_t k = 0; k < kFillBlock / 64; k++) total += wave_tot[k];
 
     // stage the records sorted by chunk
-    float gmax = 0.0f;
-#pragma unroll
-    for (uint32_t k = 0; k < S; k++) {
-        if (!live[k]) continue;
-        const uint32_t b = b0 + k * kFillBlock + threadIdx.x;
-        const float2 gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * gstride + b];
-        gmax = fmaxf(gmax, fmaxf(fabsf(gr.x), fabsf(gr.y)));
-        if (!(gr.x == gr.x && gr.y == gr.y)) gmax = __uint_as_float(0x7f800000u);   // NaN -> inf
+    float gmax = nan ? __uint_as_float(0x7f800000u) : 0.0f;   // NaN -> inf
+    if (emit) {
 #pragma unroll
         for (uint32_t corner = 0; corner < 8; corner++) {
-            float wgt = 1.0f;
-#pragma unroll
-            for (uint32_t d = 0; d < 3; d++) wgt *= (corner & (1u << d)) ? cl[k].f[d] : 1.0f - cl[k].f[d];
-            const uint32_t bin = rows[k][corner] >> kChunkShift;
+            gmax = fmaxf(gmax, fmaxf(fabsf(vx[corner]), fabsf(vy[corner])));
+            const uint32_t bin = rows[corner] >> kChunkShift;
             uint4 r;
-            r.x = gbase[bin] + pos[k][corner];
-            r.y = rows[k][corner] & (kChunkRows - 1u);
-            r.z = __float_as_uint(wgt * gr.x);
-            r.w = __float_as_uint(wgt * gr.y);
-            stage[lbase[bin] + pos[k][corner]] = r;
+            r.x = gbase[bin] + pos[corner];
+            r.y = rows[corner] & (kChunkRows - 1u);
+            r.z = __float_as_uint(vx[corner]);
+            r.w = __float_as_uint(vy[corner]);
+            stage[lbase[bin] + pos[corner]] = r;
         }
     }
     // largest |gradient| of the call -> fixed-point scale of the reduce kernel; one word for the whole grid,
