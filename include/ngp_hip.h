@@ -262,8 +262,33 @@ int ngp_x_composite_mse_backward(const float *gt_rgba, const float *bg_rgb, floa
 
 /* One torch.optim.Adam step (no amsgrad, no weight decay; main.py:245 uses eps 1e-15) over a flat fp32
  * tensor in a single pass; `step` counts from 1; zero_grad != 0 clears `grad` afterwards. */
-int ngp_x_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr, float beta1,
-                    float beta2, float eps, uint32_t step, int zero_grad, ngp_stream_t stream);
+int ngp_x_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr, double beta1,
+                    double beta2, float eps, uint32_t step, int zero_grad, ngp_stream_t stream);
+
+/* Same update with {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)} read from `hyper` (device, written by
+ * ngp_x_schedule_step earlier on the stream): no host scalar changes between steps, so the launch can be replayed
+ * from a captured graph. */
+int ngp_x_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, const float *hyper,
+                        float beta1, float beta2, float eps, int zero_grad, ngp_stream_t stream);
+
+/* Device-side scheduler: t = step_counter[0] steps are done; writes hyper = {lr0 * 0.1^min(t/decay_steps, 1)
+ * (the LambdaLR of main.py:261), 1 - beta1^(t+1), 1/sqrt(1 - beta2^(t+1))} and increments the counter. */
+int ngp_x_schedule_step(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1,
+                        double beta2, ngp_stream_t stream);
+
+/* counter[0] += delta, stream-ordered. */
+int ngp_x_counter_add(uint32_t *counter, uint32_t delta, ngp_stream_t stream);
+
+/* Training-ray batch in one kernel: what the harness does with torch.randint + get_rays + an index gather
+ * (nerf/provider.py collate, nerf/train_utils.py:96-172, :492-506).  Ray n draws (view, pixel) with Philox4x32-10,
+ * counter (n, draw, 0, 0), key = seed: view = mulhi(r0, V), pixel = mulhi(r1, H*W); noise = 24 high bits of r2;
+ * bg_rgb from counter (n, draw, 1, 0).  `draw` is read from draw_dev[0] when draw_dev is not NULL.
+ * images [V,H,W,C] uint8 (C = 3 or 4, straight alpha), poses [V,4,4] camera-to-world; outputs rays_o/rays_d [N,3],
+ * gt_rgba [N,4] in [0,1] (alpha 1 when C = 3), optional noises [N], bg_rgb [N,3], index [N,2] = (view, pixel). */
+int ngp_x_sample_rays(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W, uint32_t C, const float *poses, float fx,
+                      float fy, float cx, float cy, uint32_t N, uint64_t seed, const uint32_t *draw_dev, uint32_t draw,
+                      float *rays_o, float *rays_d, float *gt_rgba, float *noises, float *bg_rgb, int32_t *index,
+                      ngp_stream_t stream);
 
 /* The slab test NeRFRenderer.run_cuda actually uses (the torch function, nerf/renderer.py:139-158, not the
  * CUDA kernel): divides by (d + 1e-15), marks a miss with near = far = 1e9. */

@@ -284,3 +284,53 @@ def march_rays_train_backward(grad_xyzs, grad_dirs, ts, rays, N, M):
     lib().orc_march_rays_train_backward(_p(grad_xyzs), _p(grad_dirs), _p(ts), _p(rays), c_u(N), c_u(M),
                                         _p(go), _p(gd))
     return go, gd
+
+
+# ----------------------------------------------------------------------------- ray batch sampling (engine extension)
+def philox4x32_10(counter, key):
+    """Philox4x32-10 of Salmon et al. (SC'11, Random123): counter [..., 4] uint32, key (k0, k1) -> [..., 4] uint32."""
+    c = np.array(counter, dtype=np.uint64).reshape(-1, 4).copy()
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = np.stack([hi1 ^ c[:, 1] ^ k0, lo1, hi0 ^ c[:, 3] ^ k1, lo0], 1)
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return c.astype(np.uint32).reshape(np.shape(counter))
+
+
+def sample_rays(images, poses, intrinsics, N, seed, draw):
+    """What ngp_x_sample_rays draws and builds: the harness' random (view, pixel) per ray, get_rays
+    (nerf/train_utils.py:96-172: pixel centre +0.5, -z forward, y flipped, unnormalised) and the target gather.
+    Returns dict(index [N,2], rays_o, rays_d, gt [N,4], noises [N], bg [N,3])."""
+    V, H, W, C = images.shape
+    fx, fy, cx, cy = [np.float32(v) for v in intrinsics]
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    n = np.arange(N, dtype=np.uint32)
+    ctr = np.stack([n, np.full(N, draw, np.uint32), np.zeros(N, np.uint32), np.zeros(N, np.uint32)], 1)
+    r = philox4x32_10(ctr, key).astype(np.uint64)
+    view = ((r[:, 0] * np.uint64(V)) >> np.uint64(32)).astype(np.int64)
+    pix = ((r[:, 1] * np.uint64(H * W)) >> np.uint64(32)).astype(np.int64)
+    j, i = pix // W, pix % W
+    f32 = np.float32
+    dx = (i.astype(f32) + f32(0.5) - cx) / fx
+    dy = -((j.astype(f32) + f32(0.5) - cy) / fy)
+    dz = np.full(N, -1.0, f32)
+    P = poses.astype(f32)[view]
+    rays_d = np.stack([(dx * P[:, k, 0] + dy * P[:, k, 1]) + dz * P[:, k, 2] for k in range(3)], 1).astype(f32)
+    rays_o = P[:, :3, 3].copy()
+    px = images.reshape(V, H * W, C)[view, pix].astype(f32) / f32(255)
+    gt = np.concatenate([px[:, :3], px[:, 3:4] if C == 4 else np.ones((N, 1), f32)], 1).astype(f32)
+    u01 = lambda x: (x >> np.uint64(8)).astype(f32) * f32(2.0 ** -24)
+    ctr[:, 2] = 1
+    q = philox4x32_10(ctr, key).astype(np.uint64)
+    return {"index": np.stack([view, pix], 1).astype(np.int32), "rays_o": rays_o, "rays_d": rays_d, "gt": gt,
+            "noises": u01(r[:, 2]), "bg": np.stack([u01(q[:, k]) for k in range(3)], 1)}
+
+
+def schedule(step_done, lr0, decay_steps, beta1, beta2):
+    """ngp_x_schedule_step: (lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)) for the step after `step_done` finished ones."""
+    t = step_done + 1
+    return (np.float32(lr0 * 0.1 ** min(step_done / decay_steps, 1.0)), np.float32(1 - beta1 ** t),
+            np.float32(1 / np.sqrt(1 - beta2 ** t)))

@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libngp_hip.so")
 
-_f, _u, _i, _p = ctypes.c_float, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p
+_f, _u, _i, _p, _d = ctypes.c_float, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
 
 # name -> argument ctypes (the trailing stream pointer is appended automatically)
 _SIGNATURES = {
@@ -51,8 +51,12 @@ _SIGNATURES = {
     "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
     "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
     "ngp_x_composite_mse_backward": [_p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p],
-    "ngp_x_adam_step": [_p, _p, _p, _p, ctypes.c_uint64, _f, _f, _f, _f, _u, _i],
+    "ngp_x_adam_step": [_p, _p, _p, _p, ctypes.c_uint64, _f, _d, _d, _f, _u, _i],
     "ngp_x_near_far_from_aabb_v2": [_p, _p, _p, _u, _f, _p, _p],
+    "ngp_x_adam_step_dev": [_p, _p, _p, _p, ctypes.c_uint64, _p, _f, _f, _f, _i],
+    "ngp_x_schedule_step": [_p, _p, _d, _d, _d, _d],
+    "ngp_x_counter_add": [_p, _u],
+    "ngp_x_sample_rays": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p],
     "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_march_rays_train_arena": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _u, _p, _p, _p,
                                      _p, _p, _p, _p],
@@ -92,7 +96,7 @@ def declared_symbols():
             "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes"] + list(_SIGNATURES)
 
 
-_DT = {"f": torch.float32, "i": torch.int32, "b": torch.uint8}
+_DT = {"f": torch.float32, "i": torch.int32, "b": torch.uint8, "u": torch.int32}   # counters: int32 storage
 
 
 def _ptr(t, kind, name, optional=False):
@@ -109,8 +113,10 @@ def _ptr(t, kind, name, optional=False):
     return t.data_ptr()
 
 
-# Optional per-kernel probe (bench.py): HIP events recorded on the launch stream around every call of ONE
-# C symbol, plus the value of one integer argument (the number of samples the launch processes).
+# Optional per-entry-point probe (bench.py): HIP events recorded on the launch stream around every call of ONE
+# C symbol, plus the value of one integer argument (the number of samples the launch processes).  Events cannot be
+# timed inside a captured graph, so the fused engine keeps the probed entry point out of its graphs (it asks
+# `probed_symbol()` when it captures).
 _probe = {"name": None, "arg": 0, "events": []}
 
 
@@ -118,8 +124,17 @@ def set_probe(name, units_arg=0):
     _probe["name"], _probe["arg"], _probe["events"] = name, units_arg, []
 
 
+def probed_symbol():
+    return _probe["name"]
+
+
+def probe_reset():
+    """Forget the measurements taken so far, keep probing."""
+    _probe["events"] = []
+
+
 def probe_results():
-    """(launches, total units, total seconds) of the probed symbol since set_probe()."""
+    """(launches, total units, total seconds) of the probed symbol since set_probe() / probe_reset()."""
     torch.cuda.synchronize()
     ev = _probe["events"]
     return len(ev), sum(u for _, _, u in ev), sum(a.elapsed_time(b) for a, b, _ in ev) * 1e-3
@@ -132,6 +147,8 @@ def _call(name, anchor, *args):
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
         if probing:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"{name} is being probed: it must not be captured into a graph")
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record(stream)
         rc = getattr(lib, name)(*args, stream.cuda_stream)
@@ -353,10 +370,17 @@ class _MlpBackend:
 
 
     @staticmethod
-    def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws):
-        """dws: six pre-allocated fp32 tensors shaped like the weights (overwritten)."""
+    def backward_workspace_bytes(M):
+        return int(load().ngp_x_mlp_backward_workspace_bytes(M))
+
+    @staticmethod
+    def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws, workspace=None):
+        """dws: six pre-allocated fp32 tensors shaped like the weights (overwritten).  workspace: uint8 tensor of
+        backward_workspace_bytes(M) (allocated per call when omitted)."""
         nbytes = load().ngp_x_mlp_backward_workspace_bytes(M)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+        ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+        if ws.numel() < nbytes or not ws.is_cuda:
+            raise RuntimeError("mlp backward: workspace too small")
         _call("ngp_x_mlp_backward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"),
               _ptr(dsigma, "f", "dsigma"), _ptr(drgb, "f", "drgb"), _ptr(M_dev, "i", "M_dev", True), M,
               image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"),
@@ -404,6 +428,34 @@ class _EngineBackend:
         _call("ngp_x_adam_step", param, _ptr(param, "f", "param"), _ptr(grad, "f", "grad"),
               _ptr(exp_avg, "f", "exp_avg"), _ptr(exp_avg_sq, "f", "exp_avg_sq"), param.numel(), float(lr),
               float(beta1), float(beta2), float(eps), int(step), int(bool(zero_grad)))
+
+    @staticmethod
+    def adam_step_dev(param, grad, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps, zero_grad=False):
+        _call("ngp_x_adam_step_dev", param, _ptr(param, "f", "param"), _ptr(grad, "f", "grad"),
+              _ptr(exp_avg, "f", "exp_avg"), _ptr(exp_avg_sq, "f", "exp_avg_sq"), param.numel(),
+              _ptr(hyper, "f", "hyper"), float(beta1), float(beta2), float(eps), int(bool(zero_grad)))
+
+    @staticmethod
+    def schedule_step(step_counter, hyper, lr0, decay_steps, beta1, beta2):
+        _call("ngp_x_schedule_step", hyper, _ptr(step_counter, "u", "step_counter"), _ptr(hyper, "f", "hyper"),
+              float(lr0), float(decay_steps), float(beta1), float(beta2))
+
+    @staticmethod
+    def counter_add(counter, delta=1):
+        _call("ngp_x_counter_add", counter, _ptr(counter, "u", "counter"), int(delta))
+
+    @staticmethod
+    def sample_rays(images, poses, intrinsics, N, seed, draw, rays_o, rays_d, gt_rgba, noises=None, bg_rgb=None,
+                    index=None):
+        """`draw`: int32 device tensor (read at run time) or a Python int."""
+        V, H, W, C = images.shape
+        fx, fy, cx, cy = [float(v) for v in intrinsics]
+        on_dev = torch.is_tensor(draw)
+        _call("ngp_x_sample_rays", images, _ptr(images, "b", "images"), V, H, W, C, _ptr(poses, "f", "poses"), fx, fy,
+              cx, cy, N, int(seed) & (2 ** 64 - 1), _ptr(draw, "u", "draw") if on_dev else None,
+              0 if on_dev else int(draw) & 0xffffffff, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
+              _ptr(gt_rgba, "f", "gt_rgba"), _ptr(noises, "f", "noises", True), _ptr(bg_rgb, "f", "bg_rgb", True),
+              _ptr(index, "i", "index", True))
 
     @staticmethod
     def near_far_from_aabb_v2(rays_o, rays_d, aabb, N, min_near, nears, fars):

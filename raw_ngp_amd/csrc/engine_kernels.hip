@@ -264,8 +264,13 @@ __global__ __launch_bounds__(256) void composite_backward_wave_kernel(
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *g, float *__restrict__ m,
                                                    float *__restrict__ v, size_t n4, size_t n, float lr, float b1,
                                                    float b2, float eps, float bc1, float rsqrt_bc2, bool zero_grad,
-                                                   float *g_mut)
+                                                   float *g_mut, const float *__restrict__ hyper)
 {
+    if (hyper) {   // {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)} written by schedule_kernel earlier on this stream
+        lr = hyper[0];
+        bc1 = hyper[1];
+        rsqrt_bc2 = hyper[2];
+    }
     const float step_size = lr / bc1;
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
     for (size_t i = tid; i < n4; i += nthreads) {
@@ -289,6 +294,82 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         v[i] = vi;
         p[i] -= step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + eps));
         if (zero_grad) g_mut[i] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------ step state on the device
+// The harness' scheduler (main.py:261: lr = lr0 * 0.1^min(step/iters, 1)) and Adam's bias corrections, kept on the
+// device so that a captured step never needs a host-supplied scalar.
+__global__ void schedule_kernel(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double b1, double b2)
+{
+    const uint32_t done = step_counter[0];
+    const double t = (double)done + 1.0;
+    const double frac = fmin((double)done / decay_steps, 1.0);
+    hyper[0] = (float)(lr0 * pow(0.1, frac));
+    hyper[1] = (float)(1.0 - pow(b1, t));
+    hyper[2] = (float)(1.0 / sqrt(1.0 - pow(b2, t)));
+    step_counter[0] = done + 1u;
+}
+
+__global__ void counter_add_kernel(uint32_t *counter, uint32_t delta) { counter[0] += delta; }
+
+// ------------------------------------------------------------------ ray batch sampling
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so a ray's draws depend only on (seed, draw number, ray).
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0;
+        c[1] = lo1;
+        c[2] = n2;
+        c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }   // [0,1), 24 bits
+
+// The random_image_batch collate + get_rays + target gather of the harness (nerf/provider.py, nerf/train_utils.py:96-172)
+// as one kernel: every ray draws its own (view, pixel), builds its origin / direction from that view's pose and
+// reads its target colour.  Pixel centre +0.5, camera looks down -z, y flipped, directions not normalised.
+__global__ __launch_bounds__(256) void sample_rays_kernel(
+    const uint8_t *__restrict__ images, uint32_t V, uint32_t H, uint32_t W, uint32_t C, const float *__restrict__ poses,
+    float fx, float fy, float cx, float cy, uint32_t N, uint32_t seed_lo, uint32_t seed_hi,
+    const uint32_t *__restrict__ draw_dev, uint32_t draw, float *__restrict__ rays_o, float *__restrict__ rays_d,
+    float *__restrict__ gt, float *__restrict__ noises, float *__restrict__ bg, int32_t *__restrict__ index)
+{
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    if (draw_dev) draw = draw_dev[0];
+    uint32_t r[4] = {n, draw, 0u, 0u};
+    philox4x32_10(r, seed_lo, seed_hi);
+    const uint32_t view = __umulhi(r[0], V), pix = __umulhi(r[1], H * W);
+    const uint32_t j = pix / W, i = pix - j * W;
+    const float dx = ((float)i + 0.5f - cx) / fx, dy = -(((float)j + 0.5f - cy) / fy), dz = -1.0f;
+    const float *P = poses + (size_t)view * 16;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        rays_d[(size_t)n * 3 + k] = dx * P[4 * k] + dy * P[4 * k + 1] + dz * P[4 * k + 2];
+        rays_o[(size_t)n * 3 + k] = P[4 * k + 3];
+    }
+    const uint8_t *px = images + ((size_t)view * H * W + pix) * C;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) gt[(size_t)n * 4 + k] = (float)px[k] / 255.0f;
+    gt[(size_t)n * 4 + 3] = C == 4 ? (float)px[3] / 255.0f : 1.0f;
+    if (noises) noises[n] = u01(r[2]);
+    if (bg) {
+        uint32_t q[4] = {n, draw, 1u, 0u};
+        philox4x32_10(q, seed_lo, seed_hi);
+#pragma unroll
+        for (int k = 0; k < 3; k++) bg[(size_t)n * 3 + k] = u01(q[k]);
+    }
+    if (index) {
+        index[2 * n] = (int32_t)view;
+        index[2 * n + 1] = (int32_t)pix;
     }
 }
 
@@ -387,20 +468,70 @@ extern "C" int ngp_x_composite_mse_backward(const float *gt_rgba, const float *b
 }
 
 extern "C" int ngp_x_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr,
-                               float beta1, float beta2, float eps, uint32_t step, int zero_grad, ngp_stream_t stream)
+                               double beta1, double beta2, float eps, uint32_t step, int zero_grad, ngp_stream_t stream)
 {
     if (n == 0) return NGP_OK;
     NGP_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adam_step: null tensor");
     NGP_REQUIRE(step >= 1, "adam_step: step counts from 1");
     NGP_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) == 0,
                 "adam_step: tensors must be 16-byte aligned");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     const size_t n4 = n / 4;
     const uint32_t blocks = (uint32_t)min((size_t)256 * 8, (n4 + 255) / 256 + 1);
-    adam_kernel<<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n4, n, lr, beta1, beta2,
-                                                                  eps, (float)bc1, (float)(1.0 / sqrt(bc2)), zero_grad != 0,
-                                                                  grad);
+    adam_kernel<<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n4, n, lr, (float)beta1,
+                                                                  (float)beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), zero_grad != 0,
+                                                                  grad, nullptr);
     NGP_CHECK_LAUNCH("adam_step");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n,
+                                   const float *hyper, float beta1, float beta2, float eps, int zero_grad,
+                                   ngp_stream_t stream)
+{
+    if (n == 0) return NGP_OK;
+    NGP_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper, "adam_step_dev: null tensor");
+    NGP_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) == 0,
+                "adam_step_dev: tensors must be 16-byte aligned");
+    const size_t n4 = n / 4;
+    const uint32_t blocks = (uint32_t)min((size_t)256 * 8, (n4 + 255) / 256 + 1);
+    adam_kernel<<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n4, n, 0.0f, beta1,
+                                                                  beta2, eps, 1.0f, 1.0f, zero_grad != 0, grad, hyper);
+    NGP_CHECK_LAUNCH("adam_step_dev");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_schedule_step(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1,
+                                   double beta2, ngp_stream_t stream)
+{
+    NGP_REQUIRE(step_counter && hyper, "schedule_step: null tensor");
+    NGP_REQUIRE(decay_steps > 0.0, "schedule_step: decay_steps must be positive");
+    schedule_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(step_counter, hyper, lr0, decay_steps, beta1, beta2);
+    NGP_CHECK_LAUNCH("schedule_step");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_counter_add(uint32_t *counter, uint32_t delta, ngp_stream_t stream)
+{
+    NGP_REQUIRE(counter, "counter_add: null tensor");
+    counter_add_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(counter, delta);
+    NGP_CHECK_LAUNCH("counter_add");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_sample_rays(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W, uint32_t C, const float *poses,
+                                 float fx, float fy, float cx, float cy, uint32_t N, uint64_t seed,
+                                 const uint32_t *draw_dev, uint32_t draw, float *rays_o, float *rays_d, float *gt_rgba,
+                                 float *noises, float *bg_rgb, int32_t *index, ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(images && poses && rays_o && rays_d && gt_rgba, "sample_rays: null tensor");
+    NGP_REQUIRE(V > 0 && H > 0 && W > 0 && (uint64_t)H * W < (1ull << 32), "sample_rays: bad image shape");
+    NGP_REQUIRE(C == 3 || C == 4, "sample_rays: images must be RGB or RGBA (uint8)");
+    sample_rays_kernel<<<dim3(ceil_div(N, 256u)), dim3(256), 0, as_stream(stream)>>>(
+        images, V, H, W, C, poses, fx, fy, cx, cy, N, (uint32_t)seed, (uint32_t)(seed >> 32), draw_dev, draw, rays_o, rays_d,
+        gt_rgba, noises, bg_rgb, index);
+    NGP_CHECK_LAUNCH("sample_rays");
     return NGP_OK;
 }
 

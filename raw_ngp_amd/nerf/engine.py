@@ -35,10 +35,7 @@ class _Slot:
         self.gt, self.bg = torch.empty(N, 4, **f32), torch.empty(N, 3, **f32)
         self.noises = torch.empty(N, **f32)
         self.nears, self.fars = torch.empty(N, **f32), torch.empty(N, **f32)
-        self.step = -1
-        if dev.type == "cuda":
-            self.ready, self.free = torch.cuda.Event(), torch.cuda.Event()
-            self.free.record()
+        self.step = -1                     # training step whose rays the slot holds
 
 
 class FusedTrainer:
@@ -85,7 +82,17 @@ class FusedTrainer:
         self.slots = [_Slot(N, opt.max_steps, cap, dev) for _ in range(2 if self.prefetch else 1)]
         self.arena = self.slots[0].arena
         self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
-        self.ev_params = torch.cuda.Event() if self.prefetch else None
+        # ray batches drawn on the device (one kernel, counter-based RNG) when the dataset keeps uint8 images there
+        imgs = getattr(dataset, "images", None)
+        self.device_sampler = bool(getattr(opt, "device_sampler", True)) and torch.is_tensor(imgs) \
+            and imgs.dtype == torch.uint8 and imgs.is_cuda and imgs.dim() == 4
+        self.seed64 = (seed * 1000 + self.rank) & (2 ** 64 - 1)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.draw_ctr, self.step_ctr = torch.zeros(1, **i32), torch.zeros(1, **i32)
+        self.hyper = torch.zeros(4, **f32)                  # {lr, 1 - b1^t, 1/sqrt(1 - b2^t)} of the current step
+        # the main stream's part of a step replayed from captured hipGraphs (one per ray slot)
+        self.use_graph = bool(getattr(opt, "capture_graph", True)) and opt.lambda_tv == 0 and dev.type == "cuda"
+        self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
         self.enc = torch.empty(self.L, cap, 2, **f32)
         self.denc = torch.empty(self.L, cap, 2, **f32)
         self.x01 = torch.empty(cap, 3, **f32)
@@ -95,10 +102,11 @@ class FusedTrainer:
         self.ws, self.depth, self.image = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, 3, **f32)
         self.loss = torch.zeros(1, **f32)
         self.mlp_image = torch.empty(mb.image_bytes(), dtype=torch.uint8, device=dev)
+        self.ws_mlp = torch.empty(mb.backward_workspace_bytes(cap), dtype=torch.uint8, device=dev)
         self.ws_grid = torch.empty(gb.backward_workspace_bytes(cap, self.L, self.rows), dtype=torch.uint8, device=dev)
         self.global_step = 0
         self.samples_seen = torch.zeros(1, dtype=torch.int64, device=dev)     # running total, never read per step
-        self.ray_gen = torch.Generator(device=dev).manual_seed(seed * 1000 + self.rank)
+        self.ray_gen = torch.Generator(device=dev).manual_seed(seed * 1000 + self.rank)   # torch sampling path
         self.last_loss = None
         if self.world_size > 1:
             parallel.broadcast_module(self.model)
@@ -122,69 +130,131 @@ class FusedTrainer:
         self.field_forward_backward(slot, gt_rgba, bg_rgb, bg_const)
 
     def field_forward_backward(self, slot, gt_rgba, bg_rgb=None, bg_const=0.0):
-        opt, m, ar, N, cap = self.opt, self.model, slot.arena, self.N, self.cap
-        self.arena = ar
-        cnt = ar.counter
-        eb.grid_encode_forward_slab(ar.xyzs, m.bound, self.table, m.grid_encoder.offsets, self.enc, self.x01, cnt, cap,
-                                    cap, self.L, self.L, self.S, self.H)
-        mb.prepare(self.weights, self.mlp_image)
-        mb.forward(self.enc, cap, ar.dirs, cnt, cap, self.mlp_image, self.sigma, self.rgb)
-        eb.composite_rays_train_forward(self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.weights_buf,
-                                        self.ws, self.depth, self.image)
-        self.loss.zero_()
-        eb.composite_mse_backward(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, self.ws, self.depth,
-                                  self.image, cap, N, opt.T_thresh, self.dsigma, self.drgb, self.loss)
-        mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap, self.mlp_image, opt.loss_scale, self.denc,
-                    self.dws)
-        gb.grid_backward_binned(self.denc, self.x01, m.grid_encoder.offsets, self.table_grad, cnt, cap, cap, self.L,
-                                self.L, self.S, self.H, self.ws_grid)
+        for _, op in self._field_ops(slot, gt_rgba, bg_rgb, bg_const):
+            op()
 
-    def optimizer_step(self):
+    def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const):
+        """The field part of the step as (C entry point, thunk) pairs, in launch order."""
+        opt, m, ar, N, cap = self.opt, self.model, slot.arena, self.N, self.cap
+        cnt, offsets = ar.counter, m.grid_encoder.offsets
+
+        def loss_and_composite_backward():
+            self.loss.zero_()
+            eb.composite_mse_backward(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, self.ws,
+                                      self.depth, self.image, cap, N, opt.T_thresh, self.dsigma, self.drgb, self.loss)
+
+        return [
+            ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
+                ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt, cap, cap, self.L, self.L, self.S, self.H)),
+            ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image)),
+            ("ngp_x_mlp_forward", lambda: mb.forward(self.enc, cap, ar.dirs, cnt, cap, self.mlp_image, self.sigma,
+                                                     self.rgb)),
+            ("ngp_x_composite_rays_train_forward", lambda: eb.composite_rays_train_forward(
+                self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.weights_buf, self.ws, self.depth,
+                self.image)),
+            ("ngp_x_composite_mse_backward", loss_and_composite_backward),
+            ("ngp_x_mlp_backward", lambda: mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap,
+                                                       self.mlp_image, opt.loss_scale, self.denc, self.dws, self.ws_mlp)),
+            ("ngp_x_grid_encode_backward_binned", lambda: gb.grid_backward_binned(
+                self.denc, self.x01, offsets, self.table_grad, cnt, cap, cap, self.L, self.L, self.S, self.H,
+                self.ws_grid)),
+        ]
+
+    def reduce_gradients(self):
         if self.world_size > 1:
             torch.distributed.all_reduce(self.table_grad)
             torch.distributed.all_reduce(self.w_grad)
             self.table_grad.div_(self.world_size)
             self.w_grad.div_(self.world_size)
+
+    def optimizer_step(self, device_hyper=False):
+        """Adam on the table and the MLP weights.  device_hyper: learning rate and bias corrections come from
+        self.hyper (written by schedule_step earlier in the step) instead of host scalars."""
         if self.opt.lambda_tv > 0:
             self.model.grid_encoder.embeddings.grad = self.table_grad
             self.model.apply_total_variation(self.opt.lambda_tv)
         if self.opt.lambda_wd > 0:
             self.model.grid_encoder.embeddings.grad = self.table_grad
             self.model.apply_weight_decay(self.opt.lambda_wd)
+        if device_hyper:
+            eb.adam_step_dev(self.table, self.table_grad, self.t_m, self.t_v, self.hyper, *self.betas, self.eps, True)
+            eb.adam_step_dev(self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps, False)
+            return
         step, lr = self.global_step + 1, self.lr()
         eb.adam_step(self.table, self.table_grad, self.t_m, self.t_v, lr, *self.betas, self.eps, step, zero_grad=True)
         eb.adam_step(self.w_flat, self.w_grad, self.w_m, self.w_v, lr, *self.betas, self.eps, step, zero_grad=False)
 
     # ------------------------------------------------------------------ one optimiser step
-    def _load_slot(self, slot, step, batch=None, noises=None):
-        """Draw (or take) the ray batch of `step`, copy it into the slot's buffers and march it -- on the
-        current stream.  The slot's buffers are fixed allocations, so nothing here outlives its stream."""
-        if batch is None:
-            batch = self.data.sample_rays(self.N, self.ray_gen)
-        gt = batch["images"]
-        slot.gt[:, :gt.shape[-1]].copy_(gt)
-        if gt.shape[-1] == 3:
-            slot.gt[:, 3] = 1.0
-        slot.rays_o.copy_(batch["rays_o"])
-        slot.rays_d.copy_(batch["rays_d"])
-        if self.opt.background == "random":
-            torch.rand(slot.bg.shape, out=slot.bg, generator=self.ray_gen)
-        if noises is None:
-            torch.rand(slot.noises.shape, out=slot.noises, generator=self.ray_gen)
+    def _load_slot(self, slot, batch=None, noises=None):
+        """Draw (or take) a ray batch into the slot's fixed buffers and march it, on the current stream."""
+        opt = self.opt
+        if batch is None and self.device_sampler:
+            d = self.data
+            eb.sample_rays(d.images, d.poses, d.intrinsics, self.N, self.seed64, self.draw_ctr, slot.rays_o, slot.rays_d,
+                           slot.gt, slot.noises, slot.bg if opt.background == "random" else None)
+            eb.counter_add(self.draw_ctr, 1)
         else:
-            slot.noises.copy_(noises)
+            if batch is None:
+                batch = self.data.sample_rays(self.N, self.ray_gen)
+            gt = batch["images"]
+            slot.gt[:, :gt.shape[-1]].copy_(gt)
+            if gt.shape[-1] == 3:
+                slot.gt[:, 3] = 1.0
+            slot.rays_o.copy_(batch["rays_o"])
+            slot.rays_d.copy_(batch["rays_d"])
+            if opt.background == "random":
+                torch.rand(slot.bg.shape, out=slot.bg, generator=self.ray_gen)
+            if noises is None:
+                torch.rand(slot.noises.shape, out=slot.noises, generator=self.ray_gen)
+            else:
+                slot.noises.copy_(noises)
         self.march(slot, slot.rays_o, slot.rays_d, slot.noises)
-        slot.step = step
 
-    def _prefetch(self, step):
-        """Queue step `step`'s rays + march on the side stream, behind (a) everything the main stream has queued
-        up to now that it could depend on -- the occupancy bitfield -- and (b) the slot's previous user."""
-        slot = self.slots[step % 2]
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev_params)
-            self.side.wait_event(slot.free)
-            self._load_slot(slot, step)
-            slot.ready.record(self.side)
+    def _step_ops(self, slot):
+        """Everything the main stream does in one step, as (name, thunk) pairs."""
+        opt = self.opt
+        bg_const = 1.0 if opt.background in ("white", "last_sample") else 0.0
+
+        def count_samples():
+            self.samples_seen += slot.arena.counter[:1]
+
+        ops = [("ngp_x_schedule_step", lambda: eb.schedule_step(self.step_ctr, self.hyper, self.lr0, float(opt.iters),
+                                                                 *self.betas))]
+        ops += self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const)
+        ops.append(("samples_seen", count_samples))
+        if self.world_size > 1:
+            ops.append(("all_reduce", self.reduce_gradients))
+        ops.append(("ngp_x_adam_step_dev", lambda: self.optimizer_step(device_hyper=True)))
+        return ops
+
+    def _capture(self, slot):
+        """The step as hipGraphs.  Two kinds of op stay outside: the gradient all-reduce (RCCL, under DP) and an
+        entry point bench.py is timing with HIP events (events inside a graph cannot be timed); the runs of ops
+        between them become one graph each."""
+        from .. import _lib
+        if self.graph_pool is None:
+            self.graph_pool = torch.cuda.graph_pool_handle()
+        eager = {"all_reduce", _lib.probed_symbol()}
+        parts, run = [], []
+
+        def flush():
+            if run:
+                g, ops = torch.cuda.CUDAGraph(), list(run)
+                with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
+                    for op in ops:
+                        op()
+                parts.append(g.replay)
+                self._graphs_alive.append(g)
+                run.clear()
+
+        for name, op in self._step_ops(slot):
+            if name in eager:
+                flush()
+                parts.append(op)
+            else:
+                run.append(op)
+        flush()
+        return parts
 
     def train_step(self, batch=None, noises=None):
         opt, model = self.opt, self.model
@@ -194,27 +264,34 @@ class FusedTrainer:
             if self.world_size > 1:
                 torch.manual_seed(1234567 + step)
             model.update_extra_state()
+        slot = self.slots[step % len(self.slots)]
+        if batch is not None or slot.step != step:      # explicit batch, first step, or just after a grid refresh
+            self._load_slot(slot, batch, noises)
+            slot.step = step
+        # the occupancy bitfield the next step marches through is final unless that step refreshes it first
+        ahead = self.prefetch and batch is None and (step + 1) % opt.update_extra_interval != 0
+        nxt = self.slots[(step + 1) % 2] if ahead else None
         main = torch.cuda.current_stream(self.device) if self.prefetch else None
-        if self.prefetch and batch is None:
-            slot = self.slots[step % 2]
-            self.ev_params.record(main)                 # the bitfield is final for this step and the next
-            if slot.step != step:                       # first step, or the step of a bitfield refresh
-                self._prefetch(step)
-            main.wait_event(slot.ready)
+        if nxt is not None:
+            # fork: the next step's rays are drawn and marched on the side stream, concurrently with everything
+            # this step does on the main stream (nxt's previous user, step - 1, is already behind this point)
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._load_slot(nxt)
+            nxt.step = step + 1
+        if self.use_graph and batch is None and step >= 2:      # the first steps run eagerly (lazy init, caches)
+            key = step % 2
+            if key not in self.graphs:
+                self.graphs[key] = self._capture(slot)
+            for part in self.graphs[key]:
+                part()
+            self.last_graph_key = key
         else:
-            slot = self.slots[0]
-            if self.prefetch:
-                main.wait_stream(self.side)             # an earlier prefetch may still be writing the slot
-            self._load_slot(slot, step, batch, noises)
-        bg_const = 1.0 if opt.background in ("white", "last_sample") else 0.0
-        self.field_forward_backward(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const)
-        self.samples_seen += slot.arena.counter[:1]
-        if self.prefetch:
-            slot.free.record(main)
-            nxt = step + 1
-            if batch is None and nxt % opt.update_extra_interval != 0:
-                self._prefetch(nxt)                     # overlaps this step's backward + optimiser
-        self.optimizer_step()
+            for _, op in self._step_ops(slot):
+                op()
+            self.last_graph_key = None
+        if nxt is not None:
+            main.wait_stream(self.side)                 # join
         self.global_step += 1
         self.last_loss = self.loss
         return self.loss

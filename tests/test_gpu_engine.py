@@ -139,7 +139,7 @@ def test_adam_matches_torch(lib):
         gg = g.clone()
         lib.engine_backend.adam_step(p, gg, m, v, lr, 0.9, 0.999, 1e-15, step, zero_grad=(step % 2 == 0))
         assert torch.all(gg == 0) if step % 2 == 0 else torch.equal(gg, g)
-        np.testing.assert_allclose(host(p), host(ref), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(host(p), host(ref), rtol=2e-6, atol=3e-7)
 
 
 def test_fused_step_matches_autograd_path(lib):
@@ -189,3 +189,79 @@ def test_fused_step_matches_autograd_path(lib):
     np.testing.assert_allclose(host(eng.table[changed]), host(ref_p.detach()[changed]), rtol=0, atol=2.1 * eng.lr())
     assert float((eng.table - ref_p.detach()).abs().mean()) < 0.05 * eng.lr()
     assert torch.all(eng.table_grad == 0)
+
+
+def test_sample_rays_matches_oracle(lib, orc):
+    rng = np.random.default_rng(3)
+    V, H, W, N = 7, 40, 52, 5000
+    images = rng.integers(0, 256, (V, H, W, 4), dtype=np.uint8)
+    poses = np.tile(np.eye(4, dtype=np.float32), (V, 1, 1))
+    poses[:, :3, :4] = rng.normal(size=(V, 3, 4)).astype(np.float32)
+    intr = np.array([55.0, 54.0, W / 2, H / 2], np.float32)
+    e = lib.engine_backend
+    f = lambda *s: torch.empty(*s, device="cuda")
+    for C in (4, 3):
+        img = np.ascontiguousarray(images[..., :C])
+        want = orc.sample_rays(img, poses, intr, N, seed=(9 << 32) | 77, draw=12)
+        ro, rd, gt, nz, bg = f(N, 3), f(N, 3), f(N, 4), f(N), f(N, 3)
+        idx = torch.empty(N, 2, dtype=torch.int32, device="cuda")
+        draw = torch.tensor([12], dtype=torch.int32, device="cuda")
+        e.sample_rays(dev(img), dev(poses), intr, N, (9 << 32) | 77, draw, ro, rd, gt, nz, bg, idx)
+        np.testing.assert_array_equal(host(idx), want["index"])            # integer draws: bit exact
+        np.testing.assert_array_equal(host(gt), want["gt"])
+        np.testing.assert_array_equal(host(nz), want["noises"])
+        np.testing.assert_array_equal(host(bg), want["bg"])
+        np.testing.assert_array_equal(host(ro), want["rays_o"])
+        np.testing.assert_allclose(host(rd), want["rays_d"], rtol=1e-6, atol=1e-6)
+        # host-supplied draw number, optional outputs omitted
+        ro2, rd2, gt2 = f(N, 3), f(N, 3), f(N, 4)
+        e.sample_rays(dev(img), dev(poses), intr, N, (9 << 32) | 77, 12, ro2, rd2, gt2)
+        assert torch.equal(rd2, rd) and torch.equal(gt2, gt)
+        e.counter_add(draw, 1)
+        assert int(draw) == 13
+
+
+def test_device_schedule_and_adam_match_host_versions(lib, orc):
+    e = lib.engine_backend
+    torch.manual_seed(1)
+    n = 4099
+    ctr = torch.tensor([0], dtype=torch.int32, device="cuda")
+    hyper = torch.zeros(4, device="cuda")
+    p0, g = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    pa, ma, va = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb, mb_, vb = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 40):
+        e.schedule_step(ctr, hyper, 1e-2, 30.0, 0.9, 0.999)
+        lr, bc1, rs = orc.schedule(step - 1, 1e-2, 30.0, 0.9, 0.999)
+        np.testing.assert_allclose(host(hyper)[:3], [lr, bc1, rs], rtol=2e-7)
+        assert int(ctr) == step
+        e.adam_step_dev(pa, g.clone(), ma, va, hyper, 0.9, 0.999, 1e-15)
+        e.adam_step(pb, g.clone(), mb_, vb, float(lr), 0.9, 0.999, 1e-15, step)
+        np.testing.assert_allclose(host(pa), host(pb), rtol=1e-6, atol=1e-8)
+
+
+def test_graph_replay_matches_eager_steps(lib):
+    """Same seed, same device-side ray draws: 40 steps replayed from captured graphs vs launched one by one."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    res = []
+    for graph in (True, False):
+        torch.manual_seed(0)
+        opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True, capture_graph=graph)
+        data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
+        eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
+        assert eng.use_graph == graph and eng.device_sampler
+        losses = []
+        for _ in range(40):
+            losses.append(eng.train_step().clone())
+        torch.cuda.synchronize()
+        assert (eng.last_graph_key is not None) == graph
+        assert int(eng.step_ctr) == 40 and int(eng.draw_ctr) == 41      # step 40 is already drawn and marched
+        res.append((torch.cat(losses).cpu().numpy(), int(eng.samples_seen), eng.table.clone()))
+    (la, sa, ta), (lb, sb, tb) = res
+    assert la[-5:].mean() < 0.9 * la[:5].mean()      # it trains
+    np.testing.assert_allclose(la[:16], lb[:16], rtol=2e-3)          # before the first learned grid refresh
+    np.testing.assert_allclose(la, lb, rtol=0.1)
+    assert abs(sa - sb) <= 0.02 * sb

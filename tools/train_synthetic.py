@@ -29,17 +29,20 @@ def main():
     ap.add_argument("--fused-mlp", action="store_true")
     ap.add_argument("--arena", type=int, default=0)
     ap.add_argument("--engine", action="store_true", help="fused training step (nerf/engine.py)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--torch-sampler", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     opt = Options(bound=1.0, num_rays=args.rays, iters=args.iters, fp16=args.fp16, fused_mlp=args.fused_mlp,
-                  arena_capacity=args.arena)
+                  arena_capacity=args.arena, capture_graph=not args.no_graph, device_sampler=not args.torch_sampler)
     t0 = time.time()
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     val = SyntheticDataset(opt, dev, "val", n_views=args.val_views, H=args.res, W=args.res)
     print(f"scene rendered in {time.time() - t0:.1f}s", flush=True)
     model = NeRFNetwork(opt)
-    trainer = FusedTrainer(opt, model, data, device=dev, capacity=args.arena or args.rays * 160) if args.engine \
+    trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed, capacity=args.arena or args.rays * 160) if args.engine \
         else Trainer(opt, model, data, device=dev)
     hist = []
     done = 0
