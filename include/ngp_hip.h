@@ -167,7 +167,15 @@ int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const
                                  const float *nears, const float *fars, const float *noises,
                                  float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
                                  float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
-                                 ngp_stream_t stream);
+                                 const uint32_t *occ_index, ngp_stream_t stream);
+
+/* Compressed copy of the occupancy bitfield that the arena march can keep in LDS (occ_index above; NULL = probe
+ * the bitfield in global memory).  The bitfield is Morton-ordered (raymarching.cu:56-81), so 64 consecutive bits
+ * are one 4x4x4 block; the index stores which blocks are non-zero plus the non-zero blocks themselves.  Rebuild it
+ * after every ngp_packbits.  Needs C*H^3 % 2048 == 0; index buffer of ngp_x_occupancy_index_bytes(C, H) bytes,
+ * 8-byte aligned.  The march result does not depend on whether the index is used. */
+size_t ngp_x_occupancy_index_bytes(uint32_t C, uint32_t H);
+int ngp_x_build_occupancy_index(const uint8_t *grid, uint32_t C, uint32_t H, uint32_t *index, ngp_stream_t stream);
 
 /* Hash-grid table gradient without global float atomics (D = 3, C = 2 only): same result as
  * ngp_grid_encode_backward's scatter (grad_embeddings += ...; different summation order), computed as

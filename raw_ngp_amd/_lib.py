@@ -59,7 +59,8 @@ _SIGNATURES = {
     "ngp_x_sample_rays": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p],
     "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_march_rays_train_arena": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _u, _p, _p, _p,
-                                     _p, _p, _p, _p],
+                                     _p, _p, _p, _p, _p],
+    "ngp_x_build_occupancy_index": [_p, _u, _u, _p],
 }
 
 _lib = None
@@ -79,6 +80,8 @@ def load():
         lib.ngp_abi_version.restype = ctypes.c_int
         lib.ngp_x_grid_backward_workspace_bytes.argtypes = [_u, _u, _u]
         lib.ngp_x_grid_backward_workspace_bytes.restype = ctypes.c_size_t
+        lib.ngp_x_occupancy_index_bytes.argtypes = [_u, _u]
+        lib.ngp_x_occupancy_index_bytes.restype = ctypes.c_size_t
         lib.ngp_x_mlp_image_bytes.argtypes = []
         lib.ngp_x_mlp_image_bytes.restype = ctypes.c_size_t
         lib.ngp_x_mlp_backward_workspace_bytes.argtypes = [_u]
@@ -93,7 +96,7 @@ def load():
 
 def declared_symbols():
     return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes",
-            "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes"] + list(_SIGNATURES)
+            "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes", "ngp_x_occupancy_index_bytes"] + list(_SIGNATURES)
 
 
 _DT = {"f": torch.float32, "i": torch.int32, "b": torch.uint8, "u": torch.int32}   # counters: int32 storage
@@ -340,13 +343,26 @@ class _RayBackend:
 
     @staticmethod
     def march_rays_train_arena(rays_o, rays_d, rays_ldir, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears,
-                               fars, noises, t_scratch, M_cap, xyzs, dirs, ts, ldirs, rays, counter, ray_idx):
+                               fars, noises, t_scratch, M_cap, xyzs, dirs, ts, ldirs, rays, counter, ray_idx,
+                               occ_index=None):
         _call("ngp_x_march_rays_train_arena", rays_o, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
               _ptr(rays_ldir, "f", "rays_ldir", True), _ptr(grid, "b", "grid"), float(bound), int(bool(contract)),
               float(dt_gamma), max_steps, N, C, H, _ptr(nears, "f", "nears"), _ptr(fars, "f", "fars"),
               _ptr(noises, "f", "noises"), _ptr(t_scratch, "f", "t_scratch"), M_cap, _ptr(xyzs, "f", "xyzs"),
               _ptr(dirs, "f", "dirs"), _ptr(ts, "f", "ts"), _ptr(ldirs, "f", "ldirs", True),
-              _ptr(rays, "i", "rays"), _ptr(counter, "i", "counter"), _ptr(ray_idx, "i", "ray_idx", True))
+              _ptr(rays, "i", "rays"), _ptr(counter, "i", "counter"), _ptr(ray_idx, "i", "ray_idx", True),
+              _ptr(occ_index, "i", "occ_index", True))
+
+    @staticmethod
+    def occupancy_index_bytes(C, H):
+        return int(load().ngp_x_occupancy_index_bytes(C, H))
+
+    @staticmethod
+    def build_occupancy_index(grid, C, H, index):
+        """index: int32 tensor of occupancy_index_bytes(C, H) / 4 words (rebuilt after every packbits)."""
+        if index.numel() * 4 < load().ngp_x_occupancy_index_bytes(C, H):
+            raise RuntimeError("build_occupancy_index: index buffer too small")
+        _call("ngp_x_build_occupancy_index", grid, _ptr(grid, "b", "grid"), C, H, _ptr(index, "i", "index"))
 
 
 class _MlpBackend:

@@ -190,13 +190,21 @@ struct Marcher {
     // length; the caller advances t).  false: empty space was skipped, t has been advanced.
     __device__ __forceinline__ bool probe(float &t, float &dt_out, float &px, float &py, float &pz) const
     {
+        const uint8_t *__restrict__ g = grid;
+        return probe_with(t, dt_out, px, py, pz, [g](uint32_t bit) { return (g[bit >> 3] >> (bit & 7u)) & 1u; });
+    }
+
+    template <class Occ>
+    __device__ __forceinline__ bool probe_with(float &t, float &dt_out, float &px, float &py, float &pz, Occ occupied) const
+    {
         const float x = clampf(fmaf(t, dx, ox), -bound, bound);
         const float y = clampf(fmaf(t, dy, oy), -bound, bound);
         const float z = clampf(fmaf(t, dz, oz), -bound, bound);
         float dt = clampf(t * dt_gamma, dt_min, dt_max);
 
         const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-        const int level = max(mip_of(mag, cascades), mip_of(dt * Hf * 0.5f, cascades));
+        int level = 0;   // one cascade: both mip_of() clamp to 0
+        if (cascades > 1.0f) level = max(mip_of(mag, cascades), mip_of(dt * Hf * 0.5f, cascades));
         const float mip_bound = fminf(scalbnf(1.0f, level), bound);
         const float mip_rbound = 1.0f / mip_bound;
 
@@ -211,7 +219,7 @@ struct Marcher {
         const int nz = (int)clampf(0.5f * fmaf(cz, mip_rbound, 1.0f) * Hf, 0.0f, Hm1);
 
         const uint32_t bit = (uint32_t)((float)level * H3 + (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-        const bool occ = (grid[bit >> 3] >> (bit & 7u)) & 1u;
+        const bool occ = occupied(bit);
 
         if (occ || outside) {
             px = cx; py = cy; pz = cz;
@@ -272,6 +280,122 @@ __global__ __launch_bounds__(kRayBlock) void march_count_kernel(
             if (MODE == 1) slab[step] = t;
             t += dt;
             step++;
+        }
+    }
+    rays[(size_t)n * 2 + 1] = (int32_t)step;
+}
+
+// ------------------------------------------------------------------ occupancy index (LDS-resident march)
+// The march is a chain of dependent probes (~600 per ray) and runs one wave per SIMD, so its time is
+// probes x (ALU + bitfield load latency); an L2 hit costs several hundred cycles, an LDS read ~100.  The 128^3
+// bitfield (256 KiB) does not fit the 160 KiB LDS, but a trained grid is sparse and Morton-ordered: 64
+// consecutive bits are one 4x4x4 block.  Index (uint32 words, built after every packbits):
+//   [0] nnz   [1] n_words64   [2..3] reserved
+//   pairs[n_words64 / 32] x {mask32: which of the group's 32 blocks are non-zero, rank: non-zero blocks before the group}
+//   blocks[nnz] x uint64, in block order
+// A probe is one 8-byte LDS read (pair) and, for a non-empty block, a second one (the block).  Same bits, so the
+// march result is unchanged.  When nnz exceeds the LDS budget (early training: grid all occupied) the kernel
+// falls back to global-memory probes.
+constexpr uint32_t kOccHeader = 4;
+
+__global__ __launch_bounds__(1024) void occupancy_index_kernel(const uint8_t *__restrict__ grid, uint32_t n_words64,
+                                                              uint32_t *__restrict__ index)
+{
+    __shared__ uint32_t wave_sum[16];
+    const uint64_t *__restrict__ words = reinterpret_cast<const uint64_t *>(grid);
+    const uint32_t n_groups = n_words64 >> 5;
+    uint32_t *pairs = index + kOccHeader;
+    uint64_t *blocks = reinterpret_cast<uint64_t *>(index + kOccHeader + 2 * (size_t)n_groups);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t per = (n_groups + 1023u) / 1024u, g0 = tid * per, g1 = min(n_groups, g0 + per);
+    uint32_t mine = 0;
+    for (uint32_t g = g0; g < g1; g++) {
+        uint32_t mask = 0;
+        for (uint32_t k = 0; k < 32u; k++) mask |= (words[(size_t)g * 32 + k] != 0ull ? 1u : 0u) << k;
+        pairs[2 * g] = mask;
+        mine += __popc(mask);
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63u) wave_sum[wid] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine, total = 0;
+    for (uint32_t k = 0; k < 16u; k++) {
+        if (k < wid) run += wave_sum[k];
+        total += wave_sum[k];
+    }
+    for (uint32_t g = g0; g < g1; g++) {
+        const uint32_t mask = pairs[2 * g];
+        pairs[2 * g + 1] = run;
+        for (uint32_t k = 0; k < 32u; k++)
+            if ((mask >> k) & 1u) blocks[run++] = words[(size_t)g * 32 + k];
+    }
+    if (tid == 0) {
+        index[0] = total;
+        index[1] = n_words64;
+        index[2] = index[3] = 0;
+    }
+}
+
+constexpr uint32_t kFastBlock = 256;
+
+// arena pass 1 with the occupancy index staged in LDS (lane = ray, 4 waves per workgroup share one copy)
+__global__ __launch_bounds__(kFastBlock) void march_count_indexed_kernel(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid,
+    const uint32_t *__restrict__ index, uint32_t lds_blocks_cap, float bound, bool contract, float dt_gamma,
+    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *__restrict__ nears,
+    const float *__restrict__ fars, const float *__restrict__ noises, int32_t *__restrict__ rays,
+    float *__restrict__ t_scratch)
+{
+    extern __shared__ uint64_t occ_lds[];
+    const uint32_t nnz = index[0], n_groups = index[1] >> 5;
+    const bool staged = nnz <= lds_blocks_cap;   // uniform over the grid
+    if (staged) {
+        // pairs and blocks are contiguous in the index: one flat copy of n_groups + nnz 8-byte words
+        const uint64_t *__restrict__ src = reinterpret_cast<const uint64_t *>(index + kOccHeader);
+        const uint32_t n64 = n_groups + nnz;
+        for (uint32_t i = threadIdx.x; i < n64; i += kFastBlock) occ_lds[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t n = blockIdx.x * kFastBlock + threadIdx.x;
+    if (n >= N) return;
+    Marcher m;
+    m.setup(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, false, bound, contract, dt_gamma, max_steps, C, H, grid);
+    const float far = fars[n];
+    float t = nears[n];
+    t = fmaf(clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
+    uint32_t step = 0;
+    float *slab = t_scratch + (size_t)n * max_steps;
+    const uint64_t *pairs = occ_lds, *blocks = occ_lds + n_groups;
+    auto in_lds = [pairs, blocks](uint32_t bit) -> uint32_t {
+        const uint32_t w = bit >> 6, k = w & 31u;
+        const uint64_t pr = pairs[w >> 5];
+        const uint32_t mask = (uint32_t)pr;
+        if (!((mask >> k) & 1u)) return 0u;
+        const uint32_t idx = (uint32_t)(pr >> 32) + __popc(mask & ((1u << k) - 1u));
+        return (uint32_t)(blocks[idx] >> (bit & 63u)) & 1u;
+    };
+    if (staged) {
+        while (t < far && step < max_steps) {
+            float dt, px, py, pz;
+            if (m.probe_with(t, dt, px, py, pz, in_lds)) {
+                slab[step] = t;
+                t += dt;
+                step++;
+            }
+        }
+    } else {
+        while (t < far && step < max_steps) {
+            float dt, px, py, pz;
+            if (m.probe(t, dt, px, py, pz)) {
+                slab[step] = t;
+                t += dt;
+                step++;
+            }
         }
     }
     rays[(size_t)n * 2 + 1] = (int32_t)step;
@@ -689,19 +813,58 @@ extern "C" int ngp_x_march_rays_train_arena(const float *rays_o, const float *ra
                                             const float *nears, const float *fars, const float *noises,
                                             float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
                                             float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
-                                            ngp_stream_t stream)
+                                            const uint32_t *occ_index, ngp_stream_t stream)
 {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && t_scratch && xyzs && dirs && ts,
                 "march_rays_train_arena: null tensor");
     NGP_REQUIRE(max_steps > 0 && H > 0 && C > 0 && M_cap > 0, "march_rays_train_arena: bad sizes");
-    march_count_kernel<1><<<NGP_1D(N, kRayBlock)>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C,
-                                                   H, nears, fars, noises, rays, t_scratch);
+    const uint64_t n_bits = (uint64_t)C * H * H * H;
+    if (occ_index) {
+        NGP_REQUIRE(n_bits % 2048u == 0 && ((uintptr_t)grid & 7u) == 0 && ((uintptr_t)occ_index & 7u) == 0,
+                    "march_rays_train_arena: occupancy index needs C*H^3 to be a multiple of 2048 and 8-byte aligned buffers");
+        const uint32_t n_groups = (uint32_t)(n_bits / 2048u);
+        constexpr uint32_t kLdsBudget = 144u * 1024u;
+        NGP_REQUIRE((size_t)n_groups * 8 + 8 * 1024 <= kLdsBudget, "march_rays_train_arena: too many cascades for the LDS index");
+        const uint32_t cap = (kLdsBudget - n_groups * 8u) / 8u;
+        static bool attr_set = false;
+        if (!attr_set) {
+            NGP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(march_count_indexed_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget) == hipSuccess,
+                        "march_rays_train_arena: cannot raise the dynamic LDS limit");
+            attr_set = true;
+        }
+        march_count_indexed_kernel<<<dim3(ceil_div(N, kFastBlock)), dim3(kFastBlock), kLdsBudget, as_stream(stream)>>>(
+            rays_o, rays_d, grid, occ_index, cap, bound, contract != 0, dt_gamma, max_steps, N, C, H, nears, fars, noises,
+            rays, t_scratch);
+    } else {
+        march_count_kernel<1><<<NGP_1D(N, kRayBlock)>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N,
+                                                       C, H, nears, fars, noises, rays, t_scratch);
+    }
     march_scan_kernel<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(rays, N, counter, M_cap, true);
     march_expand_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
         rays_o, rays_d, rays_ldir, bound, contract != 0, dt_gamma, max_steps, N, C, H, rays, t_scratch, xyzs, dirs, ts,
         rays_ldir ? ldirs : nullptr, ray_idx);
     NGP_CHECK_LAUNCH("march_rays_train_arena");
+    return NGP_OK;
+}
+
+extern "C" size_t ngp_x_occupancy_index_bytes(uint32_t C, uint32_t H)
+{
+    const uint64_t n_words64 = (uint64_t)C * H * H * H / 64u;
+    return (size_t)(kOccHeader * 4 + (n_words64 / 32u) * 8 + n_words64 * 8);
+}
+
+extern "C" int ngp_x_build_occupancy_index(const uint8_t *grid, uint32_t C, uint32_t H, uint32_t *index,
+                                           ngp_stream_t stream)
+{
+    NGP_REQUIRE(grid && index, "build_occupancy_index: null tensor");
+    const uint64_t n_bits = (uint64_t)C * H * H * H;
+    NGP_REQUIRE(n_bits > 0 && n_bits % 2048u == 0 && n_bits / 64u < (1ull << 31),
+                "build_occupancy_index: C*H^3 must be a positive multiple of 2048");
+    NGP_REQUIRE(((uintptr_t)grid & 7u) == 0 && ((uintptr_t)index & 7u) == 0, "build_occupancy_index: buffers must be 8-byte aligned");
+    occupancy_index_kernel<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(grid, (uint32_t)(n_bits / 64u), index);
+    NGP_CHECK_LAUNCH("build_occupancy_index");
     return NGP_OK;
 }
 

@@ -82,6 +82,12 @@ class FusedTrainer:
         self.slots = [_Slot(N, opt.max_steps, cap, dev) for _ in range(2 if self.prefetch else 1)]
         self.arena = self.slots[0].arena
         self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
+        # compressed occupancy bitfield the march keeps in LDS (rebuilt after every density-grid refresh)
+        self.occ_index = None
+        if bool(getattr(opt, "lds_march", True)) and (model.cascade * model.grid_size ** 3) % 2048 == 0:
+            self.occ_index = torch.zeros(rb.occupancy_index_bytes(model.cascade, model.grid_size) // 4,
+                                         dtype=torch.int32, device=dev)
+        self._occ_version = None
         # ray batches drawn on the device (one kernel, counter-based RNG) when the dataset keeps uint8 images there
         imgs = getattr(dataset, "images", None)
         self.device_sampler = bool(getattr(opt, "device_sampler", True)) and torch.is_tensor(imgs) \
@@ -118,10 +124,14 @@ class FusedTrainer:
     def march(self, slot, rays_o, rays_d, noises):
         """rays -> sample arena of `slot` (near/far, count, scan, expand); runs on the current stream."""
         opt, m, ar, N = self.opt, self.model, slot.arena, self.N
+        version = getattr(m, "bitfield_version", 0)
+        if self.occ_index is not None and version != self._occ_version:      # the bitfield was re-packed
+            rb.build_occupancy_index(m.density_bitfield, m.cascade, m.grid_size, self.occ_index)
+            self._occ_version = version
         eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train, N, m.min_near, slot.nears, slot.fars)
         rb.march_rays_train_arena(rays_o, rays_d, None, m.density_bitfield, m.real_bound, opt.contract, opt.dt_gamma,
                                   opt.max_steps, N, m.cascade, m.grid_size, slot.nears, slot.fars, noises, ar.t_scratch,
-                                  self.cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None)
+                                  self.cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, self.occ_index)
 
     def forward_backward(self, rays_o, rays_d, gt_rgba, noises, bg_rgb=None, bg_const=0.0):
         """march -> encode -> MLP -> composite -> loss -> backward into self.table_grad / self.w_grad."""

@@ -400,3 +400,4 @@ class NeRFRenderer(nn.Module):
             self.iter_density += 1
             thresh = min(self.mean_density, self.density_thresh)
             self.density_bitfield = raymarching.packbits(self.density_grid.detach(), thresh, self.density_bitfield)
+            self.bitfield_version = getattr(self, "bitfield_version", 0) + 1   # derived structures (LDS index) rebuild

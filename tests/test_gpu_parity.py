@@ -292,10 +292,39 @@ def test_march_rays_train_two_pass(be, orc, case):
         assert np.array_equal(host(ldirs), rl)
 
 
+def occupancy_index(be, bits, C, H):
+    rb = be.raymarching_backend
+    index = torch.zeros(rb.occupancy_index_bytes(C, H) // 4, dtype=torch.int32, device="cuda")
+    rb.build_occupancy_index(dev(bits), C, H, index)
+    return index
+
+
+@pytest.mark.parametrize("fill", [0.0, 0.05, 0.6])
+def test_occupancy_index_is_the_bitfield(be, fill):
+    """Header, block masks, ranks and non-zero 4x4x4 blocks of the LDS index against numpy."""
+    rng = np.random.default_rng(5)
+    C, H = 2, 64
+    words = np.zeros(C * H ** 3 // 64, dtype=np.uint64)
+    hot = rng.random(words.size) < fill
+    words[hot] = rng.integers(1, 2 ** 63, hot.sum(), dtype=np.uint64)
+    bits = words.view(np.uint8)
+    idx = host(occupancy_index(be, bits, C, H)).view(np.uint32)
+    n_groups = words.size // 32
+    assert idx[0] == hot.sum() and idx[1] == words.size
+    pairs = idx[4:4 + 2 * n_groups].reshape(n_groups, 2)
+    nz = (words != 0).reshape(n_groups, 32)
+    np.testing.assert_array_equal(pairs[:, 0], (nz.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(1).astype(np.uint32))
+    np.testing.assert_array_equal(pairs[:, 1], np.concatenate([[0], np.cumsum(nz.sum(1))[:-1]]).astype(np.uint32))
+    blocks = idx[4 + 2 * n_groups:4 + 2 * n_groups + 2 * int(idx[0])].view(np.uint64)
+    np.testing.assert_array_equal(blocks, words[hot])
+
+
+@pytest.mark.parametrize("indexed", [False, True], ids=["bitfield", "lds-index"])
 @pytest.mark.parametrize("case", MARCH_CASES, ids=lambda c: f"N{c[0]}H{c[1]}C{c[3]}b{c[4]}c{int(c[5])}g{c[6] > 0}")
-def test_march_rays_train_arena(be, orc, case):
+def test_march_rays_train_arena(be, orc, case, indexed):
     N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
     bits, o, d, ld, nears, fars, noises = march_inputs(orc, case, seed=1)
+    index = occupancy_index(be, bits, C, H) if indexed else None
     rx, rd, rt, rrays, rl, M = orc.march_rays_train(o, d, ld, bits, bound, contract, dt_gamma, max_steps, C, H, nears,
                                                     fars, noises)
     from raw_ngp_amd.raymarching import MarchArena
@@ -304,7 +333,7 @@ def test_march_rays_train_arena(be, orc, case):
         be.raymarching_backend.march_rays_train_arena(dev(o), dev(d), dev(ld) if ldir else None, dev(bits), bound,
                                                       contract, dt_gamma, max_steps, N, C, H, dev(nears), dev(fars),
                                                       dev(noises), ar.t_scratch, cap, ar.xyzs, ar.dirs, ar.ts,
-                                                      ar.ldirs, ar.rays, ar.counter, ar.ray_idx)
+                                                      ar.ldirs, ar.rays, ar.counter, ar.ray_idx, index)
         written, needed = host(ar.counter)
         assert needed == M
         got = host(ar.rays)
@@ -320,6 +349,25 @@ def test_march_rays_train_arena(be, orc, case):
         assert np.array_equal(host(ar.ray_idx)[:w], orc.flatten_rays(rrays, M)[:w])
         if ldir:
             assert np.array_equal(host(ar.ldirs)[:w], rl[:w])
+
+
+def test_march_arena_index_too_big_for_lds_falls_back_to_bitfield(be, orc):
+    """Dense random bitfield: every 4x4x4 block is non-zero (32768 blocks > LDS budget) -> global probes, same result."""
+    case = (2000, 128, 1024, 1, 1.0, False, 0.0, False)
+    N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
+    _, o, d, ld, nears, fars, noises = march_inputs(orc, case, seed=2)
+    bits = np.random.default_rng(9).integers(0, 256, H ** 3 // 8, dtype=np.uint8) & np.uint8(0x11)
+    rx, rd, rt, rrays, rl, M = orc.march_rays_train(o, d, ld, bits, bound, contract, dt_gamma, max_steps, C, H, nears,
+                                                    fars, noises)
+    index = occupancy_index(be, bits, C, H)
+    assert int(index[0]) > 20000
+    from raw_ngp_amd.raymarching import MarchArena
+    ar = MarchArena(N, max_steps, M + 10, "cuda")
+    be.raymarching_backend.march_rays_train_arena(dev(o), dev(d), None, dev(bits), bound, contract, dt_gamma, max_steps,
+                                                  N, C, H, dev(nears), dev(fars), dev(noises), ar.t_scratch, M + 10,
+                                                  ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, index)
+    assert int(ar.counter[0]) == M and np.array_equal(host(ar.rays), rrays)
+    assert np.array_equal(host(ar.xyzs)[:M], rx) and np.array_equal(host(ar.ts)[:M], rt)
 
 
 def test_march_empty_inputs(be, orc):
