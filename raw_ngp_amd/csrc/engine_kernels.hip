@@ -159,8 +159,10 @@ __global__ __launch_bounds__(256) void composite_forward_wave_kernel(
 //         but every sample of the ray is written: zeros after the early stop)
 // MODE 1: gradients of the MSE loss  mean_{n,c} ((image + (1 - ws) bg - gt)^2)  with gt = rgb*a + bg*(1-a);
 //         also accumulates the loss value into loss_out[0]
+constexpr uint32_t kCompBwdBlock = 1024;   // 16 rays per workgroup: one loss atomic per workgroup (same-address
+                                           // global atomics serialise: 4096 of them cost ~60 us)
 template <int MODE>
-__global__ __launch_bounds__(256) void composite_backward_wave_kernel(
+__global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
     const float *__restrict__ grad_weights, const float *__restrict__ grad_weights_sum,
     const float *__restrict__ grad_depth, const float *__restrict__ grad_image, const float *__restrict__ gt_rgba,
     const float *__restrict__ bg_rgb, float bg_const, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
@@ -168,17 +170,22 @@ __global__ __launch_bounds__(256) void composite_backward_wave_kernel(
     const float *__restrict__ depth, const float *__restrict__ image, uint32_t M, uint32_t N, float T_thresh,
     float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs, float *__restrict__ loss_out)
 {
-    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (n >= N) return;
-    const uint32_t off = (uint32_t)rays[(size_t)n * 2], cnt = (uint32_t)rays[(size_t)n * 2 + 1];
-    const bool live = cnt != 0 && off + cnt <= M;
-    const float rF = image[(size_t)n * 3], gF = image[(size_t)n * 3 + 1], bF = image[(size_t)n * 3 + 2];
-    const float wsF = weights_sum[n], dF = depth[n];
+    __shared__ float ray_err[kCompBwdBlock / 64];
+    const uint32_t n = (blockIdx.x * kCompBwdBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (MODE == 1) {   // the whole workgroup passes the barrier before any wave leaves
+        if (lane == 0) ray_err[threadIdx.x >> 6] = 0.0f;
+    }
+    const bool in_range = n < N;
+    const uint32_t nn = in_range ? n : 0u;
+    const uint32_t off = (uint32_t)rays[(size_t)nn * 2], cnt = (uint32_t)rays[(size_t)nn * 2 + 1];
+    const bool live = in_range && cnt != 0 && off + cnt <= M;
+    const float rF = image[(size_t)nn * 3], gF = image[(size_t)nn * 3 + 1], bF = image[(size_t)nn * 3 + 2];
+    const float wsF = weights_sum[nn], dF = depth[nn];
     float gr, gg, gb, gws, gd;
     if (MODE == 1) {
-        const float4 px = reinterpret_cast<const float4 *>(gt_rgba)[n];
-        const float b0 = bg_rgb ? bg_rgb[(size_t)n * 3] : bg_const, b1 = bg_rgb ? bg_rgb[(size_t)n * 3 + 1] : bg_const,
-                    b2 = bg_rgb ? bg_rgb[(size_t)n * 3 + 2] : bg_const;
+        const float4 px = reinterpret_cast<const float4 *>(gt_rgba)[nn];
+        const float b0 = bg_rgb ? bg_rgb[(size_t)nn * 3] : bg_const, b1 = bg_rgb ? bg_rgb[(size_t)nn * 3 + 1] : bg_const,
+                    b2 = bg_rgb ? bg_rgb[(size_t)nn * 3 + 2] : bg_const;
         const float e0 = (rF + (1.0f - wsF) * b0) - (px.x * px.w + b0 * (1.0f - px.w));
         const float e1 = (gF + (1.0f - wsF) * b1) - (px.y * px.w + b1 * (1.0f - px.w));
         const float e2 = (bF + (1.0f - wsF) * b2) - (px.z * px.w + b2 * (1.0f - px.w));
@@ -188,13 +195,20 @@ __global__ __launch_bounds__(256) void composite_backward_wave_kernel(
         gb = k * e2;
         gws = -(gr * b0 + gg * b1 + gb * b2);
         gd = 0.0f;
-        if (lane == 0) atomicAdd(loss_out, (e0 * e0 + e1 * e1 + e2 * e2) / (3.0f * (float)N));
+        if (lane == 0 && in_range) ray_err[threadIdx.x >> 6] = (e0 * e0 + e1 * e1 + e2 * e2) / (3.0f * (float)N);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float sum = 0.0f;
+#pragma unroll
+            for (uint32_t k = 0; k < kCompBwdBlock / 64; k++) sum += ray_err[k];
+            atomicAdd(loss_out, sum);
+        }
     } else {
-        gr = grad_image[(size_t)n * 3];
-        gg = grad_image[(size_t)n * 3 + 1];
-        gb = grad_image[(size_t)n * 3 + 2];
-        gws = grad_weights_sum[n];
-        gd = grad_depth[n];
+        gr = grad_image[(size_t)nn * 3];
+        gg = grad_image[(size_t)nn * 3 + 1];
+        gb = grad_image[(size_t)nn * 3 + 2];
+        gws = grad_weights_sum[nn];
+        gd = grad_depth[nn];
     }
     if (!live) return;
     float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0;
@@ -443,7 +457,7 @@ extern "C" int ngp_x_composite_rays_train_backward(const float *grad_weights, co
     NGP_REQUIRE(grad_weights && grad_weights_sum && grad_depth && grad_image && sigmas && rgbs && ts && rays &&
                     weights_sum && depth && image && grad_sigmas && grad_rgbs,
                 "x_composite_rays_train_backward: null tensor");
-    composite_backward_wave_kernel<0><<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
+    composite_backward_wave_kernel<0><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
         grad_weights, grad_weights_sum, grad_depth, grad_image, nullptr, nullptr, 0.0f, sigmas, rgbs, ts, rays,
         weights_sum, depth, image, M, N, T_thresh, grad_sigmas, grad_rgbs, nullptr);
     NGP_CHECK_LAUNCH("x_composite_rays_train_backward");
@@ -460,7 +474,7 @@ extern "C" int ngp_x_composite_mse_backward(const float *gt_rgba, const float *b
     NGP_REQUIRE(gt_rgba && rays && weights_sum && depth && image && loss_out, "composite_mse_backward: null tensor");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && grad_sigmas && grad_rgbs), "composite_mse_backward: null sample tensor");
     NGP_REQUIRE(((uintptr_t)gt_rgba & 15u) == 0, "composite_mse_backward: gt_rgba must be 16-byte aligned");
-    composite_backward_wave_kernel<1><<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
+    composite_backward_wave_kernel<1><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
         nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, weights_sum, depth, image, M,
         N, T_thresh, grad_sigmas, grad_rgbs, loss_out);
     NGP_CHECK_LAUNCH("composite_mse_backward");

@@ -258,7 +258,10 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w)
 }
 
 // ------------------------------------------------------------------ fill
-// LDS: hist[nbins] | lbase[nbins] | gbase[nbins] | stage[8 * kFillTile] x 16 B
+// LDS: hist[nbins] | lbase[nbins] | gbase[nbins] | stage[8 * kFillTile] x 12 B  (row-in-chunk | chunk << 12, v.x, v.y)
+struct StageRec {
+    uint32_t key, vx, vy;
+};
 __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
                                                          const int32_t *__restrict__ offsets,
                                                          const int32_t *__restrict__ B_dev, uint32_t B_cap, uint32_t gstride,
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
 {
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds, *lbase = lds + nbins_cap, *gbase = lds + 2 * nbins_cap;
-    uint4 *stage = reinterpret_cast<uint4 *>(lds + 3 * nbins_cap);
+    StageRec *stage = reinterpret_cast<StageRec *>(lds + 3 * nbins_cap);
     __shared__ uint32_t wave_tot[kFillBlock / 64];
 
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
@@ -350,11 +353,10 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
         for (uint32_t corner = 0; corner < 8; corner++) {
             gmax = fmaxf(gmax, fmaxf(fabsf(vx[corner]), fabsf(vy[corner])));
             const uint32_t bin = rows[corner] >> kChunkShift;
-            uint4 r;
-            r.x = gbase[bin] + pos[corner];
-            r.y = rows[corner] & (kChunkRows - 1u);
-            r.z = __float_as_uint(vx[corner]);
-            r.w = __float_as_uint(vy[corner]);
+            StageRec r;
+            r.key = (rows[corner] & (kChunkRows - 1u)) | (bin << kChunkShift);
+            r.vx = __float_as_uint(vx[corner]);
+            r.vy = __float_as_uint(vy[corner]);
             stage[lbase[bin] + pos[corner]] = r;
         }
     }
@@ -367,11 +369,12 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     __syncthreads();
     // consecutive lanes -> consecutive records of one chunk (until the chunk changes)
     for (uint32_t j = threadIdx.x; j < total; j += kFillBlock) {
-        const uint4 r = stage[j];
-        uint32_t *dst = w.records + (size_t)r.x * 3;
-        dst[0] = r.y;
-        dst[1] = r.z;
-        dst[2] = r.w;
+        const StageRec r = stage[j];
+        const uint32_t bin = r.key >> kChunkShift;
+        uint32_t *dst = w.records + (size_t)(gbase[bin] + (j - lbase[bin])) * 3;
+        dst[0] = r.key & (kChunkRows - 1u);
+        dst[1] = r.vx;
+        dst[2] = r.vy;
     }
 }
 
@@ -499,10 +502,11 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
     NGP_REQUIRE(max_level_rows <= n_rows_total, "grid_encode_backward_binned: max_level_rows > n_rows_total");
     const uint32_t level_chunks = max_level_rows ? ceil_div(max_level_rows, kChunkRows) : n_chunks_max;
     const uint32_t nbins_cap = (level_chunks + 3u) & ~3u;
-    const size_t fill_lds = (size_t)nbins_cap * 12 + (size_t)kFillTile * 8 * 16;
+    const size_t fill_lds = (size_t)nbins_cap * 12 + (size_t)kFillTile * 8 * sizeof(StageRec);
     static const bool lds_ok = [] {   // the fill kernel wants more than the default 64 KiB of dynamic LDS
         return hipFuncSetAttribute(reinterpret_cast<const void *>(bin_fill_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxChunks * 12 + kFillTile * 8 * 16) ==
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kMaxChunks * 12 + kFillTile * 8 * sizeof(StageRec)) ==
                hipSuccess;
     }();
     NGP_REQUIRE(lds_ok, "grid_encode_backward_binned: cannot raise the dynamic LDS limit");

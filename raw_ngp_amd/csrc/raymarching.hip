@@ -824,7 +824,9 @@ extern "C" int ngp_x_march_rays_train_arena(const float *rays_o, const float *ra
         NGP_REQUIRE(n_bits % 2048u == 0 && ((uintptr_t)grid & 7u) == 0 && ((uintptr_t)occ_index & 7u) == 0,
                     "march_rays_train_arena: occupancy index needs C*H^3 to be a multiple of 2048 and 8-byte aligned buffers");
         const uint32_t n_groups = (uint32_t)(n_bits / 2048u);
-        constexpr uint32_t kLdsBudget = 144u * 1024u;
+        // 96 KiB, not all 160: the march runs beside the main stream's kernels and must leave room for their
+        // workgroups on its CUs (a persistent-grid kernel that cannot place a workgroup there runs a second round)
+        constexpr uint32_t kLdsBudget = 96u * 1024u;
         NGP_REQUIRE((size_t)n_groups * 8 + 8 * 1024 <= kLdsBudget, "march_rays_train_arena: too many cascades for the LDS index");
         const uint32_t cap = (kLdsBudget - n_groups * 8u) / 8u;
         static bool attr_set = false;
