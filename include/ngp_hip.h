@@ -303,6 +303,32 @@ int ngp_x_sample_rays(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W,
 int ngp_x_near_far_from_aabb_v2(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
                                 float min_near, float *nears, float *fars, ngp_stream_t stream);
 
+/* ---- density-grid refresh on the device (NeRFRenderer.update_extra_state, nerf/renderer.py:811-897) -------------
+ * One cascade at a time:
+ *   ngp_x_density_grid_sample   cells to re-evaluate: n_uniform uniformly drawn cells (full != 0: every cell once,
+ *                               n_uniform = H^3) then n_occupied cells drawn uniformly among those with density > 0
+ *                               (index -1 when none is); xyz = (2 c/(H-1) - 1) * span + (2u - 1) * half with
+ *                               span = bound_cas - half (renderer.py:868-872).  Philox4x32-10, counters (i, draw, 2|3, 0).
+ *   (caller evaluates the density at xyzs)
+ *   ngp_x_density_grid_scatter  tmp[index] = max(tmp[index], sigma); tmp holds -1 where nothing was evaluated
+ * then over all cascades:
+ *   ngp_x_density_grid_update   grid = max(grid * decay, tmp) where grid >= 0 and tmp >= 0; stats[0] = sum of
+ *                               clamp(grid, 0); tmp is reset to -1
+ *   ngp_x_packbits_mean         ngp_packbits with thresh = min(stats[0] / cells, density_thresh); N = bytes of the
+ *                               bitfield; writes stats[1] = mean density, stats[2] = thresh
+ * Nothing is read back to the host. */
+size_t ngp_x_density_grid_workspace_bytes(uint32_t H);
+int ngp_x_density_grid_sample(const float *grid_cas, uint32_t H, float span, float half, uint32_t n_uniform,
+                              uint32_t n_occupied, int full, uint64_t seed, const uint32_t *draw_dev, uint32_t draw,
+                              void *workspace, size_t workspace_bytes, int32_t *indices, float *xyzs,
+                              ngp_stream_t stream);
+int ngp_x_density_grid_scatter(const int32_t *indices, const float *sigmas, uint32_t n, float *tmp_cas,
+                               ngp_stream_t stream);
+int ngp_x_density_grid_update(float *grid, float *tmp, uint32_t n_cells, float decay, float *stats,
+                              ngp_stream_t stream);
+int ngp_x_packbits_mean(const float *grid, uint32_t N, float *stats, float density_thresh, uint8_t *bitfield,
+                        ngp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -334,3 +334,56 @@ def schedule(step_done, lr0, decay_steps, beta1, beta2):
     t = step_done + 1
     return (np.float32(lr0 * 0.1 ** min(step_done / decay_steps, 1.0)), np.float32(1 - beta1 ** t),
             np.float32(1 / np.sqrt(1 - beta2 ** t)))
+
+
+# ----------------------------------------------------------------------------- density-grid refresh (engine extension)
+def _compact_bits(v):
+    v = v.astype(np.uint32) & np.uint32(0x49249249)
+    v = (v | (v >> np.uint32(2))) & np.uint32(0xc30c30c3)
+    v = (v | (v >> np.uint32(4))) & np.uint32(0x0f00f00f)
+    v = (v | (v >> np.uint32(8))) & np.uint32(0xff0000ff)
+    v = (v | (v >> np.uint32(16))) & np.uint32(0x0000ffff)
+    return v
+
+
+def density_grid_sample(grid_cas, H, span, half, n_uniform, n_occupied, full, seed, draw):
+    """ngp_x_density_grid_sample: the cell draws of update_extra_state (nerf/renderer.py:851-872) with Philox in
+    place of torch's generator.  Returns (indices int32 [n], xyzs f32 [n,3])."""
+    n = n_uniform + n_occupied
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    i = np.arange(n, dtype=np.uint32)
+    ctr = np.stack([i, np.full(n, draw, np.uint32), np.full(n, 2, np.uint32), np.zeros(n, np.uint32)], 1)
+    r = philox4x32_10(ctr, key).astype(np.uint64)
+    ctr[:, 2] = 3
+    q = philox4x32_10(ctr, key).astype(np.uint64)
+    index = np.empty(n, np.int64)
+    if full:
+        index[:n_uniform] = np.arange(n_uniform)
+    else:
+        c = [((r[:n_uniform, k] * np.uint64(H)) >> np.uint64(32)).astype(np.uint32) for k in range(3)]
+        index[:n_uniform] = morton3D(np.stack(c, 1).astype(np.int32))
+    if n_occupied:
+        pos = np.flatnonzero(np.asarray(grid_cas).reshape(-1) > 0)          # ascending cell order
+        if len(pos):
+            pick = ((r[n_uniform:, 0] * np.uint64(len(pos))) >> np.uint64(32)).astype(np.int64)
+            index[n_uniform:] = pos[pick]
+        else:
+            index[n_uniform:] = -1
+    live = index >= 0
+    cell = np.where(live, index, 0).astype(np.uint32)
+    f32 = np.float32
+    u01 = lambda x: (x >> np.uint64(8)).astype(f32) * f32(2.0 ** -24)
+    xyz = np.zeros((n, 3), f32)
+    for k in range(3):
+        c = _compact_bits(cell >> np.uint32(k)).astype(f32)
+        xyz[:, k] = ((f32(2) * c) / f32(H - 1) - f32(1)) * f32(span) + (u01(q[:, k]) * f32(2) - f32(1)) * f32(half)
+    xyz[~live] = 0
+    return index.astype(np.int32), xyz
+
+
+def density_grid_update(grid, tmp, decay):
+    """renderer.py:884-887: grid = max(grid*decay, tmp) where both >= 0; returns (new grid, mean of clamp(grid, 0))."""
+    g, t = np.asarray(grid, np.float32).copy(), np.asarray(tmp, np.float32)
+    valid = (g >= 0) & (t >= 0)
+    g[valid] = np.maximum(g[valid] * np.float32(decay), t[valid])
+    return g, float(np.clip(g, 0, None).astype(np.float64).mean())

@@ -61,6 +61,10 @@ _SIGNATURES = {
     "ngp_x_march_rays_train_arena": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _u, _p, _p, _p,
                                      _p, _p, _p, _p, _p],
     "ngp_x_build_occupancy_index": [_p, _u, _u, _p],
+    "ngp_x_density_grid_sample": [_p, _u, _f, _f, _u, _u, _i, ctypes.c_uint64, _p, _u, _p, ctypes.c_size_t, _p, _p],
+    "ngp_x_density_grid_scatter": [_p, _p, _u, _p],
+    "ngp_x_density_grid_update": [_p, _p, _u, _f, _p],
+    "ngp_x_packbits_mean": [_p, _u, _p, _f, _p],
 }
 
 _lib = None
@@ -82,6 +86,8 @@ def load():
         lib.ngp_x_grid_backward_workspace_bytes.restype = ctypes.c_size_t
         lib.ngp_x_occupancy_index_bytes.argtypes = [_u, _u]
         lib.ngp_x_occupancy_index_bytes.restype = ctypes.c_size_t
+        lib.ngp_x_density_grid_workspace_bytes.argtypes = [_u]
+        lib.ngp_x_density_grid_workspace_bytes.restype = ctypes.c_size_t
         lib.ngp_x_mlp_image_bytes.argtypes = []
         lib.ngp_x_mlp_image_bytes.restype = ctypes.c_size_t
         lib.ngp_x_mlp_backward_workspace_bytes.argtypes = [_u]
@@ -96,7 +102,8 @@ def load():
 
 def declared_symbols():
     return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes",
-            "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes", "ngp_x_occupancy_index_bytes"] + list(_SIGNATURES)
+            "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes", "ngp_x_occupancy_index_bytes",
+            "ngp_x_density_grid_workspace_bytes"] + list(_SIGNATURES)
 
 
 _DT = {"f": torch.float32, "i": torch.int32, "b": torch.uint8, "u": torch.int32}   # counters: int32 storage
@@ -472,6 +479,35 @@ class _EngineBackend:
               0 if on_dev else int(draw) & 0xffffffff, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
               _ptr(gt_rgba, "f", "gt_rgba"), _ptr(noises, "f", "noises", True), _ptr(bg_rgb, "f", "bg_rgb", True),
               _ptr(index, "i", "index", True))
+
+    @staticmethod
+    def density_grid_workspace_bytes(H):
+        return int(load().ngp_x_density_grid_workspace_bytes(H))
+
+    @staticmethod
+    def density_grid_sample(grid_cas, H, span, half, n_uniform, n_occupied, full, seed, draw, workspace, indices, xyzs):
+        """`draw`: int32 device tensor or a Python int (as in sample_rays)."""
+        on_dev = torch.is_tensor(draw)
+        _call("ngp_x_density_grid_sample", grid_cas, _ptr(grid_cas, "f", "grid_cas"), H, float(span), float(half),
+              n_uniform, n_occupied, int(bool(full)), int(seed) & (2 ** 64 - 1),
+              _ptr(draw, "u", "draw") if on_dev else None, 0 if on_dev else int(draw) & 0xffffffff,
+              _ptr(workspace, "b", "workspace"), workspace.numel(), _ptr(indices, "i", "indices"),
+              _ptr(xyzs, "f", "xyzs"))
+
+    @staticmethod
+    def density_grid_scatter(indices, sigmas, n, tmp_cas):
+        _call("ngp_x_density_grid_scatter", sigmas, _ptr(indices, "i", "indices"), _ptr(sigmas, "f", "sigmas"), n,
+              _ptr(tmp_cas, "f", "tmp_cas"))
+
+    @staticmethod
+    def density_grid_update(grid, tmp, decay, stats):
+        _call("ngp_x_density_grid_update", grid, _ptr(grid, "f", "grid"), _ptr(tmp, "f", "tmp"), grid.numel(),
+              float(decay), _ptr(stats, "f", "stats"))
+
+    @staticmethod
+    def packbits_mean(grid, stats, density_thresh, bitfield):
+        _call("ngp_x_packbits_mean", grid, _ptr(grid, "f", "grid"), bitfield.numel(), _ptr(stats, "f", "stats"),
+              float(density_thresh), _ptr(bitfield, "b", "bitfield"))
 
     @staticmethod
     def near_far_from_aabb_v2(rays_o, rays_d, aabb, N, min_near, nears, fars):

@@ -1,0 +1,282 @@
+// Density-grid refresh on the device (extension; the reference does this with ~60 small torch kernels and three
+// host round trips, NeRFRenderer.update_extra_state, nerf/renderer.py:811-897).
+//
+//   sample    cells to re-evaluate for one cascade: n_uniform cells drawn uniformly (or, in `full` mode, every cell
+//             once) followed by n_occupied cells drawn uniformly among the cells with density > 0
+//             (renderer.py:851-866), each with a position jittered inside the cell (:868-872)
+//   (caller)  density at those positions: hash-grid encode + density MLP
+//   scatter   tmp[cell] = sigma (renderer.py:881; duplicates resolve to the larger value instead of "last writer")
+//   update    grid = max(grid * decay, tmp) where both are >= 0 (:884-885); sum of clamp(grid, 0) for the mean (:887)
+//   packbits  with thresh = min(mean, density_thresh) read from device memory (:890-894)
+//
+// "uniformly among the occupied cells" without torch.nonzero: a 64-cell occupancy mask per word + an exclusive prefix
+// of the popcounts; a draw r in [0, n_pos) is located by binary search over the prefix and a select inside the word.
+#include "morton.hpp"
+#include "rng_common.hpp"
+
+namespace ngp {
+
+// workspace: mask[n_words] u64 | prefix[n_words + 1] u32
+struct GridWs {
+    uint64_t *mask;
+    uint32_t *prefix;
+};
+__host__ __device__ inline GridWs grid_ws(void *ws, uint32_t n_words)
+{
+    GridWs g;
+    g.mask = reinterpret_cast<uint64_t *>(ws);
+    g.prefix = reinterpret_cast<uint32_t *>(g.mask + n_words);
+    return g;
+}
+
+// one wave per 64 cells: coalesced read, ballot -> mask word; prefix[w + 1] holds the word's popcount until the scan
+__global__ __launch_bounds__(256) void grid_positive_mask_kernel(const float *__restrict__ grid, uint32_t n_words,
+                                                                GridWs g)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+    for (uint32_t w = wave; w < n_words; w += n_waves) {
+        const unsigned long long m = __ballot(grid[(size_t)w * 64 + lane] > 0.0f);
+        if (lane == 0) {
+            g.mask[w] = m;
+            g.prefix[w + 1] = (uint32_t)__popcll(m);
+        }
+    }
+}
+
+// in place: prefix[w + 1] = counts -> prefix[w] = cells before word w, prefix[n_words] = total
+__global__ __launch_bounds__(1024) void grid_prefix_kernel(uint32_t n_words, GridWs g)
+{
+    __shared__ uint32_t wave_sum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t per = (n_words + 1023u) / 1024u, w0 = tid * per, w1 = min(n_words, w0 + per);
+    uint32_t mine = 0;
+    for (uint32_t w = w0; w < w1; w++) mine += g.prefix[w + 1];
+    uint32_t inc = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63u) wave_sum[wid] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (uint32_t k = 0; k < wid; k++) run += wave_sum[k];
+    if (tid == 0) g.prefix[0] = 0;
+    for (uint32_t w = w0; w < w1; w++) {   // inclusive values, written one slot up: a lane only overwrites its own inputs
+        run += g.prefix[w + 1];
+        g.prefix[w + 1] = run;
+    }
+}
+
+// index of the r-th (0-based) set bit of m
+__device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t r)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t width = 32; width >= 1; width >>= 1) {
+        const uint64_t low = m & ((1ull << width) - 1ull);
+        const uint32_t c = (uint32_t)__popcll(low);
+        if (r >= c) {
+            r -= c;
+            m >>= width;
+            pos += width;
+        } else {
+            m = low;
+        }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(256) void grid_sample_cells_kernel(GridWs g, uint32_t n_words, uint32_t H, float span,
+                                                               float half, uint32_t n_uniform, uint32_t n_occupied,
+                                                               bool full, uint32_t seed_lo, uint32_t seed_hi,
+                                                               const uint32_t *__restrict__ draw_dev, uint32_t draw,
+                                                               int32_t *__restrict__ indices, float *__restrict__ xyzs)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_uniform + n_occupied) return;
+    if (draw_dev) draw = draw_dev[0];
+    uint32_t r[4] = {i, draw, 2u, 0u}, q[4] = {i, draw, 3u, 0u};
+    philox4x32_10(r, seed_lo, seed_hi);
+    philox4x32_10(q, seed_lo, seed_hi);
+    uint32_t cx, cy, cz;
+    int32_t index;
+    if (i < n_uniform) {
+        if (full) {
+            index = (int32_t)i;
+            cx = compact_bits(i);
+            cy = compact_bits(i >> 1);
+            cz = compact_bits(i >> 2);
+        } else {
+            cx = __umulhi(r[0], H);
+            cy = __umulhi(r[1], H);
+            cz = __umulhi(r[2], H);
+            index = (int32_t)morton3(cx, cy, cz);
+        }
+    } else {
+        const uint32_t n_pos = g.prefix[n_words];
+        if (n_pos == 0) {   // nothing occupied yet: the reference leaves this half out
+            indices[i] = -1;
+            xyzs[(size_t)i * 3] = xyzs[(size_t)i * 3 + 1] = xyzs[(size_t)i * 3 + 2] = 0.0f;
+            return;
+        }
+        const uint32_t pick = __umulhi(r[0], n_pos);
+        uint32_t lo = 0, hi = n_words;   // largest w with prefix[w] <= pick
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (g.prefix[mid] <= pick)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t cell = lo * 64u + select_bit(g.mask[lo], pick - g.prefix[lo]);
+        index = (int32_t)cell;
+        cx = compact_bits(cell);
+        cy = compact_bits(cell >> 1);
+        cz = compact_bits(cell >> 2);
+    }
+    indices[i] = index;
+    const float inv = (float)(H - 1u);
+    // (2 c / (H - 1) - 1) * (bound - half) + (2 u - 1) * half      (renderer.py:868-872)
+    xyzs[(size_t)i * 3] = ((2.0f * (float)cx) / inv - 1.0f) * span + (u01(q[0]) * 2.0f - 1.0f) * half;
+    xyzs[(size_t)i * 3 + 1] = ((2.0f * (float)cy) / inv - 1.0f) * span + (u01(q[1]) * 2.0f - 1.0f) * half;
+    xyzs[(size_t)i * 3 + 2] = ((2.0f * (float)cz) / inv - 1.0f) * span + (u01(q[2]) * 2.0f - 1.0f) * half;
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const int32_t *__restrict__ indices,
+                                                          const float *__restrict__ sigmas, uint32_t n,
+                                                          float *__restrict__ tmp)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int32_t idx = indices[i];
+    if (idx < 0) return;
+    // sigma >= 0, tmp starts at -1: as signed integers, float bit patterns of non-negative values order like the floats
+    atomicMax(reinterpret_cast<int *>(tmp) + idx, __float_as_int(sigmas[i]));
+}
+
+__global__ __launch_bounds__(256) void grid_update_kernel(float *__restrict__ grid, float *__restrict__ tmp, uint32_t n4,
+                                                         float decay, float *__restrict__ stats)
+{
+    __shared__ float wave_sum[4];
+    float sum = 0.0f;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        float4 v = reinterpret_cast<float4 *>(grid)[i];
+        const float4 t = reinterpret_cast<float4 *>(tmp)[i];
+#define NGP_UPD(c)                                                  \
+    if (v.c >= 0.0f && t.c >= 0.0f) v.c = fmaxf(v.c * decay, t.c);  \
+    sum += fmaxf(v.c, 0.0f);
+        NGP_UPD(x) NGP_UPD(y) NGP_UPD(z) NGP_UPD(w)
+#undef NGP_UPD
+        reinterpret_cast<float4 *>(grid)[i] = v;
+        reinterpret_cast<float4 *>(tmp)[i] = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);   // ready for the next refresh
+    }
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63u) == 0) wave_sum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(stats, wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3]);
+}
+
+// packbits (raymarching.cu:267-289) with thresh = min(mean density, density_thresh) taken from the device
+__global__ __launch_bounds__(256) void packbits_mean_kernel(const float *__restrict__ grid, uint32_t N, float *stats,
+                                                           float inv_cells, float density_thresh,
+                                                           uint8_t *__restrict__ bitfield)
+{
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    const float mean = stats[0] * inv_cells;
+    const float thresh = fminf(mean, density_thresh);
+    if (n == 0) {
+        stats[1] = mean;
+        stats[2] = thresh;
+    }
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2];
+    const float4 b = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2 + 1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;
+    bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;
+    bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;
+    bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;
+    bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" size_t ngp_x_density_grid_workspace_bytes(uint32_t H)
+{
+    const size_t n_words = (size_t)H * H * H / 64;
+    return n_words * 8 + (n_words + 1) * 4 + 64;
+}
+
+extern "C" int ngp_x_density_grid_sample(const float *grid_cas, uint32_t H, float span, float half, uint32_t n_uniform,
+                                         uint32_t n_occupied, int full, uint64_t seed, const uint32_t *draw_dev,
+                                         uint32_t draw, void *workspace, size_t workspace_bytes, int32_t *indices,
+                                         float *xyzs, ngp_stream_t stream)
+{
+    NGP_REQUIRE(grid_cas && workspace && indices && xyzs, "density_grid_sample: null tensor");
+    const uint64_t cells = (uint64_t)H * H * H;
+    NGP_REQUIRE(H >= 4 && H <= 1024 && cells % 64 == 0, "density_grid_sample: H^3 must be a multiple of 64, H <= 1024");
+    NGP_REQUIRE(!full || n_uniform == cells, "density_grid_sample: a full sweep takes n_uniform = H^3");
+    NGP_REQUIRE((uint64_t)n_uniform + n_occupied < (1ull << 31), "density_grid_sample: too many cells");
+    NGP_REQUIRE(workspace_bytes >= ngp_x_density_grid_workspace_bytes(H) && ((uintptr_t)workspace & 7u) == 0,
+                "density_grid_sample: workspace too small or misaligned");
+    const uint32_t n_words = (uint32_t)(cells / 64), n = n_uniform + n_occupied;
+    if (n == 0) return NGP_OK;
+    hipStream_t st = as_stream(stream);
+    const GridWs g = grid_ws(workspace, n_words);
+    if (n_occupied) {
+        grid_positive_mask_kernel<<<dim3(min(ceil_div(n_words, 4u), 2048u)), dim3(256), 0, st>>>(grid_cas, n_words, g);
+        grid_prefix_kernel<<<dim3(1), dim3(1024), 0, st>>>(n_words, g);
+    }
+    grid_sample_cells_kernel<<<dim3(ceil_div(n, 256u)), dim3(256), 0, st>>>(g, n_words, H, span, half, n_uniform, n_occupied,
+                                                                           full != 0, (uint32_t)seed, (uint32_t)(seed >> 32),
+                                                                           draw_dev, draw, indices, xyzs);
+    NGP_CHECK_LAUNCH("density_grid_sample");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_density_grid_scatter(const int32_t *indices, const float *sigmas, uint32_t n, float *tmp_cas,
+                                          ngp_stream_t stream)
+{
+    if (n == 0) return NGP_OK;
+    NGP_REQUIRE(indices && sigmas && tmp_cas, "density_grid_scatter: null tensor");
+    grid_scatter_kernel<<<dim3(ceil_div(n, 256u)), dim3(256), 0, as_stream(stream)>>>(indices, sigmas, n, tmp_cas);
+    NGP_CHECK_LAUNCH("density_grid_scatter");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_density_grid_update(float *grid, float *tmp, uint32_t n_cells, float decay, float *stats,
+                                         ngp_stream_t stream)
+{
+    NGP_REQUIRE(grid && tmp && stats, "density_grid_update: null tensor");
+    NGP_REQUIRE(n_cells % 4 == 0 && (((uintptr_t)grid | (uintptr_t)tmp) & 15u) == 0,
+                "density_grid_update: grids must be 16-byte aligned with a multiple of 4 cells");
+    hipStream_t st = as_stream(stream);
+    NGP_REQUIRE(hipMemsetAsync(stats, 0, 4 * sizeof(float), st) == hipSuccess, "density_grid_update: memset failed");
+    if (n_cells) {
+        grid_update_kernel<<<dim3(min(ceil_div(n_cells / 4, 256u), 1024u)), dim3(256), 0, st>>>(grid, tmp, n_cells / 4,
+                                                                                               decay, stats);
+    }
+    NGP_CHECK_LAUNCH("density_grid_update");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_packbits_mean(const float *grid, uint32_t N, float *stats, float density_thresh, uint8_t *bitfield,
+                                   ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(grid && stats && bitfield, "packbits_mean: null tensor");
+    NGP_REQUIRE(((uintptr_t)grid & 15u) == 0, "packbits_mean: grid must be 16-byte aligned");
+    packbits_mean_kernel<<<dim3(ceil_div(N, 256u)), dim3(256), 0, as_stream(stream)>>>(grid, N, stats, 1.0f / (8.0f * (float)N),
+                                                                                      density_thresh, bitfield);
+    NGP_CHECK_LAUNCH("packbits_mean");
+    return NGP_OK;
+}

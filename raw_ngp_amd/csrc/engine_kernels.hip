@@ -14,6 +14,7 @@
 //   adam                  torch.optim.Adam (main.py:245: eps 1e-15, no weight decay) in one pass
 //   near_far_v2           the torch slab test run_cuda really uses (renderer.py:139-158): /(d + 1e-15), miss -> 1e9
 #include "grid_common.hpp"
+#include "rng_common.hpp"
 
 namespace ngp {
 
@@ -328,25 +329,6 @@ __global__ void schedule_kernel(uint32_t *step_counter, float *hyper, double lr0
 __global__ void counter_add_kernel(uint32_t *counter, uint32_t delta) { counter[0] += delta; }
 
 // ------------------------------------------------------------------ ray batch sampling
-// Philox4x32-10 (Salmon et al., SC'11): counter-based, so a ray's draws depend only on (seed, draw number, ray).
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0;
-        c[1] = lo1;
-        c[2] = n2;
-        c[3] = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
-__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }   // [0,1), 24 bits
-
 // The random_image_batch collate + get_rays + target gather of the harness (nerf/provider.py, nerf/train_utils.py:96-172)
 // as one kernel: every ray draws its own (view, pixel), builds its origin / direction from that view's pose and
 // reads its target colour.  Pixel centre +0.5, camera looks down -z, y flipped, directions not normalised.

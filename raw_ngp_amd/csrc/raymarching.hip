@@ -12,6 +12,7 @@
 // written operation for operation like oracle/ngp_oracle.c so that per-ray sample counts
 // agree bit for bit.
 #include "ngp_common.hpp"
+#include "morton.hpp"
 
 namespace ngp {
 
@@ -20,27 +21,6 @@ constexpr uint32_t kFlatBlock = 256;
 constexpr float kSqrt3 = 1.7320508075688772f;
 constexpr float kRPi = 0.3183098861837907f;
 
-__device__ __forceinline__ uint32_t expand_bits(uint32_t v)
-{
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
-__device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z)
-{
-    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
-}
-__device__ __forceinline__ uint32_t compact_bits(uint32_t x)
-{
-    x &= 0x49249249u;
-    x = (x | (x >> 2)) & 0xc30c30c3u;
-    x = (x | (x >> 4)) & 0x0f00f00fu;
-    x = (x | (x >> 8)) & 0xff0000ffu;
-    x = (x | (x >> 16)) & 0x0000ffffu;
-    return x;
-}
 // frexp exponent clamped to [0, cascades-1]
 __device__ __forceinline__ int mip_of(float mx, float cascades)
 {

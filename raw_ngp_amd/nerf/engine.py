@@ -99,6 +99,17 @@ class FusedTrainer:
         # the main stream's part of a step replayed from captured hipGraphs (one per ray slot)
         self.use_graph = bool(getattr(opt, "capture_graph", True)) and opt.lambda_tv == 0 and dev.type == "cuda"
         self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
+        # density-grid refresh on the device (no host round trips)
+        self.native_refresh = bool(getattr(opt, "native_grid_refresh", True)) and model.grid_size ** 3 % 64 == 0
+        if self.native_refresh:
+            cells = model.grid_size ** 3
+            self.dg_indices = torch.empty(cells, **i32)
+            self.dg_xyzs, self.dg_sigma = torch.empty(cells, 3, **f32), torch.empty(cells, **f32)
+            self.dg_tmp = torch.full_like(model.density_grid, -1.0)
+            self.dg_stats = torch.zeros(4, **f32)
+            self.dg_draw = torch.zeros(1, **i32)
+            self.dg_ws = torch.empty(eb.density_grid_workspace_bytes(model.grid_size), dtype=torch.uint8, device=dev)
+            self.dg_seed = ((seed * 1000) ^ 0x9E3779B97F4A7C15) & (2 ** 64 - 1)     # same on every rank
         self.enc = torch.empty(self.L, cap, 2, **f32)
         self.denc = torch.empty(self.L, cap, 2, **f32)
         self.x01 = torch.empty(cap, 3, **f32)
@@ -169,6 +180,40 @@ class FusedTrainer:
                 self.denc, self.x01, offsets, self.table_grad, cnt, cap, cap, self.L, self.L, self.S, self.H,
                 self.ws_grid)),
         ]
+
+    @torch.no_grad()
+    def refresh_density_grid(self, decay=0.95):
+        """NeRFRenderer.update_extra_state (nerf/renderer.py:811-897) as ~10 launches per cascade with nothing read
+        back: draw the cells (every cell for the first 16 calls, then H^3/4 uniform + H^3/4 occupied ones), evaluate
+        the density there with the slab encoder + the density half of the fused MLP, EMA-max into the grid, re-pack
+        the bitfield with thresh = min(mean, density_thresh)."""
+        m, cap = self.model, self.cap
+        H, cells = m.grid_size, m.grid_size ** 3
+        full = m.iter_density < 16
+        n_uni, n_occ = (cells, 0) if full else (cells // 4, cells // 4)
+        total = n_uni + n_occ
+        offsets = m.grid_encoder.offsets
+        mb.prepare(self.weights, self.mlp_image)
+        for cas in range(m.cascade):
+            bound = min(2 ** cas, m.bound)
+            half = bound / H
+            eb.density_grid_sample(m.density_grid[cas], H, bound - half, half, n_uni, n_occ, full, self.dg_seed,
+                                   self.dg_draw, self.dg_ws, self.dg_indices[:total], self.dg_xyzs[:total])
+            eb.counter_add(self.dg_draw, 1)
+            for s in range(0, total, cap):
+                k = min(cap, total - s)
+                eb.grid_encode_forward_slab(self.dg_xyzs[s:s + k], m.bound, self.table, offsets, self.enc, None, None, k,
+                                            cap, self.L, self.L, self.S, self.H)
+                mb.forward(self.enc, cap, None, None, k, self.mlp_image, self.dg_sigma[s:s + k], None)
+            eb.density_grid_scatter(self.dg_indices[:total], self.dg_sigma[:total], total, self.dg_tmp[cas])
+        eb.density_grid_update(m.density_grid, self.dg_tmp, decay, self.dg_stats)
+        eb.packbits_mean(m.density_grid, self.dg_stats, m.density_thresh, m.density_bitfield)
+        m.iter_density += 1
+        m.bitfield_version = getattr(m, "bitfield_version", 0) + 1
+
+    @property
+    def mean_density(self):
+        return float(self.dg_stats[1]) if self.native_refresh else float(self.model.mean_density)   # host read
 
     def reduce_gradients(self):
         if self.world_size > 1:
@@ -271,9 +316,12 @@ class FusedTrainer:
         model.train()
         step = self.global_step
         if step % opt.update_extra_interval == 0:
-            if self.world_size > 1:
-                torch.manual_seed(1234567 + step)
-            model.update_extra_state()
+            if self.native_refresh:
+                self.refresh_density_grid()
+            else:
+                if self.world_size > 1:
+                    torch.manual_seed(1234567 + step)
+                model.update_extra_state()
         slot = self.slots[step % len(self.slots)]
         if batch is not None or slot.step != step:      # explicit batch, first step, or just after a grid refresh
             self._load_slot(slot, batch, noises)

@@ -13,11 +13,15 @@ def main():
     ap.add_argument("--anchor", default="composite_train_forward", help="kernel launched exactly once per step")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--out", default="")
+    ap.add_argument("--timeline", default="", help="write a per-launch timeline (start, duration, queue, gap) of the "
+                                                   "last --timeline-steps steps to this file")
+    ap.add_argument("--timeline-steps", type=int, default=18)
     args = ap.parse_args()
     rows = []
     with open(args.trace) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                         r.get("Queue_Id", r.get("Stream_Id", "?"))))
     rows.sort()
     anchors = [i for i, r in enumerate(rows) if args.anchor in r[2]]
     if len(anchors) <= args.steps:
@@ -26,7 +30,7 @@ def main():
     last = anchors[-1]
     sel = rows[first:last]
     agg = collections.defaultdict(lambda: [0, 0])
-    for s, e, n in sel:
+    for s, e, n, _ in sel:
         agg[n][0] += 1
         agg[n][1] += e - s
     wall = (rows[last][0] - rows[first][0]) / args.steps / 1e3
@@ -38,11 +42,27 @@ def main():
           f"{sum(v[0] for v in agg.values()) / args.steps:.0f} launches/step")
     for row in out[:40]:
         print(*row, sep=" | ")
+    if args.timeline:
+        timeline(rows, anchors, args.timeline_steps, args.timeline)
     if args.out:
         with open(args.out, "w", newline="") as f:
             w = csv.writer(f)
             w.writerow([f"# last {args.steps} steps: wall {wall:.1f} us/step, kernel-busy {busy:.1f} us/step"])
             w.writerows(out)
+
+
+def timeline(rows, anchors, steps, path):
+    """One line per launch: time since the window start, duration, queue, idle time since the previous launch ended
+    on the same queue."""
+    first = anchors[-steps - 1]
+    t0 = rows[first][0]
+    last_end = {}
+    with open(path, "w") as f:
+        f.write("start_us,dur_us,queue,gap_us,kernel\n")
+        for s, e, n, q in rows[first:anchors[-1]]:
+            gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
+            last_end[q] = max(e, last_end.get(q, 0))
+            f.write(f"{(s - t0) / 1e3:.1f},{(e - s) / 1e3:.1f},{q},{gap:.1f},{n[:60]}\n")
 
 
 if __name__ == "__main__":

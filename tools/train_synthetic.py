@@ -30,13 +30,15 @@ def main():
     ap.add_argument("--arena", type=int, default=0)
     ap.add_argument("--engine", action="store_true", help="fused training step (nerf/engine.py)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--torch-refresh", action="store_true", help="density-grid refresh through torch ops")
     ap.add_argument("--torch-sampler", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     opt = Options(bound=1.0, num_rays=args.rays, iters=args.iters, fp16=args.fp16, fused_mlp=args.fused_mlp,
-                  arena_capacity=args.arena, capture_graph=not args.no_graph, device_sampler=not args.torch_sampler)
+                  arena_capacity=args.arena, capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
+                  native_grid_refresh=not args.torch_refresh)
     t0 = time.time()
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     val = SyntheticDataset(opt, dev, "val", n_views=args.val_views, H=args.res, W=args.res)
@@ -55,7 +57,7 @@ def main():
         dt = time.time() - t1
         done += n
         row = {"iter": done, "loss": float(trainer.last_loss), "samples": int(trainer.last_num_points),
-               "ms_per_step": round(dt / n * 1e3, 3), "mean_density": round(float(model.mean_density), 4)}
+               "ms_per_step": round(dt / n * 1e3, 3), "mean_density": round(float(getattr(trainer, "mean_density", model.mean_density)), 4)}
         hist.append(row)
         print(json.dumps(row), flush=True)
     psnr = trainer.evaluate(val)
