@@ -167,7 +167,12 @@ int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const
                                  const float *nears, const float *fars, const float *noises,
                                  float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
                                  float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
-                                 const uint32_t *occ_index, ngp_stream_t stream);
+                                 const uint32_t *occ_index, float *chain, uint16_t *chain_code, int32_t *chain_len,
+                                 uint32_t chain_cap, ngp_stream_t stream);
+/* chain != NULL selects the chain-parallel first pass (same result, no serial per-ray loop over the grid): chain
+ * [chain_cap, N] f32 and chain_code [chain_cap, N] u16 are scratch, chain_len [N] i32; chain_cap must cover
+ * (far - near) / dt_min + 1 candidate parameters per ray (max_steps * ceil(bound) + 2 always does).  counter then
+ * needs 4 ints: counter[2] becomes non-zero (and stays so) if a ray's chain did not fit. */
 
 /* Compressed copy of the occupancy bitfield that the arena march can keep in LDS (occ_index above; NULL = probe
  * the bitfield in global memory).  The bitfield is Morton-ordered (raymarching.cu:56-81), so 64 consecutive bits

@@ -177,10 +177,25 @@ struct Marcher {
     template <class Occ>
     __device__ __forceinline__ bool probe_with(float &t, float &dt_out, float &px, float &py, float &pz, Occ occupied) const
     {
+        float tt;
+        if (classify(t, dt_out, px, py, pz, tt, occupied)) return true;
+        do {
+            const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+            t += dt;
+        } while (t < tt);
+        return false;
+    }
+
+    // What happens at parameter t: true = a sample starts here (p, dt as in probe); false = the cell is empty and
+    // the ray leaves it at parameter tt (the caller steps t forward until t >= tt).
+    template <class Occ>
+    __device__ __forceinline__ bool classify(float t, float &dt_out, float &px, float &py, float &pz, float &tt,
+                                             Occ occupied) const
+    {
         const float x = clampf(fmaf(t, dx, ox), -bound, bound);
         const float y = clampf(fmaf(t, dy, oy), -bound, bound);
         const float z = clampf(fmaf(t, dz, oz), -bound, bound);
-        float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
 
         const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
         int level = 0;   // one cascade: both mip_of() clamp to 0
@@ -210,11 +225,7 @@ struct Marcher {
         const float tx = fmaf(fmaf(((float)nx + 0.5f + 0.5f * sx) * rH, 2.0f, -1.0f), mip_bound, -cx) * rdx;
         const float ty = fmaf(fmaf(((float)ny + 0.5f + 0.5f * sy) * rH, 2.0f, -1.0f), mip_bound, -cy) * rdy;
         const float tz = fmaf(fmaf(((float)nz + 0.5f + 0.5f * sz) * rH, 2.0f, -1.0f), mip_bound, -cz) * rdz;
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-        do {
-            dt = clampf(t * dt_gamma, dt_min, dt_max);
-            t += dt;
-        } while (t < tt);
+        tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
         return false;
     }
 
@@ -379,6 +390,98 @@ __global__ __launch_bounds__(kFastBlock) void march_count_indexed_kernel(
         }
     }
     rays[(size_t)n * 2 + 1] = (int32_t)step;
+}
+
+// ------------------------------------------------------------------ chain-parallel march (arena pass 1)
+// The reference loop visits parameters t_0, t_1, ... with t_{k+1} = t_k + clamp(t_k * dt_gamma, dt_min, dt_max): the
+// SAME recurrence whether it emits a sample or skips empty space, so a ray's chain of candidate parameters does
+// not depend on the occupancy grid.  Only which elements are visited does: an occupied element is a sample and moves on
+// to the next element; an empty one jumps to the first element >= the exit of its cell.  That splits the march into
+//   chain     lane = ray: generate the chain (one add per element), stored element-major so a wave's stores coalesce
+//   classify  thread = (element, ray): cell lookup + exit parameter -> code[k] = 0 for a sample, else the jump length.
+//             ~2.5 M independent probes on the whole chip instead of ~600 dependent ones on 64 waves
+//   walk      wave = ray: follow the codes through 64-element windows (runs of samples are emitted by all lanes at
+//             once, jumps read one lane) and write the sample start times the expansion kernel consumes
+// Results are identical to the serial loop (same float expressions on the same t values).
+__global__ __launch_bounds__(kRayBlock) void march_chain_kernel(const float *__restrict__ nears,
+                                                               const float *__restrict__ fars,
+                                                               const float *__restrict__ noises, float dt_gamma,
+                                                               float dt_min, float dt_max, uint32_t N, uint32_t chain_cap,
+                                                               float *__restrict__ chain, int32_t *__restrict__ chain_len,
+                                                               int32_t *__restrict__ counter)
+{
+    const uint32_t n = blockIdx.x * kRayBlock + threadIdx.x;
+    if (n >= N) return;
+    const float far = fars[n];
+    float t = nears[n];
+    t = fmaf(clampf(t * dt_gamma, dt_min, dt_max), noises[n], t);
+    uint32_t k = 0;
+    while (t < far && k < chain_cap) {
+        chain[(size_t)k * N + n] = t;
+        t += clampf(t * dt_gamma, dt_min, dt_max);
+        k++;
+    }
+    chain_len[n] = (int32_t)k;
+    if (t < far) atomicOr(counter + 2, 1);   // chain buffer too short: the ray was cut (reported, never silent)
+}
+
+__global__ __launch_bounds__(256) void march_classify_kernel(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid, float bound,
+    bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+    const float *__restrict__ chain, const int32_t *__restrict__ chain_len, uint16_t *__restrict__ code)
+{
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t k = blockIdx.y;
+    if (n >= N) return;
+    const uint32_t len = (uint32_t)chain_len[n];
+    if (k >= len) return;
+    Marcher m;
+    m.setup(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, false, bound, contract, dt_gamma, max_steps, C, H, grid);
+    const float t = chain[(size_t)k * N + n];
+    float dt, px, py, pz, tt;
+    const uint8_t *__restrict__ g = grid;
+    uint32_t c = 0;
+    if (!m.classify(t, dt, px, py, pz, tt, [g](uint32_t bit) { return (g[bit >> 3] >> (bit & 7u)) & 1u; })) {
+        uint32_t j = k + 1;
+        while (j < len && chain[(size_t)j * N + n] < tt) j++;
+        c = j - k;
+    }
+    code[(size_t)k * N + n] = (uint16_t)c;
+}
+
+__global__ __launch_bounds__(256) void march_walk_kernel(const float *__restrict__ chain,
+                                                        const int32_t *__restrict__ chain_len,
+                                                        const uint16_t *__restrict__ code, uint32_t N,
+                                                        uint32_t max_steps, int32_t *__restrict__ rays,
+                                                        float *__restrict__ t_scratch)
+{
+    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t len = (uint32_t)chain_len[n];
+    float *slab = t_scratch + (size_t)n * max_steps;
+    uint32_t k = 0, step = 0;   // wave-uniform
+    while (k < len && step < max_steps) {
+        const uint32_t e = k + lane;
+        const bool have = e < len;
+        const uint32_t c = have ? (uint32_t)code[(size_t)e * N + n] : 0xffffu;
+        const float t = have ? chain[(size_t)e * N + n] : 0.0f;
+        const unsigned long long samples = __ballot(have && c == 0u);
+        uint32_t pos = 0;
+        while (pos < 64u && k + pos < len && step < max_steps) {
+            if ((samples >> pos) & 1ull) {
+                const unsigned long long rest = ~(samples >> pos);
+                uint32_t run = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u - pos;
+                run = min(run, max_steps - step);
+                if (lane >= pos && lane < pos + run) slab[step + (lane - pos)] = t;
+                step += run;
+                pos += run;
+            } else {
+                pos += (uint32_t)__builtin_amdgcn_readlane((int)c, (int)pos);
+            }
+        }
+        k += pos;
+    }
+    if (lane == 0) rays[(size_t)n * 2 + 1] = (int32_t)step;
 }
 
 // Exclusive prefix sum of rays[:,1] into rays[:,0] in ray order; one workgroup of 1024 lanes
@@ -793,14 +896,25 @@ extern "C" int ngp_x_march_rays_train_arena(const float *rays_o, const float *ra
                                             const float *nears, const float *fars, const float *noises,
                                             float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
                                             float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
-                                            const uint32_t *occ_index, ngp_stream_t stream)
+                                            const uint32_t *occ_index, float *chain, uint16_t *chain_code,
+                                            int32_t *chain_len, uint32_t chain_cap, ngp_stream_t stream)
 {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && t_scratch && xyzs && dirs && ts,
                 "march_rays_train_arena: null tensor");
     NGP_REQUIRE(max_steps > 0 && H > 0 && C > 0 && M_cap > 0, "march_rays_train_arena: bad sizes");
     const uint64_t n_bits = (uint64_t)C * H * H * H;
-    if (occ_index) {
+    if (chain) {
+        NGP_REQUIRE(chain_code && chain_len && chain_cap > 0 && chain_cap < 65536u,
+                    "march_rays_train_arena: chain buffers incomplete (chain_cap must be in 1..65535)");
+        const float dt_min = 2.0f * kSqrt3 / (float)max_steps, dt_max = 2.0f * kSqrt3 * bound / (float)H;
+        march_chain_kernel<<<NGP_1D(N, kRayBlock)>>>(nears, fars, noises, dt_gamma, dt_min, dt_max, N, chain_cap, chain,
+                                                    chain_len, counter);
+        march_classify_kernel<<<dim3(ceil_div(N, 256u), chain_cap), dim3(256), 0, as_stream(stream)>>>(
+            rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, chain, chain_len, chain_code);
+        march_walk_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(chain, chain_len, chain_code, N,
+                                                                                     max_steps, rays, t_scratch);
+    } else if (occ_index) {
         NGP_REQUIRE(n_bits % 2048u == 0 && ((uintptr_t)grid & 7u) == 0 && ((uintptr_t)occ_index & 7u) == 0,
                     "march_rays_train_arena: occupancy index needs C*H^3 to be a multiple of 2048 and 8-byte aligned buffers");
         const uint32_t n_groups = (uint32_t)(n_bits / 2048u);

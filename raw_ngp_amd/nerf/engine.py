@@ -28,9 +28,9 @@ from .._lib import raymarching_backend as rb
 class _Slot:
     """One ray batch and everything derived from it before the field is evaluated."""
 
-    def __init__(self, N, max_steps, cap, dev):
+    def __init__(self, N, max_steps, cap, dev, chain_cap=0):
         f32 = dict(dtype=torch.float32, device=dev)
-        self.arena = raymarching.MarchArena(N, max_steps, cap, dev)
+        self.arena = raymarching.MarchArena(N, max_steps, cap, dev, chain_cap=chain_cap)
         self.rays_o, self.rays_d = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32)
         self.gt, self.bg = torch.empty(N, 4, **f32), torch.empty(N, 3, **f32)
         self.noises = torch.empty(N, **f32)
@@ -79,12 +79,18 @@ class FusedTrainer:
         # two ray-batch slots: while step i trains out of one, step i+1's rays are drawn and marched into the
         # other on a second stream (the march is a long, narrow kernel -- 64 waves -- that hides under backward)
         self.prefetch = bool(getattr(opt, "prefetch_march", True)) and dev.type == "cuda"
-        self.slots = [_Slot(N, opt.max_steps, cap, dev) for _ in range(2 if self.prefetch else 1)]
+        # march pass 1: "chain" (all candidate parameters classified in parallel), "index" (serial loop, occupancy
+        # index in LDS) or "serial" (serial loop on the bitfield)
+        self.march_mode = getattr(opt, "march_mode", "chain")
+        chain_cap = opt.max_steps * int(math.ceil(model.real_bound)) + 2 if self.march_mode == "chain" else 0
+        if chain_cap >= 65536:
+            self.march_mode, chain_cap = "index", 0
+        self.slots = [_Slot(N, opt.max_steps, cap, dev, chain_cap) for _ in range(2 if self.prefetch else 1)]
         self.arena = self.slots[0].arena
         self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
         # compressed occupancy bitfield the march keeps in LDS (rebuilt after every density-grid refresh)
         self.occ_index = None
-        if bool(getattr(opt, "lds_march", True)) and (model.cascade * model.grid_size ** 3) % 2048 == 0:
+        if self.march_mode == "index" and (model.cascade * model.grid_size ** 3) % 2048 == 0:
             self.occ_index = torch.zeros(rb.occupancy_index_bytes(model.cascade, model.grid_size) // 4,
                                          dtype=torch.int32, device=dev)
         self._occ_version = None
@@ -142,7 +148,8 @@ class FusedTrainer:
         eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train, N, m.min_near, slot.nears, slot.fars)
         rb.march_rays_train_arena(rays_o, rays_d, None, m.density_bitfield, m.real_bound, opt.contract, opt.dt_gamma,
                                   opt.max_steps, N, m.cascade, m.grid_size, slot.nears, slot.fars, noises, ar.t_scratch,
-                                  self.cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, self.occ_index)
+                                  self.cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, self.occ_index,
+                                  ar.chain)
 
     def forward_backward(self, rays_o, rays_d, gt_rgba, noises, bg_rgb=None, bg_const=0.0):
         """march -> encode -> MLP -> composite -> loss -> backward into self.table_grad / self.w_grad."""

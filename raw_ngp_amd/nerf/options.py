@@ -58,7 +58,7 @@ class Options:
     loss_scale: float = 1024.0    # static loss scale of the fused MLP backward (f16 deltas)
     arena_capacity: int = 0       # > 0: sample arena (no host sync per step); 0 = reference 2-pass protocol
     native_grid_refresh: bool = True  # fused engine: density-grid refresh as device kernels (no host syncs)
-    lds_march: bool = True        # fused engine: march with the compressed occupancy index staged in LDS
+    march_mode: str = "chain"     # fused engine, march pass 1: chain | index | serial (see engine.py)
     device_sampler: bool = True   # fused engine: draw ray batches with one kernel (Philox) instead of torch ops
     capture_graph: bool = True    # fused engine: replay whole steps from captured hipGraphs
     prefetch_march: bool = True   # fused engine: march step i+1's rays on a second stream during step i's backward

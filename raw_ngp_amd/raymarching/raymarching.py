@@ -189,9 +189,15 @@ march_rays_train = _march_rays_train.apply
 class MarchArena:
     """Caller-owned sample arena for `march_rays_train_arena` (fixed capacity, reused every step)."""
 
-    def __init__(self, n_rays, max_steps, capacity, device, with_ldirs=False):
+    def __init__(self, n_rays, max_steps, capacity, device, with_ldirs=False, chain_cap=0):
+        """chain_cap > 0 adds the scratch of the chain-parallel first pass (max_steps * ceil(bound) + 2 is safe)."""
         f32 = dict(dtype=torch.float32, device=device)
         self.n_rays, self.max_steps, self.capacity = n_rays, max_steps, capacity
+        self.chain = None
+        if chain_cap:
+            self.chain = (torch.empty(chain_cap, n_rays, **f32),
+                          torch.empty(chain_cap, n_rays, dtype=torch.int16, device=device),
+                          torch.zeros(n_rays, dtype=torch.int32, device=device))
         self.t_scratch = torch.empty(n_rays * max_steps, **f32)
         self.xyzs = torch.zeros(capacity, 3, **f32)
         self.dirs = torch.zeros(capacity, 3, **f32)
@@ -199,7 +205,7 @@ class MarchArena:
         self.ldirs = torch.zeros(capacity, 3, **f32) if with_ldirs else None
         self.rays = torch.zeros(n_rays, 2, dtype=torch.int32, device=device)
         self.ray_idx = torch.zeros(capacity, dtype=torch.int32, device=device)
-        self.counter = torch.zeros(2, dtype=torch.int32, device=device)   # [written, needed]
+        self.counter = torch.zeros(4, dtype=torch.int32, device=device)   # [written, needed, chain overflow, -]
 
 
 class _march_rays_train_arena(Function):

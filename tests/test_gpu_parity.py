@@ -319,22 +319,26 @@ def test_occupancy_index_is_the_bitfield(be, fill):
     np.testing.assert_array_equal(blocks, words[hot])
 
 
-@pytest.mark.parametrize("indexed", [False, True], ids=["bitfield", "lds-index"])
+@pytest.mark.parametrize("mode", ["bitfield", "lds-index", "chain"])
 @pytest.mark.parametrize("case", MARCH_CASES, ids=lambda c: f"N{c[0]}H{c[1]}C{c[3]}b{c[4]}c{int(c[5])}g{c[6] > 0}")
-def test_march_rays_train_arena(be, orc, case, indexed):
+def test_march_rays_train_arena(be, orc, case, mode):
+    """All three first passes (serial on the bitfield, serial on the LDS index, chain-parallel) against the oracle:
+    counts, ray-ordered offsets, positions and ts bit for bit."""
     N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
     bits, o, d, ld, nears, fars, noises = march_inputs(orc, case, seed=1)
-    index = occupancy_index(be, bits, C, H) if indexed else None
+    index = occupancy_index(be, bits, C, H) if mode == "lds-index" else None
+    chain_cap = max_steps * int(np.ceil(bound)) + 2 if mode == "chain" else 0
     rx, rd, rt, rrays, rl, M = orc.march_rays_train(o, d, ld, bits, bound, contract, dt_gamma, max_steps, C, H, nears,
                                                     fars, noises)
     from raw_ngp_amd.raymarching import MarchArena
     for cap in (M + 1000, max(M // 2, 1)):                          # roomy arena, then one that overflows
-        ar = MarchArena(N, max_steps, cap, "cuda", with_ldirs=ldir)
+        ar = MarchArena(N, max_steps, cap, "cuda", with_ldirs=ldir, chain_cap=chain_cap)
         be.raymarching_backend.march_rays_train_arena(dev(o), dev(d), dev(ld) if ldir else None, dev(bits), bound,
                                                       contract, dt_gamma, max_steps, N, C, H, dev(nears), dev(fars),
                                                       dev(noises), ar.t_scratch, cap, ar.xyzs, ar.dirs, ar.ts,
-                                                      ar.ldirs, ar.rays, ar.counter, ar.ray_idx, index)
-        written, needed = host(ar.counter)
+                                                      ar.ldirs, ar.rays, ar.counter, ar.ray_idx, index, ar.chain)
+        written, needed, chain_overflow = host(ar.counter)[:3]
+        assert chain_overflow == 0
         assert needed == M
         got = host(ar.rays)
         if cap >= M:
@@ -368,6 +372,19 @@ def test_march_arena_index_too_big_for_lds_falls_back_to_bitfield(be, orc):
                                                   ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, index)
     assert int(ar.counter[0]) == M and np.array_equal(host(ar.rays), rrays)
     assert np.array_equal(host(ar.xyzs)[:M], rx) and np.array_equal(host(ar.ts)[:M], rt)
+
+
+def test_march_chain_reports_a_short_chain_buffer(be, orc):
+    case = (512, 64, 256, 1, 1.0, False, 0.0, False)
+    N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
+    bits, o, d, ld, nears, fars, noises = march_inputs(orc, case, seed=3)
+    from raw_ngp_amd.raymarching import MarchArena
+    ar = MarchArena(N, max_steps, 1 << 20, "cuda", chain_cap=40)          # rays need up to ~256 candidates
+    be.raymarching_backend.march_rays_train_arena(dev(o), dev(d), None, dev(bits), bound, contract, dt_gamma, max_steps,
+                                                  N, C, H, dev(nears), dev(fars), dev(noises), ar.t_scratch, 1 << 20,
+                                                  ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, None, ar.chain)
+    assert int(ar.counter[2]) == 1
+    assert int(host(ar.rays)[:, 1].max()) <= 40
 
 
 def test_march_empty_inputs(be, orc):
