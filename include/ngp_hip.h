@@ -201,6 +201,21 @@ int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, co
                                       uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
                                       void *workspace, size_t workspace_bytes, ngp_stream_t stream);
 
+/* The same call in two halves, so the positions-only half can run early (e.g. on another stream, while the
+ * forward pass is still running): `prepare` = plan + count + scan, reads only the sample positions -- in [0,1] when
+ * in_bound = 0, world positions in [-in_bound, in_bound] (mapped like gridencoder/grid.py:161) otherwise;
+ * `apply` = fill + reduce on the prepared workspace with the [0,1] inputs and the same B_dev value. */
+int ngp_x_grid_backward_binned_prepare(const float *inputs, float in_bound, const int32_t *offsets, const int32_t *B_dev,
+                                       uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                       uint32_t gridtype, int align_corners, uint32_t interp, uint32_t n_rows_total,
+                                       uint32_t max_level_rows, void *workspace, size_t workspace_bytes,
+                                       ngp_stream_t stream);
+int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, const int32_t *offsets,
+                                     float *grad_embeddings, const int32_t *B_dev, uint32_t B, uint32_t grad_stride,
+                                     uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                     int align_corners, uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
+                                     void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+
 /* grad_inputs[b, d] = sum_{l, ch} grad[l, b, ch] * dy_dx[b, l, d, ch] -- the second half of
  * ngp_grid_encode_backward (gridencoder.cu:352-378) on its own. */
 int ngp_x_grid_input_backward(const float *grad, const float *dy_dx, float *grad_inputs, uint32_t B, uint32_t D,
@@ -283,11 +298,20 @@ int ngp_x_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq
  * from a captured graph. */
 int ngp_x_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, const float *hyper,
                         float beta1, float beta2, float eps, int zero_grad, ngp_stream_t stream);
+/* Two parameter tensors in one launch (the hash table and the flat MLP weights). */
+int ngp_x_adam_step_dev2(float *param_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a, uint64_t n_a,
+                         int zero_grad_a, float *param_b, float *grad_b, float *exp_avg_b, float *exp_avg_sq_b,
+                         uint64_t n_b, int zero_grad_b, const float *hyper, float beta1, float beta2, float eps,
+                         ngp_stream_t stream);
 
 /* Device-side scheduler: t = step_counter[0] steps are done; writes hyper = {lr0 * 0.1^min(t/decay_steps, 1)
  * (the LambdaLR of main.py:261), 1 - beta1^(t+1), 1/sqrt(1 - beta2^(t+1))} and increments the counter. */
 int ngp_x_schedule_step(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1,
                         double beta2, ngp_stream_t stream);
+/* ... plus the other per-step scalars of the training step in the same launch: loss_out[0] = 0 (the compositor's
+ * backward accumulates into it) and samples_seen[0] += sample_counter[0]; each pair may be NULL. */
+int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1, double beta2,
+                     float *loss_out, int64_t *samples_seen, const int32_t *sample_counter, ngp_stream_t stream);
 
 /* counter[0] += delta, stream-ordered. */
 int ngp_x_counter_add(uint32_t *counter, uint32_t delta, ngp_stream_t stream);

@@ -43,6 +43,9 @@ _SIGNATURES = {
     "ngp_composite_rays": [_u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _p],
     "ngp_x_grid_encode_backward_binned": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
                                           ctypes.c_size_t],
+    "ngp_x_grid_backward_binned_prepare": [_p, _f, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p, ctypes.c_size_t],
+    "ngp_x_grid_backward_binned_apply": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
+                                         ctypes.c_size_t],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
@@ -55,6 +58,8 @@ _SIGNATURES = {
     "ngp_x_near_far_from_aabb_v2": [_p, _p, _p, _u, _f, _p, _p],
     "ngp_x_adam_step_dev": [_p, _p, _p, _p, ctypes.c_uint64, _p, _f, _f, _f, _i],
     "ngp_x_schedule_step": [_p, _p, _d, _d, _d, _d],
+    "ngp_x_step_begin": [_p, _p, _d, _d, _d, _d, _p, _p, _p],
+    "ngp_x_adam_step_dev2": [_p, _p, _p, _p, ctypes.c_uint64, _i, _p, _p, _p, _p, ctypes.c_uint64, _i, _p, _f, _f, _f],
     "ngp_x_counter_add": [_p, _u],
     "ngp_x_sample_rays": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p],
     "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
@@ -127,15 +132,20 @@ def _ptr(t, kind, name, optional=False):
 # C symbol, plus the value of one integer argument (the number of samples the launch processes).  Events cannot be
 # timed inside a captured graph, so the fused engine keeps the probed entry point out of its graphs (it asks
 # `probed_symbol()` when it captures).
-_probe = {"name": None, "arg": 0, "events": []}
+_probe = {"names": (), "arg": 0, "events": []}
 
 
-def set_probe(name, units_arg=0):
-    _probe["name"], _probe["arg"], _probe["events"] = name, units_arg, []
+def set_probe(names, units_arg=0):
+    """names: one C symbol or a tuple of them (e.g. the two halves of one operation); units_arg applies to the first."""
+    if names is None:
+        names = ()
+    elif isinstance(names, str):
+        names = (names,)
+    _probe["names"], _probe["arg"], _probe["events"] = tuple(names), units_arg, []
 
 
-def probed_symbol():
-    return _probe["name"]
+def probed_symbols():
+    return _probe["names"]
 
 
 def probe_reset():
@@ -144,16 +154,18 @@ def probe_reset():
 
 
 def probe_results():
-    """(launches, total units, total seconds) of the probed symbol since set_probe() / probe_reset()."""
+    """(launches of the first symbol, its total units, seconds summed over all probed symbols) since set_probe() /
+    probe_reset()."""
     torch.cuda.synchronize()
-    ev = _probe["events"]
-    return len(ev), sum(u for _, _, u in ev), sum(a.elapsed_time(b) for a, b, _ in ev) * 1e-3
+    ev, first = _probe["events"], (_probe["names"] or (None,))[0]
+    return (sum(1 for n, *_ in ev if n == first), sum(u for n, _, _, u in ev if n == first),
+            sum(a.elapsed_time(b) for _, a, b, _ in ev) * 1e-3)
 
 
 def _call(name, anchor, *args):
     lib = load()
     dev = anchor.device
-    probing = _probe["name"] == name
+    probing = name in _probe["names"]
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
         if probing:
@@ -164,7 +176,8 @@ def _call(name, anchor, *args):
         rc = getattr(lib, name)(*args, stream.cuda_stream)
         if probing:
             stop.record(stream)
-            _probe["events"].append((start, stop, int(args[_probe["arg"]])))
+            units = int(args[_probe["arg"]]) if name == _probe["names"][0] else 0
+            _probe["events"].append((name, start, stop, units))
     if rc != 0:
         raise RuntimeError(lib.ngp_last_error().decode())
 
@@ -220,6 +233,25 @@ class _GridBackend:
                              workspace, gridtype=0, align_corners=False, interp=0):
         """Extension entry for the fused step: caller-owned workspace, live count read from the device."""
         _call("ngp_x_grid_encode_backward_binned", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
+              _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings"),
+              _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
+              int(bool(align_corners)), interp, grad_embeddings.shape[0], _GridBackend._max_level_rows(offsets),
+              workspace.data_ptr(), workspace.numel())
+
+    @staticmethod
+    def grid_backward_binned_prepare(inputs, in_bound, offsets, n_rows, B_dev, B_cap, L, max_level, S, H, workspace,
+                                     gridtype=0, align_corners=False, interp=0):
+        """Positions-only half (plan, count, scan).  in_bound > 0: `inputs` are world positions."""
+        _call("ngp_x_grid_backward_binned_prepare", inputs, _ptr(inputs, "f", "inputs"), float(in_bound),
+              _ptr(offsets, "i", "offsets"), _ptr(B_dev, "i", "B_dev", True), B_cap, L, max_level, float(S), H, gridtype,
+              int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets), workspace.data_ptr(),
+              workspace.numel())
+
+    @staticmethod
+    def grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
+                                   workspace, gridtype=0, align_corners=False, interp=0):
+        """Fill + reduce on a workspace prepared for the same positions."""
+        _call("ngp_x_grid_backward_binned_apply", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
               _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings"),
               _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
               int(bool(align_corners)), interp, grad_embeddings.shape[0], _GridBackend._max_level_rows(offsets),
@@ -472,6 +504,25 @@ class _EngineBackend:
     def schedule_step(step_counter, hyper, lr0, decay_steps, beta1, beta2):
         _call("ngp_x_schedule_step", hyper, _ptr(step_counter, "u", "step_counter"), _ptr(hyper, "f", "hyper"),
               float(lr0), float(decay_steps), float(beta1), float(beta2))
+
+    @staticmethod
+    def step_begin(step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out=None, samples_seen=None,
+                   sample_counter=None):
+        if samples_seen is not None and (samples_seen.dtype != torch.int64 or not samples_seen.is_cuda):
+            raise RuntimeError("samples_seen must be an int64 CUDA tensor")
+        _call("ngp_x_step_begin", hyper, _ptr(step_counter, "u", "step_counter"), _ptr(hyper, "f", "hyper"), float(lr0),
+              float(decay_steps), float(beta1), float(beta2), _ptr(loss_out, "f", "loss_out", True),
+              samples_seen.data_ptr() if samples_seen is not None else None,
+              _ptr(sample_counter, "i", "sample_counter", True))
+
+    @staticmethod
+    def adam_step_dev2(a, b, hyper, beta1, beta2, eps):
+        """a, b = (param, grad, exp_avg, exp_avg_sq, zero_grad) of two tensors updated by one launch."""
+        args = []
+        for name, (p_, g_, m_, v_, z_) in (("a", a), ("b", b)):
+            args += [_ptr(p_, "f", f"param_{name}"), _ptr(g_, "f", f"grad_{name}"), _ptr(m_, "f", f"exp_avg_{name}"),
+                     _ptr(v_, "f", f"exp_avg_sq_{name}"), p_.numel(), int(bool(z_))]
+        _call("ngp_x_adam_step_dev2", hyper, *args, _ptr(hyper, "f", "hyper"), float(beta1), float(beta2), float(eps))
 
     @staticmethod
     def counter_add(counter, delta=1):

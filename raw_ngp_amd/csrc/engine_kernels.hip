@@ -45,24 +45,44 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
         *dst = make_float2(0.f, 0.f);
         return;
     }
+    // The gathers are bound by the address pipeline (one lane per clock), not by bytes: fetch the two x-neighbours of a
+    // corner pair with ONE 16-byte load whenever their rows are adjacent -- always on dense levels (stride 1 along x),
+    // and on hashed levels when the cell's x is even (prime_x = 1, so the two hashes differ in bit 0 only).
     Row<2> rows[8];
     float wts[8];
+    const uint32_t x0 = cl.c[0], x1 = min(cl.c[0] + 1u, g.res - 1u);
 #pragma unroll
-    for (uint32_t corner = 0; corner < 8; corner++) {
-        float w = 1.0f;
+    for (uint32_t yz = 0; yz < 4; yz++) {
         uint32_t c[3];
 #pragma unroll
-        for (uint32_t d = 0; d < 3; d++) {
-            if (corner & (1u << d)) {
-                w *= cl.f[d];
-                c[d] = min(cl.c[d] + 1u, g.res - 1u);
-            } else {
-                w *= 1.0f - cl.f[d];
-                c[d] = cl.c[d];
-            }
+        for (uint32_t d = 1; d < 3; d++) c[d] = (yz & (1u << (d - 1))) ? min(cl.c[d] + 1u, g.res - 1u) : cl.c[d];
+        c[0] = x0;
+        const uint32_t ra = row_of<3>(g, c);
+        c[0] = x1;
+        const uint32_t rb = row_of<3>(g, c);
+        // weights in the reference's multiplication order: x factor first
+        float wa = 1.0f - cl.f[0], wb = cl.f[0];
+#pragma unroll
+        for (uint32_t d = 1; d < 3; d++) {
+            const float f = (yz & (1u << (d - 1))) ? cl.f[d] : 1.0f - cl.f[d];
+            wa *= f;
+            wb *= f;
         }
-        wts[corner] = w;
-        rows[corner].load(tab + (size_t)row_of<3>(g, c) * 2);
+        const uint32_t ca = yz * 2u, cb = yz * 2u + 1u;
+        wts[ca] = wa;
+        wts[cb] = wb;
+        if (rb == ra + 1u || ra == rb + 1u) {
+            const uint32_t lo = min(ra, rb);
+            const float4 v = *reinterpret_cast<const float4 *>(tab + (size_t)lo * 2);
+            const bool a_first = ra < rb;
+            rows[ca].v[0] = a_first ? v.x : v.z;
+            rows[ca].v[1] = a_first ? v.y : v.w;
+            rows[cb].v[0] = a_first ? v.z : v.x;
+            rows[cb].v[1] = a_first ? v.w : v.y;
+        } else {
+            rows[ca].load(tab + (size_t)ra * 2);
+            rows[cb].load(tab + (size_t)rb * 2);
+        }
     }
     float ax = 0.f, ay = 0.f;
 #pragma unroll
@@ -276,18 +296,12 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
 // ------------------------------------------------------------------ Adam
 // torch.optim.Adam(step): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 //                         p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),  bc_i = 1 - b_i^step
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *g, float *__restrict__ m,
-                                                   float *__restrict__ v, size_t n4, size_t n, float lr, float b1,
-                                                   float b2, float eps, float bc1, float rsqrt_bc2, bool zero_grad,
-                                                   float *g_mut, const float *__restrict__ hyper)
+__device__ __forceinline__ void adam_span(float *__restrict__ p, const float *g, float *__restrict__ m,
+                                          float *__restrict__ v, size_t n4, size_t n, float lr, float b1, float b2,
+                                          float eps, float bc1, float rsqrt_bc2, bool zero_grad, float *g_mut, size_t tid,
+                                          size_t nthreads)
 {
-    if (hyper) {   // {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)} written by schedule_kernel earlier on this stream
-        lr = hyper[0];
-        bc1 = hyper[1];
-        rsqrt_bc2 = hyper[2];
-    }
     const float step_size = lr / bc1;
-    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
     for (size_t i = tid; i < n4; i += nthreads) {
         float4 pp = reinterpret_cast<float4 *>(p)[i];
         const float4 gg = reinterpret_cast<const float4 *>(g)[i];
@@ -312,6 +326,37 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
 }
 
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *g, float *__restrict__ m,
+                                                   float *__restrict__ v, size_t n4, size_t n, float lr, float b1,
+                                                   float b2, float eps, float bc1, float rsqrt_bc2, bool zero_grad,
+                                                   float *g_mut, const float *__restrict__ hyper)
+{
+    if (hyper) {   // {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)} written by schedule_kernel earlier on this stream
+        lr = hyper[0];
+        bc1 = hyper[1];
+        rsqrt_bc2 = hyper[2];
+    }
+    adam_span(p, g, m, v, n4, n, lr, b1, b2, eps, bc1, rsqrt_bc2, zero_grad, g_mut, (size_t)blockIdx.x * 256 + threadIdx.x,
+              (size_t)gridDim.x * 256);
+}
+
+struct AdamTensor {
+    float *p, *g, *m, *v;
+    size_t n;
+    bool zero_grad;
+};
+
+// blocks [0, blocks_a) update tensor a, the rest tensor b
+__global__ __launch_bounds__(256) void adam2_kernel(AdamTensor a, AdamTensor b, uint32_t blocks_a, float b1, float b2,
+                                                    float eps, const float *__restrict__ hyper)
+{
+    const bool first = blockIdx.x < blocks_a;
+    const AdamTensor t = first ? a : b;
+    const uint32_t blk = first ? blockIdx.x : blockIdx.x - blocks_a, nblk = first ? blocks_a : gridDim.x - blocks_a;
+    adam_span(t.p, t.g, t.m, t.v, t.n / 4, t.n, hyper[0], b1, b2, eps, hyper[1], hyper[2], t.zero_grad, t.g,
+              (size_t)blk * 256 + threadIdx.x, (size_t)nblk * 256);
+}
+
 // ------------------------------------------------------------------ step state on the device
 // The harness' scheduler (main.py:261: lr = lr0 * 0.1^min(step/iters, 1)) and Adam's bias corrections, kept on the
 // device so that a captured step never needs a host-supplied scalar.
@@ -327,6 +372,20 @@ __global__ void schedule_kernel(uint32_t *step_counter, float *hyper, double lr0
 }
 
 __global__ void counter_add_kernel(uint32_t *counter, uint32_t delta) { counter[0] += delta; }
+
+__global__ void step_begin_kernel(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double b1, double b2,
+                                  float *loss_out, long long *samples_seen, const int32_t *sample_counter)
+{
+    const uint32_t done = step_counter[0];
+    const double t = (double)done + 1.0;
+    const double frac = fmin((double)done / decay_steps, 1.0);
+    hyper[0] = (float)(lr0 * pow(0.1, frac));
+    hyper[1] = (float)(1.0 - pow(b1, t));
+    hyper[2] = (float)(1.0 / sqrt(1.0 - pow(b2, t)));
+    step_counter[0] = done + 1u;
+    if (loss_out) loss_out[0] = 0.0f;
+    if (samples_seen && sample_counter) samples_seen[0] += (long long)sample_counter[0];
+}
 
 // ------------------------------------------------------------------ ray batch sampling
 // The random_image_batch collate + get_rays + target gather of the harness (nerf/provider.py, nerf/train_utils.py:96-172)
@@ -504,6 +563,39 @@ extern "C" int ngp_x_schedule_step(uint32_t *step_counter, float *hyper, double 
     NGP_REQUIRE(decay_steps > 0.0, "schedule_step: decay_steps must be positive");
     schedule_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(step_counter, hyper, lr0, decay_steps, beta1, beta2);
     NGP_CHECK_LAUNCH("schedule_step");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1,
+                                double beta2, float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
+                                ngp_stream_t stream)
+{
+    NGP_REQUIRE(step_counter && hyper, "step_begin: null tensor");
+    NGP_REQUIRE(decay_steps > 0.0, "step_begin: decay_steps must be positive");
+    NGP_REQUIRE((samples_seen == nullptr) == (sample_counter == nullptr), "step_begin: samples_seen and sample_counter go together");
+    step_begin_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out,
+                                                                  reinterpret_cast<long long *>(samples_seen), sample_counter);
+    NGP_CHECK_LAUNCH("step_begin");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_adam_step_dev2(float *param_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a, uint64_t n_a,
+                                    int zero_grad_a, float *param_b, float *grad_b, float *exp_avg_b,
+                                    float *exp_avg_sq_b, uint64_t n_b, int zero_grad_b, const float *hyper, float beta1,
+                                    float beta2, float eps, ngp_stream_t stream)
+{
+    NGP_REQUIRE(n_a > 0 && n_b > 0, "adam_step_dev2: empty tensor (use adam_step_dev)");
+    NGP_REQUIRE(param_a && grad_a && exp_avg_a && exp_avg_sq_a && param_b && grad_b && exp_avg_b && exp_avg_sq_b && hyper,
+                "adam_step_dev2: null tensor");
+    NGP_REQUIRE((((uintptr_t)param_a | (uintptr_t)grad_a | (uintptr_t)exp_avg_a | (uintptr_t)exp_avg_sq_a |
+                  (uintptr_t)param_b | (uintptr_t)grad_b | (uintptr_t)exp_avg_b | (uintptr_t)exp_avg_sq_b) & 15u) == 0,
+                "adam_step_dev2: tensors must be 16-byte aligned");
+    const auto blocks_for = [](uint64_t n) { return (uint32_t)min((size_t)256 * 8, (size_t)(n / 4 + 255) / 256 + 1); };
+    const uint32_t ba = blocks_for(n_a), bb = blocks_for(n_b);
+    const AdamTensor a{param_a, grad_a, exp_avg_a, exp_avg_sq_a, (size_t)n_a, zero_grad_a != 0};
+    const AdamTensor b{param_b, grad_b, exp_avg_b, exp_avg_sq_b, (size_t)n_b, zero_grad_b != 0};
+    adam2_kernel<<<dim3(ba + bb), dim3(256), 0, as_stream(stream)>>>(a, b, ba, beta1, beta2, eps, hyper);
+    NGP_CHECK_LAUNCH("adam_step_dev2");
     return NGP_OK;
 }
 

@@ -98,12 +98,17 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const int32_t *__restric
 
 // ------------------------------------------------------------------ shared traversal piece
 // rows of the 8 corners of sample b at one level; false when the sample is outside [0,1]^3
+// in_bound > 0: `inputs` are world positions in [-in_bound, in_bound], mapped like the encoder does (grid.py:161)
 __device__ __forceinline__ bool corner_rows(const float *__restrict__ inputs, uint32_t b, const Geom<3> &g,
-                                            bool align_corners, uint32_t interp, Cell<3> &cl, uint32_t (&rows)[8])
+                                            bool align_corners, uint32_t interp, Cell<3> &cl, uint32_t (&rows)[8],
+                                            float in_bound = 0.0f)
 {
     float x[3];
 #pragma unroll
-    for (uint32_t d = 0; d < 3; d++) x[d] = inputs[(size_t)b * 3 + d];
+    for (uint32_t d = 0; d < 3; d++) {
+        x[d] = inputs[(size_t)b * 3 + d];
+        if (in_bound > 0.0f) x[d] = (x[d] + in_bound) / (2.0f * in_bound);
+    }
     if (!locate<3>(x, g.res, align_corners, interp, cl)) return false;
 #pragma unroll
     for (uint32_t corner = 0; corner < 8; corner++) {
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restri
                                                           const int32_t *__restrict__ offsets,
                                                           const int32_t *__restrict__ B_dev, uint32_t B_cap,
                                                           uint32_t ntiles, LevelRes lv, uint32_t gridtype,
-                                                          bool align_corners, uint32_t interp, WsLayout w)
+                                                          bool align_corners, uint32_t interp, float in_bound, WsLayout w)
 {
     extern __shared__ uint32_t hist[];
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restri
         if (b0 + k * kBlock >= B) break;                 // uniform
         Cell<3> cl;
         uint32_t rows[8];
-        const bool live = b < B && corner_rows(inputs, b, g, align_corners, interp, cl, rows);
+        const bool live = b < B && corner_rows(inputs, b, g, align_corners, interp, cl, rows, in_bound);
         bool emit = live;
         if (merge) {
             uint32_t dist;
@@ -477,6 +482,92 @@ extern "C" size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, ui
     return ws_bytes(B, L, n_chunks_max);
 }
 
+namespace {
+struct BinnedCall {
+    LevelRes lv;
+    WsLayout w;
+    uint32_t n_chunks_max, nbins_cap;
+    size_t fill_lds;
+};
+
+// shared argument checks of the three entry points; returns NGP_OK or the error code (message already set)
+int binned_setup(BinnedCall &c, const char *who, const int32_t *offsets, uint32_t B, uint32_t L, uint32_t max_level, float S,
+                 uint32_t H, uint32_t n_rows_total, uint32_t max_level_rows, void *workspace, size_t workspace_bytes)
+{
+    NGP_REQUIRE(offsets && workspace, "%s: null tensor", who);
+    NGP_REQUIRE(fill_levels(c.lv, S, H, L), "%s: L must be in [1, %u]", who, kMaxLevels);
+    NGP_REQUIRE(max_level <= L, "%s: max_level > L", who);
+    NGP_REQUIRE(((uintptr_t)workspace & 15u) == 0, "%s: workspace must be 16-byte aligned", who);
+    c.n_chunks_max = n_rows_total / kChunkRows + L + 1;
+    NGP_REQUIRE(workspace_bytes >= ws_bytes(B, L, c.n_chunks_max), "%s: workspace too small", who);
+    NGP_REQUIRE((uint64_t)B * L * 8 + 4ull * c.n_chunks_max < (1ull << 32), "%s: B * L too large", who);
+    NGP_REQUIRE(c.n_chunks_max <= kMaxChunks, "%s: table too large (> %u chunks)", who, kMaxChunks);
+    c.w = ws_layout(workspace, c.n_chunks_max);
+    // LDS histograms are per level: the caller may tell us the largest level (rows); 0 = unknown
+    NGP_REQUIRE(max_level_rows <= n_rows_total, "%s: max_level_rows > n_rows_total", who);
+    const uint32_t level_chunks = max_level_rows ? ceil_div(max_level_rows, kChunkRows) : c.n_chunks_max;
+    c.nbins_cap = (level_chunks + 3u) & ~3u;
+    c.fill_lds = (size_t)c.nbins_cap * 12 + (size_t)kFillTile * 8 * sizeof(StageRec);
+    return NGP_OK;
+}
+}  // namespace
+
+// positions only: plan + count + scan.  in_bound > 0: `inputs` are world positions (the encoder's [0,1] mapping is
+// applied here), so this half can run as soon as the samples exist -- e.g. on another stream, before the forward pass
+extern "C" int ngp_x_grid_backward_binned_prepare(const float *inputs, float in_bound, const int32_t *offsets,
+                                                  const int32_t *B_dev, uint32_t B, uint32_t L, uint32_t max_level,
+                                                  float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                                  uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
+                                                  void *workspace, size_t workspace_bytes, ngp_stream_t stream)
+{
+    if (B == 0 || max_level == 0) return NGP_OK;
+    NGP_REQUIRE(inputs, "grid_backward_binned_prepare: null tensor");
+    BinnedCall c;
+    const int rc = binned_setup(c, "grid_backward_binned_prepare", offsets, B, L, max_level, S, H, n_rows_total,
+                                max_level_rows, workspace, workspace_bytes);
+    if (rc != NGP_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    bin_plan_kernel<<<1, 1024, 0, st>>>(offsets, L, c.n_chunks_max, c.w);
+    const uint32_t ct = ceil_div(B, kCountTile);
+    bin_count_kernel<<<ct * max_level, kBlock, (size_t)c.nbins_cap * 4, st>>>(inputs, offsets, B_dev, B, ct, c.lv, gridtype,
+                                                                                align_corners != 0, interp, in_bound, c.w);
+    bin_scan_kernel<<<1, 1024, 0, st>>>(L, c.w);
+    NGP_CHECK_LAUNCH("grid_backward_binned_prepare");
+    return NGP_OK;
+}
+
+// fill + reduce on a prepared workspace (same inputs, in [0,1], and the same B_dev value as the prepare call)
+extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, const int32_t *offsets,
+                                                float *grad_embeddings, const int32_t *B_dev, uint32_t B,
+                                                uint32_t grad_stride, uint32_t L, uint32_t max_level, float S,
+                                                uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
+                                                size_t workspace_bytes, ngp_stream_t stream)
+{
+    if (B == 0 || max_level == 0) return NGP_OK;
+    NGP_REQUIRE(grad && inputs && grad_embeddings, "grid_backward_binned_apply: null tensor");
+    NGP_REQUIRE(grad_stride >= B, "grid_backward_binned_apply: grad_stride smaller than B");
+    BinnedCall c;
+    const int rc = binned_setup(c, "grid_backward_binned_apply", offsets, B, L, max_level, S, H, n_rows_total,
+                                max_level_rows, workspace, workspace_bytes);
+    if (rc != NGP_OK) return rc;
+    static const bool lds_ok = [] {   // the fill kernel wants more than the default 64 KiB of dynamic LDS
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(bin_fill_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kMaxChunks * 12 + kFillTile * 8 * sizeof(StageRec)) == hipSuccess;
+    }();
+    NGP_REQUIRE(lds_ok, "grid_backward_binned_apply: cannot raise the dynamic LDS limit");
+    hipStream_t st = as_stream(stream);
+    const uint32_t ft = ceil_div(B, kFillTile);
+    bin_fill_kernel<<<ft * max_level, kFillBlock, c.fill_lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft,
+                                                                   c.nbins_cap, c.lv, gridtype, align_corners != 0, interp,
+                                                                   c.w);
+    const uint32_t n_items_max = c.n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
+    bin_reduce_kernel<<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w);
+    NGP_CHECK_LAUNCH("grid_backward_binned_apply");
+    return NGP_OK;
+}
+
 extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,
                                                  float *grad_embeddings, const int32_t *B_dev, uint32_t B,
                                                  uint32_t grad_stride, uint32_t L, uint32_t max_level,
@@ -484,43 +575,11 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
                                                  uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
                                                  void *workspace, size_t workspace_bytes, ngp_stream_t stream)
 {
-    if (B == 0 || max_level == 0) return NGP_OK;
-    NGP_REQUIRE(grad && inputs && offsets && grad_embeddings && workspace, "grid_encode_backward_binned: null tensor");
-    LevelRes lv;
-    NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_backward_binned: L must be in [1, %u]", kMaxLevels);
-    NGP_REQUIRE(max_level <= L, "grid_encode_backward_binned: max_level > L");
-    NGP_REQUIRE(grad_stride >= B, "grid_encode_backward_binned: grad_stride smaller than B");
-    NGP_REQUIRE(((uintptr_t)workspace & 15u) == 0, "grid_encode_backward_binned: workspace must be 16-byte aligned");
-    const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
-    NGP_REQUIRE(workspace_bytes >= ws_bytes(B, L, n_chunks_max), "grid_encode_backward_binned: workspace too small");
-    NGP_REQUIRE((uint64_t)B * L * 8 + 4ull * n_chunks_max < (1ull << 32), "grid_encode_backward_binned: B * L too large");
-    NGP_REQUIRE(n_chunks_max <= kMaxChunks, "grid_encode_backward_binned: table too large (> %u chunks)", kMaxChunks);
-    hipStream_t st = as_stream(stream);
-    const WsLayout w = ws_layout(workspace, n_chunks_max);
-    const bool align = align_corners != 0;
-    // LDS histograms are per level: the caller may tell us the largest level (rows); 0 = unknown
-    NGP_REQUIRE(max_level_rows <= n_rows_total, "grid_encode_backward_binned: max_level_rows > n_rows_total");
-    const uint32_t level_chunks = max_level_rows ? ceil_div(max_level_rows, kChunkRows) : n_chunks_max;
-    const uint32_t nbins_cap = (level_chunks + 3u) & ~3u;
-    const size_t fill_lds = (size_t)nbins_cap * 12 + (size_t)kFillTile * 8 * sizeof(StageRec);
-    static const bool lds_ok = [] {   // the fill kernel wants more than the default 64 KiB of dynamic LDS
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(bin_fill_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kMaxChunks * 12 + kFillTile * 8 * sizeof(StageRec)) ==
-               hipSuccess;
-    }();
-    NGP_REQUIRE(lds_ok, "grid_encode_backward_binned: cannot raise the dynamic LDS limit");
-
-    bin_plan_kernel<<<1, 1024, 0, st>>>(offsets, L, n_chunks_max, w);
-    const uint32_t ct = ceil_div(B, kCountTile);
-    bin_count_kernel<<<ct * max_level, kBlock, (size_t)nbins_cap * 4, st>>>(inputs, offsets, B_dev, B, ct, lv, gridtype,
-                                                                              align, interp, w);
-    bin_scan_kernel<<<1, 1024, 0, st>>>(L, w);
-    const uint32_t ft = ceil_div(B, kFillTile);
-    bin_fill_kernel<<<ft * max_level, kFillBlock, fill_lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft, nbins_cap, lv, gridtype,
-                                                             align, interp, w);
-    const uint32_t n_items_max = n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
-    bin_reduce_kernel<<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, w);
-    NGP_CHECK_LAUNCH("grid_encode_backward_binned");
-    return NGP_OK;
+    const int rc = ngp_x_grid_backward_binned_prepare(inputs, 0.0f, offsets, B_dev, B, L, max_level, S, H, gridtype,
+                                                      align_corners, interp, n_rows_total, max_level_rows, workspace,
+                                                      workspace_bytes, stream);
+    if (rc != NGP_OK) return rc;
+    return ngp_x_grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L, max_level, S, H,
+                                            gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
+                                            workspace_bytes, stream);
 }

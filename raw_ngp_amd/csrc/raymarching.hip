@@ -415,13 +415,29 @@ __global__ __launch_bounds__(kRayBlock) void march_chain_kernel(const float *__r
     const float far = fars[n];
     float t = nears[n];
     t = fmaf(clampf(t * dt_gamma, dt_min, dt_max), noises[n], t);
-    uint32_t k = 0;
-    while (t < far && k < chain_cap) {
+    // A lone wave pays ~8 cycles per instruction, so the loop is unrolled 8x with the exit test once per group:
+    // elements past a lane's end are still stored (never read: consumers stop at chain_len) and its length is the
+    // number of elements that were < far, which is the same thing because t only grows.
+    uint32_t len = 0, k = 0;
+    float *p = chain + n;
+    const size_t stride = N;
+    while (k + 8u <= chain_cap && __any(t < far)) {
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            p[(size_t)u * stride] = t;
+            len += t < far ? 1u : 0u;
+            t += clampf(t * dt_gamma, dt_min, dt_max);
+        }
+        p += 8u * stride;
+        k += 8u;
+    }
+    while (t < far && k < chain_cap) {   // fewer than 8 slots left in the buffer
         chain[(size_t)k * N + n] = t;
+        len++;
         t += clampf(t * dt_gamma, dt_min, dt_max);
         k++;
     }
-    chain_len[n] = (int32_t)k;
+    chain_len[n] = (int32_t)len;
     if (t < far) atomicOr(counter + 2, 1);   // chain buffer too short: the ray was cut (reported, never silent)
 }
 
@@ -494,18 +510,22 @@ __global__ __launch_bounds__(1024) void march_scan_kernel(int32_t *__restrict__ 
                                                          int32_t *__restrict__ counter, uint32_t M_cap,
                                                          bool arena)
 {
-    __shared__ uint32_t wave_sum[16];
-    __shared__ uint32_t carry_s, kept_s;
+    __shared__ uint32_t wave_sum[16], wave_kept[16];
+    __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    if (tid == 0) {
-        carry_s = arena ? 0u : (uint32_t)counter[0];
-        kept_s = 0u;
-    }
+    if (tid == 0) carry_s = arena ? 0u : (uint32_t)counter[0];
     __syncthreads();
-    for (uint32_t base = 0; base < N; base += 1024u) {
-        const uint32_t n = base + tid;
-        const uint32_t cnt = n < N ? (uint32_t)rays[(size_t)n * 2 + 1] : 0u;
-        uint32_t v = cnt;  // inclusive scan inside the wave
+    uint32_t kept_total = 0;   // meaningful in lane 0 of wave 0
+    // 4 consecutive rays per lane: a 4096-ray batch is one tile (one load round trip, one store round trip)
+    for (uint32_t base = 0; base < N; base += 4096u) {
+        const uint32_t n0 = base + tid * 4u;
+        uint32_t cnt[4], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            cnt[j] = n0 + j < N ? (uint32_t)rays[(size_t)(n0 + j) * 2 + 1] : 0u;
+            sum += cnt[j];
+        }
+        uint32_t v = sum;  // inclusive scan inside the wave
 #pragma unroll
         for (uint32_t d = 1; d < 64u; d <<= 1) {
             const uint32_t up = __shfl_up(v, d, 64);
@@ -519,26 +539,37 @@ __global__ __launch_bounds__(1024) void march_scan_kernel(int32_t *__restrict__ 
             tile_total += wave_sum[w];
         }
         const uint32_t carry = carry_s;
-        const uint32_t off = carry + wave_off + v - cnt;
-        if (n < N) {
-            if (!arena) {
-                rays[(size_t)n * 2] = (int32_t)off;
-            } else {
-                const bool keep = off + cnt <= M_cap;
-                rays[(size_t)n * 2] = (int32_t)(keep ? off : M_cap);
-                if (keep)
-                    atomicAdd(&kept_s, cnt);
-                else
-                    rays[(size_t)n * 2 + 1] = 0;
+        uint32_t off = carry + wave_off + v - sum, kept = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t n = n0 + j;
+            if (n < N) {
+                if (!arena) {
+                    rays[(size_t)n * 2] = (int32_t)off;
+                } else {
+                    const bool keep = off + cnt[j] <= M_cap;
+                    rays[(size_t)n * 2] = (int32_t)(keep ? off : M_cap);
+                    if (keep)
+                        kept += cnt[j];
+                    else
+                        rays[(size_t)n * 2 + 1] = 0;
+                }
             }
+            off += cnt[j];
         }
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d, 64);
+        if (lane == 0) wave_kept[wid] = kept;
         __syncthreads();
-        if (tid == 0) carry_s = carry + tile_total;
+        if (tid == 0) {
+            carry_s = carry + tile_total;
+            for (uint32_t w = 0; w < 16u; w++) kept_total += wave_kept[w];
+        }
         __syncthreads();
     }
     if (tid == 0) {
         if (arena) {
-            counter[0] = (int32_t)kept_s;
+            counter[0] = (int32_t)kept_total;
             counter[1] = (int32_t)carry_s;
         } else {
             counter[0] = (int32_t)carry_s;

@@ -126,7 +126,8 @@ class FusedTrainer:
         self.loss = torch.zeros(1, **f32)
         self.mlp_image = torch.empty(mb.image_bytes(), dtype=torch.uint8, device=dev)
         self.ws_mlp = torch.empty(mb.backward_workspace_bytes(cap), dtype=torch.uint8, device=dev)
-        self.ws_grid = torch.empty(gb.backward_workspace_bytes(cap, self.L, self.rows), dtype=torch.uint8, device=dev)
+        for slot in self.slots:         # the binned backward's bookkeeping is per ray batch (prepared with the march)
+            slot.ws_grid = torch.empty(gb.backward_workspace_bytes(cap, self.L, self.rows), dtype=torch.uint8, device=dev)
         self.global_step = 0
         self.samples_seen = torch.zeros(1, dtype=torch.int64, device=dev)     # running total, never read per step
         self.ray_gen = torch.Generator(device=dev).manual_seed(seed * 1000 + self.rank)   # torch sampling path
@@ -150,6 +151,9 @@ class FusedTrainer:
                                   opt.max_steps, N, m.cascade, m.grid_size, slot.nears, slot.fars, noises, ar.t_scratch,
                                   self.cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, self.occ_index,
                                   ar.chain)
+        # positions are all the table-gradient binning needs to size its bins: do that here, off the main stream
+        gb.grid_backward_binned_prepare(ar.xyzs, m.bound, m.grid_encoder.offsets, self.rows, ar.counter, self.cap, self.L,
+                                        self.L, self.S, self.H, slot.ws_grid)
 
     def forward_backward(self, rays_o, rays_d, gt_rgba, noises, bg_rgb=None, bg_const=0.0):
         """march -> encode -> MLP -> composite -> loss -> backward into self.table_grad / self.w_grad."""
@@ -161,13 +165,14 @@ class FusedTrainer:
         for _, op in self._field_ops(slot, gt_rgba, bg_rgb, bg_const):
             op()
 
-    def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const):
+    def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True):
         """The field part of the step as (C entry point, thunk) pairs, in launch order."""
         opt, m, ar, N, cap = self.opt, self.model, slot.arena, self.N, self.cap
         cnt, offsets = ar.counter, m.grid_encoder.offsets
 
         def loss_and_composite_backward():
-            self.loss.zero_()
+            if zero_loss:
+                self.loss.zero_()
             eb.composite_mse_backward(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, self.ws,
                                       self.depth, self.image, cap, N, opt.T_thresh, self.dsigma, self.drgb, self.loss)
 
@@ -183,9 +188,9 @@ class FusedTrainer:
             ("ngp_x_composite_mse_backward", loss_and_composite_backward),
             ("ngp_x_mlp_backward", lambda: mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap,
                                                        self.mlp_image, opt.loss_scale, self.denc, self.dws, self.ws_mlp)),
-            ("ngp_x_grid_encode_backward_binned", lambda: gb.grid_backward_binned(
+            ("ngp_x_grid_backward_binned_apply", lambda: gb.grid_backward_binned_apply(
                 self.denc, self.x01, offsets, self.table_grad, cnt, cap, cap, self.L, self.L, self.S, self.H,
-                self.ws_grid)),
+                slot.ws_grid)),
         ]
 
     @torch.no_grad()
@@ -239,8 +244,8 @@ class FusedTrainer:
             self.model.grid_encoder.embeddings.grad = self.table_grad
             self.model.apply_weight_decay(self.opt.lambda_wd)
         if device_hyper:
-            eb.adam_step_dev(self.table, self.table_grad, self.t_m, self.t_v, self.hyper, *self.betas, self.eps, True)
-            eb.adam_step_dev(self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps, False)
+            eb.adam_step_dev2((self.table, self.table_grad, self.t_m, self.t_v, True),
+                              (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
             return
         step, lr = self.global_step + 1, self.lr()
         eb.adam_step(self.table, self.table_grad, self.t_m, self.t_v, lr, *self.betas, self.eps, step, zero_grad=True)
@@ -277,16 +282,14 @@ class FusedTrainer:
         opt = self.opt
         bg_const = 1.0 if opt.background in ("white", "last_sample") else 0.0
 
-        def count_samples():
-            self.samples_seen += slot.arena.counter[:1]
-
-        ops = [("ngp_x_schedule_step", lambda: eb.schedule_step(self.step_ctr, self.hyper, self.lr0, float(opt.iters),
-                                                                 *self.betas))]
-        ops += self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const)
-        ops.append(("samples_seen", count_samples))
+        # lr / Adam bias corrections of this step, loss = 0, samples_seen += this batch's sample count
+        ops = [("ngp_x_step_begin", lambda: eb.step_begin(self.step_ctr, self.hyper, self.lr0, float(opt.iters),
+                                                           *self.betas, self.loss, self.samples_seen,
+                                                           slot.arena.counter))]
+        ops += self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False)
         if self.world_size > 1:
             ops.append(("all_reduce", self.reduce_gradients))
-        ops.append(("ngp_x_adam_step_dev", lambda: self.optimizer_step(device_hyper=True)))
+        ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True)))
         return ops
 
     def _capture(self, slot):
@@ -296,7 +299,7 @@ class FusedTrainer:
         from .. import _lib
         if self.graph_pool is None:
             self.graph_pool = torch.cuda.graph_pool_handle()
-        eager = {"all_reduce", _lib.probed_symbol()}
+        eager = {"all_reduce", *_lib.probed_symbols()}
         parts, run = [], []
 
         def flush():

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Standalone driver of the hash-grid forward (slab) and the binned table backward on ray-ordered samples, for
+rocprofv3 --pmc passes and quick timing (the full bench cannot run under --pmc: the profiler's dispatch hook
+crashes on one of the compositor launches).  Samples: 4096 rays x ~50 steps of dt = 2*sqrt(3)/1024 through a shell
+around a sphere, like a trained occupancy grid produces."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raw_ngp_amd import _lib  # noqa: E402
+from raw_ngp_amd._lib import engine_backend as eb, gridencoder_backend as gb  # noqa: E402
+from oracle import oracle as orc  # noqa: E402  (level table only)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--per-ray", type=int, default=50)
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    _lib.load()
+    g = torch.Generator(device=dev).manual_seed(0)
+    N, K = args.rays, args.per_ray
+    o = torch.nn.functional.normalize(torch.randn(N, 3, device=dev, generator=g), dim=-1) * 3.0
+    target = (torch.rand(N, 3, device=dev, generator=g) - 0.5) * 0.8
+    d = torch.nn.functional.normalize(target - o, dim=-1)
+    t0 = (target - o).norm(dim=-1, keepdim=True) - 0.09
+    dt = 2 * 3 ** 0.5 / 1024
+    t = t0 + dt * torch.arange(K, device=dev).float()[None]
+    xyz = (o[:, None] + d[:, None] * t[..., None]).reshape(-1, 3).clamp(-0.999, 0.999).contiguous()
+    B = xyz.shape[0]
+    offsets_np, scale = orc.grid_offsets(desired_resolution=2048)
+    offsets = torch.from_numpy(offsets_np).to(dev)
+    L, H, S = 16, 16, float(np.log2(scale))
+    rows = int(offsets_np[-1])
+    table = (torch.rand(rows, 2, device=dev, generator=g) - 0.5) * 2e-4
+    enc = torch.empty(L, B, 2, device=dev)
+    x01 = torch.empty(B, 3, device=dev)
+    denc = torch.randn(L, B, 2, device=dev, generator=g)
+    grad = torch.zeros(rows, 2, device=dev)
+    ws = torch.empty(gb.backward_workspace_bytes(B, L, rows), dtype=torch.uint8, device=dev)
+    cnt = torch.tensor([B, B, 0, 0], dtype=torch.int32, device=dev)
+
+    def once():
+        eb.grid_encode_forward_slab(xyz, 1.0, table, offsets, enc, x01, cnt, B, B, L, L, S, H)
+        gb.grid_backward_binned_prepare(xyz, 1.0, offsets, rows, cnt, B, L, L, S, H, ws)
+        gb.grid_backward_binned_apply(denc, x01, offsets, grad, cnt, B, B, L, L, S, H, ws)
+
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.iters):
+        once()
+    torch.cuda.synchronize()
+    print(f"{B} samples, {(time.perf_counter() - t1) / args.iters * 1e6:.1f} us per forward + binned backward")
+
+
+if __name__ == "__main__":
+    main()
