@@ -69,6 +69,82 @@ __device__ __forceinline__ TileInB<WANT_SH> load_tile_b(const float *__restrict_
     return in;
 }
 
+// One wave per SIMD (417 VGPRs) means nothing hides a tile's load latency but the wave itself: the raw inputs of
+// the NEXT tile are requested before the current tile's MFMA chain starts and converted when their turn comes.
+struct RawTile {
+    float2 e[8];        // encoder rows: levels 8s + 4q + 2h and +1, in load_tile_b order
+    float d[3];         // direction (view kernel)
+    float gs, gr[3];    // d loss / d sigma, d rgb (view kernel)
+    half8 p3;           // delta of the density MLP's output layer (grid kernel)
+};
+
+template <bool VIEW>
+__device__ __forceinline__ RawTile fetch_raw(const float *__restrict__ enc, size_t stride, const float *__restrict__ dirs,
+                                             const float *__restrict__ dsigma, const float *__restrict__ drgb,
+                                             const half8 *__restrict__ d3buf, uint32_t row, bool valid, uint32_t h)
+{
+    RawTile r;
+#pragma unroll
+    for (uint32_t s = 0; s < 2; s++)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {
+            const uint32_t level = 8 * s + 4 * q + 2 * h;
+            r.e[4 * s + 2 * q] = make_float2(0.f, 0.f);
+            r.e[4 * s + 2 * q + 1] = make_float2(0.f, 0.f);
+            if (valid) {
+                r.e[4 * s + 2 * q] = reinterpret_cast<const float2 *>(enc)[(size_t)level * stride + row];
+                r.e[4 * s + 2 * q + 1] = reinterpret_cast<const float2 *>(enc)[(size_t)(level + 1) * stride + row];
+            }
+        }
+    r.d[0] = r.d[1] = 0.f;
+    r.d[2] = 1.f;
+    r.gs = r.gr[0] = r.gr[1] = r.gr[2] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; t++) r.p3[t] = (_Float16)0.0f;
+    if (valid) {
+        if constexpr (VIEW) {
+            r.d[0] = dirs[(size_t)row * 3];
+            r.d[1] = dirs[(size_t)row * 3 + 1];
+            r.d[2] = dirs[(size_t)row * 3 + 2];
+            r.gs = dsigma[row];
+            r.gr[0] = drgb[(size_t)row * 3];
+            r.gr[1] = drgb[(size_t)row * 3 + 1];
+            r.gr[2] = drgb[(size_t)row * 3 + 2];
+        } else {
+            r.p3 = d3buf[(size_t)row * 2 + h];
+        }
+    }
+    return r;
+}
+
+template <bool WANT_SH>
+__device__ __forceinline__ TileInB<WANT_SH> convert_raw(const RawTile &r, uint32_t h)
+{
+    TileInB<WANT_SH> in;
+#pragma unroll
+    for (uint32_t s = 0; s < 2; s++)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {
+            const float2 a = r.e[4 * s + 2 * q], b = r.e[4 * s + 2 * q + 1];
+            in.x0[s][4 * q + 0] = (_Float16)a.x;
+            in.x0[s][4 * q + 1] = (_Float16)a.y;
+            in.x0[s][4 * q + 2] = (_Float16)b.x;
+            in.x0[s][4 * q + 3] = (_Float16)b.y;
+        }
+    if constexpr (WANT_SH) {
+        const float dx = r.d[0], dy = r.d[1], dz = r.d[2];
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        float sh[16], j0[1], j1[1], j2[1];
+        sh_eval<4, false>(dx * inv, dy * inv, dz * inv, sh, j0, j1, j2);
+#pragma unroll
+        for (uint32_t t = 0; t < 8; t++) {
+            const float lo = sh[8 * (t >> 2) + (t & 3)], hi = sh[8 * (t >> 2) + 4 + (t & 3)];
+            in.sh[t] = (_Float16)(h ? hi : lo);
+        }
+    }
+    return in;
+}
+
 // registers 8S..8S+7 of `a`, zeroed where the matching post-ReLU activation (same tile, same k-step) is 0
 template <int S>
 __device__ __forceinline__ half8 pack_masked(const f32x16 &a, const half8 &act)
@@ -139,11 +215,17 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 #pragma unroll
     for (int i = 0; i < 8; i++) g[i] = zero16();
 
+    RawTile nxt = fetch_raw<true>(enc, stride, dirs, dsigma, drgb, nullptr, wave * 32u + n, wave * 32u + n < M, h);
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         asm volatile("" ::: "memory");   // keep the weight fragments in LDS: no hoisting of 46 KiB into VGPRs
         const uint32_t row = tile * 32u + n;
         const bool valid = row < M;
-        const TileInB<true> in = load_tile_b<true>(enc, stride, dirs, row, valid, h);
+        const RawTile cur = nxt;
+        {
+            const uint32_t nrow = (tile + n_waves) * 32u + n;
+            nxt = fetch_raw<true>(enc, stride, dirs, dsigma, drgb, nullptr, nrow, tile + n_waves < n_tiles && nrow < M, h);
+        }
+        const TileInB<true> in = convert_raw<true>(cur, h);
 
         // ---------------- recompute the forward pass
         f32x16 a[2];
@@ -210,13 +292,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             for (int s = 0; s < 2; s++) c = mfma(NGP_FRAG(F_W6 + kb * 2 + s), h4[kb][s], c);
 
         // ---------------- output deltas (scaled by loss_scale so that they survive f16)
-        float gs = 0.f, gr0 = 0.f, gr1 = 0.f, gr2 = 0.f;
-        if (valid) {
-            gs = dsigma[row];
-            gr0 = drgb[(size_t)row * 3];
-            gr1 = drgb[(size_t)row * 3 + 1];
-            gr2 = drgb[(size_t)row * 3 + 2];
-        }
+        const float gs = cur.gs, gr0 = cur.gr[0], gr1 = cur.gr[1], gr2 = cur.gr[2];
         f32x16 d6 = zero16();
         if (h == 0) {   // rows 0..2 of the tile: d rgb / d raw = exp(raw - 5) where the clamp at 5 is inactive
             const float e0 = __expf(c[0] - 5.0f), e1 = __expf(c[1] - 5.0f), e2 = __expf(c[2] - 5.0f);
@@ -327,15 +403,18 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
 #pragma unroll
     for (int i = 0; i < 8; i++) g[i] = zero16();
 
+    RawTile nxt = fetch_raw<false>(enc, stride, nullptr, nullptr, nullptr, d3buf, wave * 32u + n, wave * 32u + n < M, h);
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         asm volatile("" ::: "memory");   // keep the weight fragments in LDS (see the view kernel)
         const uint32_t row = tile * 32u + n;
         const bool valid = row < M;
-        const TileInB<false> in = load_tile_b<false>(enc, stride, nullptr, row, valid, h);
-        half8 p3;
-#pragma unroll
-        for (int t = 0; t < 8; t++) p3[t] = (_Float16)0.0f;
-        if (valid) p3 = d3buf[(size_t)row * 2 + h];
+        const RawTile cur = nxt;
+        {
+            const uint32_t nrow = (tile + n_waves) * 32u + n;
+            nxt = fetch_raw<false>(enc, stride, nullptr, nullptr, nullptr, d3buf, nrow, tile + n_waves < n_tiles && nrow < M, h);
+        }
+        const TileInB<false> in = convert_raw<false>(cur, h);
+        const half8 p3 = cur.p3;
 
         f32x16 a[2];
         half8 h1[2][2], h2[2][2];
