@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--psnr-iters", type=int, default=0, help="if > 0: keep training to this many iterations and report PSNR")
     ap.add_argument("--arena", type=int, default=0, help="sample arena capacity (0 = reference two-pass march)")
     ap.add_argument("--torch-mlp", action="store_true", help="fp32 nn.Linear MLPs instead of the fused f16 MFMA field")
+    ap.add_argument("--probe-every", type=int, default=4,
+                    help="time every N-th launch of the roofline entry point with HIP events (each timed launch drains the queue)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event roofline probe (roofline: null)")
     ap.add_argument("--no-graph", action="store_true", help="fused step: launch kernels one by one (no hipGraph replay)")
     ap.add_argument("--torch-sampler", action="store_true", help="fused step: draw rays with torch ops (implies no graph)")
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
@@ -176,7 +179,7 @@ def main():
     symbols = args.roofline_kernel
     if symbols == "ngp_x_grid_backward_binned":
         symbols = ("ngp_x_grid_backward_binned_apply", "ngp_x_grid_backward_binned_prepare")
-    _lib.set_probe(symbols, arg_idx)
+    _lib.set_probe(None if args.no_probe else symbols, arg_idx, every=args.probe_every)
     trainer.train(args.burnin)
     trainer.train(args.warmup)
 
@@ -187,8 +190,11 @@ def main():
     seen0 = int(trainer.samples_seen) if fused else 0
     t0 = time.perf_counter()
     samples = 0
+    host = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         trainer.train_step()
+        host += time.perf_counter() - h0
         if not fused:
             samples += trainer.last_num_points      # (host value of the per-op path; the fused step never syncs)
     torch.cuda.synchronize()
@@ -206,6 +212,16 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    in_sync = None
+    if world > 1 and fused:
+        # replicas must hold identical parameters and the same occupancy bitfield after the timed steps
+        sums = torch.stack([trainer.table.double().sum(), trainer.w_flat.double().sum(),
+                            model.density_bitfield.double().sum()])
+        lo, hi = sums.clone(), sums.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
+
     psnr = None
     if args.psnr_iters > trainer.global_step:
         trainer.train(args.psnr_iters - trainer.global_step)
@@ -220,7 +236,7 @@ def main():
             ach = units * bytes_per_sample / ksec / 1e9
             roof = {"bound": "hbm", "kernel": args.roofline_kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
-                    "launches": launches, "avg_us": round(ksec / launches * 1e6, 2),
+                    "launches": launches, "timed_every": args.probe_every, "avg_us": round(ksec / launches * 1e6, 2),
                     "bytes_per_sample": bytes_per_sample, "samples_per_launch": round(units / launches)}
         cpu = None
         if not args.no_cpu_baseline:
@@ -236,9 +252,10 @@ def main():
                                    + ("fp32 nn.Linear MLPs" if args.torch_mlp else "fused tiny-MLP (configs[2])"),
                        "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
                        "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
-                       "parallelism": f"dp{world}", "step": "fused" if fused else "autograd",
+                       "parallelism": f"dp{world}", "replicas_in_sync": in_sync, "step": "fused" if fused else "autograd",
                        "graph": bool(fused and trainer.use_graph), "prefetch": bool(fused and trainer.prefetch),
                        "device_sampler": bool(fused and trainer.device_sampler),
+                       "host_enqueue_ms_per_step": round(host / max(args.steps, 1) * 1e3, 4),
                        "arena_capacity": trainer.cap if fused else 0, "arena_overflow": bool(fused and overflow)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -16,7 +16,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libngp_hip.so")
+LIB_PATH = os.environ.get("NGP_HIP_LIB") or os.path.join(_HERE, "csrc", "libngp_hip.so")   # override: kernel experiments
 
 _f, _u, _i, _p, _d = ctypes.c_float, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
 
@@ -132,16 +132,18 @@ def _ptr(t, kind, name, optional=False):
 # C symbol, plus the value of one integer argument (the number of samples the launch processes).  Events cannot be
 # timed inside a captured graph, so the fused engine keeps the probed entry point out of its graphs (it asks
 # `probed_symbol()` when it captures).
-_probe = {"names": (), "arg": 0, "events": []}
+_probe = {"names": (), "arg": 0, "events": [], "every": 1, "calls": {}}
 
 
-def set_probe(names, units_arg=0):
-    """names: one C symbol or a tuple of them (e.g. the two halves of one operation); units_arg applies to the first."""
+def set_probe(names, units_arg=0, every=1):
+    """names: one C symbol or a tuple of them (e.g. the two halves of one operation); units_arg applies to the first.
+    every = k times only every k-th call of each symbol (timing events drain the queue around the launch: sampling
+    keeps the measurement from slowing down what it measures)."""
     if names is None:
         names = ()
     elif isinstance(names, str):
         names = (names,)
-    _probe["names"], _probe["arg"], _probe["events"] = tuple(names), units_arg, []
+    _probe.update(names=tuple(names), arg=units_arg, events=[], every=max(int(every), 1), calls={})
 
 
 def probed_symbols():
@@ -166,15 +168,21 @@ def _call(name, anchor, *args):
     lib = load()
     dev = anchor.device
     probing = name in _probe["names"]
+    if probing and _probe["every"] > 1:
+        k = _probe["calls"].get(name, 0)
+        _probe["calls"][name] = k + 1
+        timed = k % _probe["every"] == 0
+    else:
+        timed = probing
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
-        if probing:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError(f"{name} is being probed: it must not be captured into a graph")
+        if probing and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"{name} is being probed: it must not be captured into a graph")
+        if timed:
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record(stream)
         rc = getattr(lib, name)(*args, stream.cuda_stream)
-        if probing:
+        if timed:
             stop.record(stream)
             units = int(args[_probe["arg"]]) if name == _probe["names"][0] else 0
             _probe["events"].append((name, start, stop, units))

@@ -228,11 +228,20 @@ class FusedTrainer:
         return float(self.dg_stats[1]) if self.native_refresh else float(self.model.mean_density)   # host read
 
     def reduce_gradients(self):
+        """Ray-batch data parallelism: average the table and MLP gradients over the ranks (RCCL over xGMI).
+        The table gradient is reduced in place as one 46.5 MiB collective; AVG folds the division into it."""
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.table_grad)
-            torch.distributed.all_reduce(self.w_grad)
-            self.table_grad.div_(self.world_size)
-            self.w_grad.div_(self.world_size)
+            dist = torch.distributed
+            if dist.get_backend() == "nccl":
+                big = dist.all_reduce(self.table_grad, op=dist.ReduceOp.AVG, async_op=True)
+                small = dist.all_reduce(self.w_grad, op=dist.ReduceOp.AVG, async_op=True)
+                big.wait()
+                small.wait()
+            else:                                   # gloo (rehearsal): no AVG
+                dist.all_reduce(self.table_grad)
+                dist.all_reduce(self.w_grad)
+                self.table_grad.div_(self.world_size)
+                self.w_grad.div_(self.world_size)
 
     def optimizer_step(self, device_hyper=False):
         """Adam on the table and the MLP weights.  device_hyper: learning rate and bias corrections come from

@@ -27,7 +27,9 @@ def world_size():
 
 def init_from_env(device_type="cuda"):
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun env).
-    Returns (rank, world_size, local_rank); a single process without the env stays un-initialised."""
+    Returns (rank, world_size, local device index); a single process without the env stays un-initialised.
+    Rehearsal on a one-GPU box: NGP_DIST_BACKEND=gloo NGP_LOCAL_DEVICE=0 puts every rank on the same device and
+    reduces through gloo (RCCL wants one device per rank)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if ws <= 1:
         return 0, 1, 0
@@ -35,8 +37,13 @@ def init_from_env(device_type="cuda"):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if device_type == "cuda":
+        lr = int(os.environ.get("NGP_LOCAL_DEVICE", lr))
         torch.cuda.set_device(lr)
-        dist.init_process_group("nccl", rank=r, world_size=ws, device_id=torch.device("cuda", lr))
+        backend = os.environ.get("NGP_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=r, world_size=ws, device_id=torch.device("cuda", lr))
+        else:
+            dist.init_process_group(backend, rank=r, world_size=ws)
     else:
         dist.init_process_group("gloo", rank=r, world_size=ws)
     return r, ws, lr
