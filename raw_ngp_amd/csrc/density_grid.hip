@@ -44,28 +44,43 @@ __global__ __launch_bounds__(256) void grid_positive_mask_kernel(const float *__
     }
 }
 
-// in place: prefix[w + 1] = counts -> prefix[w] = cells before word w, prefix[n_words] = total
+// in place: prefix[w + 1] = counts -> prefix[w] = cells before word w, prefix[n_words] = total.
+// One workgroup; wave q owns a contiguous segment and walks it 64 words at a time (coalesced), 32 rows of loads in
+// flight before any store (a per-lane range of consecutive words would make every load a different cache line).
 __global__ __launch_bounds__(1024) void grid_prefix_kernel(uint32_t n_words, GridWs g)
 {
     __shared__ uint32_t wave_sum[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const uint32_t per = (n_words + 1023u) / 1024u, w0 = tid * per, w1 = min(n_words, w0 + per);
+    const uint32_t seg = ((n_words + 15u) / 16u + 63u) & ~63u;
+    const uint32_t lo = min(n_words, wid * seg), hi = min(n_words, lo + seg);
     uint32_t mine = 0;
-    for (uint32_t w = w0; w < w1; w++) mine += g.prefix[w + 1];
-    uint32_t inc = mine;
+    for (uint32_t w = lo + lane; w < hi; w += 64u) mine += g.prefix[w + 1];
 #pragma unroll
-    for (uint32_t d = 1; d < 64u; d <<= 1) {
-        const uint32_t up = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += up;
-    }
-    if (lane == 63u) wave_sum[wid] = inc;
+    for (uint32_t d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane == 0) wave_sum[wid] = mine;
     __syncthreads();
-    uint32_t run = inc - mine;
+    uint32_t run = 0;
     for (uint32_t k = 0; k < wid; k++) run += wave_sum[k];
     if (tid == 0) g.prefix[0] = 0;
-    for (uint32_t w = w0; w < w1; w++) {   // inclusive values, written one slot up: a lane only overwrites its own inputs
-        run += g.prefix[w + 1];
-        g.prefix[w + 1] = run;
+    for (uint32_t base = lo; base < hi; base += 32u * 64u) {
+        uint32_t c[32];
+#pragma unroll
+        for (uint32_t r = 0; r < 32; r++) {
+            const uint32_t w = base + r * 64u + lane;
+            c[r] = w < hi ? g.prefix[w + 1] : 0u;
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 32; r++) {
+            uint32_t v = c[r];
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const uint32_t up = __shfl_up(v, d, 64);
+                if (lane >= d) v += up;
+            }
+            const uint32_t w = base + r * 64u + lane;
+            if (w < hi) g.prefix[w + 1] = run + v;
+            run += __shfl(v, 63, 64);
+        }
     }
 }
 

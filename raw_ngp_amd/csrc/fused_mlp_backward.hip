@@ -541,22 +541,28 @@ __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restr
                                                            float *__restrict__ dw4, float *__restrict__ dw5,
                                                            float *__restrict__ dw6)
 {
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= 2 * kAccFloats) return;
+    // 64 outputs per workgroup; wave q sums the slabs q, q + 4, q + 8, ... (eight loads in flight: the sum is
+    // latency-bound otherwise) and the four partial sums are added in wave order -- a fixed order, so the result is
+    // reproducible run to run
+    __shared__ float part[4][64];
+    const uint32_t e = blockIdx.x * 64 + (threadIdx.x & 63u), q = threadIdx.x >> 6;
     const bool view = e >= kAccFloats;
     const uint32_t i = view ? e - kAccFloats : e;
     const float *src = (view ? part_view : part_grid) + i;
-    // fixed order (slab 0, 1, 2, ...) but eight loads in flight: the sum is latency-bound otherwise
     float s = 0.0f;
-    uint32_t w = 0;
-    for (; w + 8 <= n_wg; w += 8) {
+    uint32_t w = q;
+    for (; w + 28 < n_wg; w += 32) {
         float t[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) t[k] = src[(size_t)(w + k) * kAccFloats];
+        for (int k = 0; k < 8; k++) t[k] = src[(size_t)(w + 4 * k) * kAccFloats];
 #pragma unroll
         for (int k = 0; k < 8; k++) s += t[k];
     }
-    for (; w < n_wg; w++) s += src[(size_t)w * kAccFloats];
+    for (; w < n_wg; w += 4) s += src[(size_t)w * kAccFloats];
+    part[q][threadIdx.x & 63u] = s;
+    __syncthreads();
+    if (q != 0) return;
+    s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
     s *= inv_loss_scale;
     const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
     const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;
@@ -615,7 +621,7 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
                                                                         loss_scale, d3buf, part_view);
     mlp_backward_grid_kernel<<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
                                                                         d3buf, denc, part_grid);
-    mlp_reduce_dw_kernel<<<dim3(ceil_div(2 * kAccFloats, 256u)), dim3(256), 0, st>>>(part_view, part_grid, blocks,
+    mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, st>>>(part_view, part_grid, blocks,
                                                                                     1.0f / loss_scale, dw1, dw2, dw3, dw4,
                                                                                     dw5, dw6);
     NGP_CHECK_LAUNCH("mlp_backward");
