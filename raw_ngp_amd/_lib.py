@@ -150,6 +150,19 @@ def probed_symbols():
     return _probe["names"]
 
 
+def probe_next_timed():
+    """True when the next call of a probed symbol will be bracketed by timing events (see `every`)."""
+    if not _probe["names"]:
+        return False
+    return _probe["calls"].get(_probe["names"][0], 0) % _probe["every"] == 0
+
+
+def probe_skip(names=None):
+    """Account for calls that happened inside a captured graph (where nothing can be timed)."""
+    for n in (names or _probe["names"]):
+        _probe["calls"][n] = _probe["calls"].get(n, 0) + 1
+
+
 def probe_reset():
     """Forget the measurements taken so far, keep probing."""
     _probe["events"] = []
@@ -168,16 +181,13 @@ def _call(name, anchor, *args):
     lib = load()
     dev = anchor.device
     probing = name in _probe["names"]
-    if probing and _probe["every"] > 1:
+    timed = False
+    if probing and not torch.cuda.is_current_stream_capturing():
         k = _probe["calls"].get(name, 0)
         _probe["calls"][name] = k + 1
         timed = k % _probe["every"] == 0
-    else:
-        timed = probing
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
-        if probing and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError(f"{name} is being probed: it must not be captured into a graph")
         if timed:
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record(stream)

@@ -105,6 +105,10 @@ class FusedTrainer:
         # the main stream's part of a step replayed from captured hipGraphs (one per ray slot)
         self.use_graph = bool(getattr(opt, "capture_graph", True)) and opt.lambda_tv == 0 and dev.type == "cuda"
         self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
+        self._main_symbols = {"ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
+                              "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
+                              "ngp_x_composite_mse_backward", "ngp_x_adam_step_dev2", "ngp_x_step_begin",
+                              "ngp_x_mlp_prepare"}
         # density-grid refresh on the device (no host round trips)
         self.native_refresh = bool(getattr(opt, "native_grid_refresh", True)) and model.grid_size ** 3 % 64 == 0
         if self.native_refresh:
@@ -301,14 +305,14 @@ class FusedTrainer:
         ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True)))
         return ops
 
-    def _capture(self, slot):
-        """The step as hipGraphs.  Two kinds of op stay outside: the gradient all-reduce (RCCL, under DP) and an
-        entry point bench.py is timing with HIP events (events inside a graph cannot be timed); the runs of ops
-        between them become one graph each."""
+    def _capture(self, slot, timed):
+        """The step as hipGraphs.  Two kinds of op stay outside: the gradient all-reduce (RCCL, under DP) and, on the
+        steps where bench.py times it with HIP events, the probed entry point (events inside a graph cannot be
+        timed); the runs of ops between them become one graph each."""
         from .. import _lib
         if self.graph_pool is None:
             self.graph_pool = torch.cuda.graph_pool_handle()
-        eager = {"all_reduce", *_lib.probed_symbols()}
+        eager = {"all_reduce", *(_lib.probed_symbols() if timed else ())}
         parts, run = [], []
 
         def flush():
@@ -357,11 +361,16 @@ class FusedTrainer:
                 self._load_slot(nxt)
             nxt.step = step + 1
         if self.use_graph and batch is None and step >= 2:      # the first steps run eagerly (lazy init, caches)
-            key = step % 2
+            from .. import _lib
+            probed = [n for n in _lib.probed_symbols() if n in self._main_symbols]
+            timed = bool(probed) and _lib.probe_next_timed()
+            key = (step % 2, timed)
             if key not in self.graphs:
-                self.graphs[key] = self._capture(slot)
+                self.graphs[key] = self._capture(slot, timed)
             for part in self.graphs[key]:
                 part()
+            if probed and not timed:
+                _lib.probe_skip(probed)                         # the call happened inside the graph
             self.last_graph_key = key
         else:
             for _, op in self._step_ops(slot):
