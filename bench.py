@@ -46,6 +46,9 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29
 # MI355X guide prescribes): 469 MB / 204 800.  rocprofv3's counter mode cannot run this script (it crashes in the
 # profiler's dispatch hook), so the figure is carried over from tools/grid_bench.py, which drives the same kernels.
 PMC_TRAFFIC_BYTES_PER_SAMPLE = {"ngp_x_grid_backward_binned": 2290.0}
+# slab forward, same passes: FETCH 63.7 MB (8-byte gathers, counted as reported) + WRITE 28.0 MB on 204 800 samples
+PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 448.0
+FWD_BYTES_PER_SAMPLE = 12 + 16 * (64 + 8)      # 1164 B/sample, SURVEY.md section 8d
 
 # entry point(s) timed with HIP events -> (index of the samples-per-launch argument, algorithmic bytes per sample)
 ROOFLINE_KERNELS = {
@@ -182,10 +185,13 @@ def main():
 
     # set before the step is captured into graphs: the engine keeps the probed entry point out of them
     arg_idx, bytes_per_sample = ROOFLINE_KERNELS[args.roofline_kernel]
-    symbols = args.roofline_kernel
-    if symbols == "ngp_x_grid_backward_binned":
+    symbols = (args.roofline_kernel,)
+    if args.roofline_kernel == "ngp_x_grid_backward_binned":
         symbols = ("ngp_x_grid_backward_binned_apply", "ngp_x_grid_backward_binned_prepare")
-    _lib.set_probe(None if args.no_probe else symbols, arg_idx, every=args.probe_every)
+    # the north star also names the encoder's forward: timed the same way, reported as roofline_forward
+    fwd_symbol = "ngp_x_grid_encode_forward_slab"
+    probed = symbols + ((fwd_symbol,) if fused and fwd_symbol not in symbols else ())
+    _lib.set_probe(None if args.no_probe else probed, arg_idx, every=args.probe_every)
     trainer.train(args.burnin)
     trainer.train(args.warmup)
 
@@ -206,7 +212,8 @@ def main():
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
-    probe = _lib.probe_results()
+    probe = _lib.probe_results(symbols)
+    probe_fwd = _lib.probe_results((fwd_symbol,)) if fwd_symbol in probed else (0, 0, 0.0)
     _lib.set_probe(None)
     if fused:
         samples = int(trainer.samples_seen) - seen0
@@ -247,6 +254,15 @@ def main():
                     "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_grid_traffic.csv, scaled by samples)",
                     "launches": launches, "timed_every": args.probe_every, "avg_us": round(ksec / launches * 1e6, 2),
                     "bytes_per_sample": bytes_per_sample, "samples_per_launch": round(units / launches)}
+        roof_fwd = None
+        if fused and probe_fwd[0]:
+            per_launch = samples / max(args.steps, 1)
+            ach = per_launch * FWD_BYTES_PER_SAMPLE * probe_fwd[0] / probe_fwd[2] / 1e9
+            roof_fwd = {"bound": "hbm", "kernel": fwd_symbol, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                        "traffic": round(PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE * per_launch),
+                        "launches": probe_fwd[0], "avg_us": round(probe_fwd[2] / probe_fwd[0] * 1e6, 2),
+                        "bytes_per_sample": FWD_BYTES_PER_SAMPLE, "samples_per_launch": round(per_launch)}
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(Options(bound=1.0), args.cpu_rays, args.cpu_steps)
@@ -266,7 +282,7 @@ def main():
                        "device_sampler": bool(fused and trainer.device_sampler),
                        "host_enqueue_ms_per_step": round(host / max(args.steps, 1) * 1e3, 4),
                        "arena_capacity": trainer.cap if fused else 0, "arena_overflow": bool(fused and overflow)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_forward": roof_fwd, "cpu_baseline": cpu,
         }
         if psnr is not None:
             line["psnr"] = {"iters": trainer.global_step, "value": round(float(psnr), 3)}

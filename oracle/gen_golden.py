@@ -117,6 +117,22 @@ def main():
         tabs[f"{tag}_emb_shape"] = np.array(enc.embeddings.shape)
     np.savez(os.path.join(args.out, "grid_offsets.npz"), **tabs)
 
+    # ---------------------------------------------------------------- checkpoint layout (state_dict keys/shapes)
+    import json
+    import nerf.network as NW
+    layouts = {}
+    for tag, kw in (("cuda_ray", dict(cuda_ray=True)), ("sampler", dict(cuda_ray=False)),
+                    ("cuda_ray_rfield", dict(cuda_ray=True, rfield=True))):
+        o_ = types.SimpleNamespace(**{**dict(
+            bound=1.0, cuda_ray=True, min_near=0.05, density_thresh=10, bg_radius=-1, pose_opt="none", rfield=False,
+            hashmap_size=19, hashgrid_resolution=2048, contract=False, grid_size=128, device="cpu", fp16=False,
+            num_cameras=10, softplus=False, activation="relu", clamped_exp=False, color_act="exp", real_bound=1.0), **kw})
+        net = NW.NeRFNetwork(o_)
+        layouts[tag] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+        del net
+    with open(os.path.join(args.out, "state_dict_layout.json"), "w") as f:
+        json.dump(layouts, f, indent=1)
+
     # ---------------------------------------------------------------- BARF / BAA-NGP level windows
     base = dict(bound=1.0, contract=False, grid_size=128, min_near=0.05, density_thresh=10, cuda_ray=True,
                 hashmap_size=19, hashgrid_resolution=2048, rfield=False, internal_activation="relu", beta=2.0,

@@ -150,6 +150,18 @@ def probed_symbols():
     return _probe["names"]
 
 
+class probe_paused:
+    """Context manager: calls inside are neither timed nor counted (other uses of a probed entry point)."""
+
+    def __enter__(self):
+        self.saved = _probe["names"]
+        _probe["names"] = ()
+
+    def __exit__(self, *exc):
+        _probe["names"] = self.saved
+        return False
+
+
 def probe_next_timed():
     """True when the next call of a probed symbol will be bracketed by timing events (see `every`)."""
     if not _probe["names"]:
@@ -168,11 +180,12 @@ def probe_reset():
     _probe["events"] = []
 
 
-def probe_results():
-    """(launches of the first symbol, its total units, seconds summed over all probed symbols) since set_probe() /
-    probe_reset()."""
+def probe_results(names=None):
+    """(timed launches of the first of `names`, its total units, seconds summed over all of `names`) since
+    set_probe() / probe_reset(); names defaults to every probed symbol."""
     torch.cuda.synchronize()
-    ev, first = _probe["events"], (_probe["names"] or (None,))[0]
+    names = tuple(names or _probe["names"])
+    ev, first = [e for e in _probe["events"] if e[0] in names], (names or (None,))[0]
     return (sum(1 for n, *_ in ev if n == first), sum(u for n, _, _, u in ev if n == first),
             sum(a.elapsed_time(b) for _, a, b, _ in ev) * 1e-3)
 

@@ -340,7 +340,9 @@ class FusedTrainer:
         step = self.global_step
         if step % opt.update_extra_interval == 0:
             if self.native_refresh:
-                self.refresh_density_grid()
+                from .. import _lib
+                with _lib.probe_paused():               # its encoder calls are not the training step's
+                    self.refresh_density_grid()
             else:
                 if self.world_size > 1:
                     torch.manual_seed(1234567 + step)

@@ -147,3 +147,18 @@ def test_run_sampler_with_analytic_field(golden_dir):
     np.testing.assert_allclose(out["image"].numpy(), g["image"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(out["depth"].numpy(), g["depth"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(out["weights_sum"].numpy(), g["weights_sum"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,kw", [("cuda_ray", dict(cuda_ray=True)), ("sampler", dict(cuda_ray=False)),
+                                    ("cuda_ray_rfield", dict(cuda_ray=True, rfield=True))])
+def test_state_dict_layout_matches_reference_checkpoints(golden_dir, tag, kw):
+    """A checkpoint written by the reference (nerf/train_utils.py:1141-1180 saves model.state_dict()) loads into
+    our NeRFNetwork: same keys, shapes and dtypes as the reference module built with the same options."""
+    import json
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    with open(os.path.join(golden_dir, "state_dict_layout.json")) as f:
+        want = {k: (tuple(shape), dtype) for k, shape, dtype in json.load(f)[tag]}
+    net = NeRFNetwork(Options(bound=1.0, **kw))
+    got = {k: (tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in net.state_dict().items()}
+    assert got == want
