@@ -208,13 +208,24 @@ int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, co
 int ngp_x_grid_backward_binned_prepare(const float *inputs, float in_bound, const int32_t *offsets, const int32_t *B_dev,
                                        uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                        uint32_t gridtype, int align_corners, uint32_t interp, uint32_t n_rows_total,
-                                       uint32_t max_level_rows, void *workspace, size_t workspace_bytes,
-                                       ngp_stream_t stream);
+                                       uint32_t max_level_rows, int single_segment, uint32_t merge_max_res, int stage,
+                                       void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+/* stage: 0 = plan + count + scan; 1 = plan only, 2 = scan only -- for callers that let
+ * ngp_x_grid_encode_forward_slab(..., binned_workspace) count the records between the two (it has every corner's row
+ * in registers and idle issue slots: the backward then needs no counting pass). */
+/* merge_max_res: finest level resolution at which runs of same-cell samples are merged before binning (0 = 1024,
+ * the limit of the cell key); choose ~0.7 / (sample spacing in [0,1] units) for ray-ordered samples. */
 int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, const int32_t *offsets,
                                      float *grad_embeddings, const int32_t *B_dev, uint32_t B, uint32_t grad_stride,
                                      uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
                                      int align_corners, uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
-                                     void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+                                     void *workspace, size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
+                                     float *adam_exp_avg_sq, const float *adam_hyper, float beta1, float beta2,
+                                     float eps, ngp_stream_t stream);
+/* adam_param != NULL (single GPU, no weight decay / TV on the table): the gradient of a chunk never leaves LDS -- the
+ * reduce kernel applies torch.optim.Adam to the chunk's rows of `adam_param` directly (hyper as in
+ * ngp_x_adam_step_dev) and grad_embeddings is neither read nor written.  Requires a workspace prepared with
+ * single_segment != 0 (one workgroup per 4096-row chunk). */
 
 /* grad_inputs[b, d] = sum_{l, ch} grad[l, b, ch] * dy_dx[b, l, d, ch] -- the second half of
  * ngp_grid_encode_backward (gridencoder.cu:352-378) on its own. */
@@ -263,7 +274,10 @@ int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float *dirs, con
 int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, const float *embeddings, const int32_t *offsets,
                                    float *out, float *inputs01, const int32_t *B_dev, uint32_t B_cap, uint32_t stride,
                                    uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
-                                   int align_corners, uint32_t interp, ngp_stream_t stream);
+                                   int align_corners, uint32_t interp, void *binned_workspace, uint32_t n_rows_total,
+                                   ngp_stream_t stream);
+/* binned_workspace != NULL: a workspace of ngp_x_grid_backward_binned_prepare(stage 1) for the same samples; the
+ * kernel also counts the records per 4096-row chunk (n_rows_total = rows of the whole table). */
 
 /* ngp_composite_rays_train_forward / _backward with one wave per ray (prefix product / scans instead of the
  * serial walk).  Same arguments and results, except that EVERY sample of a live ray is written (zeros after

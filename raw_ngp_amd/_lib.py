@@ -43,14 +43,15 @@ _SIGNATURES = {
     "ngp_composite_rays": [_u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _p],
     "ngp_x_grid_encode_backward_binned": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
                                           ctypes.c_size_t],
-    "ngp_x_grid_backward_binned_prepare": [_p, _f, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p, ctypes.c_size_t],
+    "ngp_x_grid_backward_binned_prepare": [_p, _f, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _i, _u, _i, _p,
+                                           ctypes.c_size_t],
     "ngp_x_grid_backward_binned_apply": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
-                                         ctypes.c_size_t],
+                                         ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
-    "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u],
+    "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
     "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
     "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
     "ngp_x_composite_mse_backward": [_p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p],
@@ -271,22 +272,31 @@ class _GridBackend:
 
     @staticmethod
     def grid_backward_binned_prepare(inputs, in_bound, offsets, n_rows, B_dev, B_cap, L, max_level, S, H, workspace,
-                                     gridtype=0, align_corners=False, interp=0):
-        """Positions-only half (plan, count, scan).  in_bound > 0: `inputs` are world positions."""
-        _call("ngp_x_grid_backward_binned_prepare", inputs, _ptr(inputs, "f", "inputs"), float(in_bound),
+                                     gridtype=0, align_corners=False, interp=0, single_segment=False, merge_max_res=0,
+                                     stage=0):
+        """Positions-only half (plan, count, scan).  in_bound > 0: `inputs` are world positions.
+        single_segment: one reduce workgroup per chunk (what the fused-Adam apply needs)."""
+        _call("ngp_x_grid_backward_binned_prepare", offsets, _ptr(inputs, "f", "inputs", stage != 0), float(in_bound),
               _ptr(offsets, "i", "offsets"), _ptr(B_dev, "i", "B_dev", True), B_cap, L, max_level, float(S), H, gridtype,
-              int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets), workspace.data_ptr(),
-              workspace.numel())
+              int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets),
+              int(bool(single_segment)), int(merge_max_res), int(stage), workspace.data_ptr(), workspace.numel())
 
     @staticmethod
     def grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
-                                   workspace, gridtype=0, align_corners=False, interp=0):
-        """Fill + reduce on a workspace prepared for the same positions."""
+                                   workspace, gridtype=0, align_corners=False, interp=0, adam=None):
+        """Fill + reduce on a workspace prepared for the same positions.  adam = (param, exp_avg, exp_avg_sq, hyper,
+        beta1, beta2, eps): apply the optimiser inside the reduce kernel instead of writing grad_embeddings."""
+        n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
+        extra = [None, None, None, None, 0.0, 0.0, 0.0]
+        if adam is not None:
+            p_, m_, v_, hyper, b1, b2, eps = adam
+            extra = [_ptr(p_, "f", "adam_param"), _ptr(m_, "f", "adam_exp_avg"), _ptr(v_, "f", "adam_exp_avg_sq"),
+                     _ptr(hyper, "f", "adam_hyper"), float(b1), float(b2), float(eps)]
         _call("ngp_x_grid_backward_binned_apply", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
-              _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings"),
+              _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings", adam is not None),
               _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
-              int(bool(align_corners)), interp, grad_embeddings.shape[0], _GridBackend._max_level_rows(offsets),
-              workspace.data_ptr(), workspace.numel())
+              int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets),
+              workspace.data_ptr(), workspace.numel(), *extra)
 
     @staticmethod
     def backward_workspace_bytes(B, L, rows):
@@ -488,11 +498,12 @@ class _EngineBackend:
 
     @staticmethod
     def grid_encode_forward_slab(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L, max_level, S,
-                                 H, gridtype=0, align_corners=False, interp=0):
+                                 H, gridtype=0, align_corners=False, interp=0, binned_workspace=None):
         _call("ngp_x_grid_encode_forward_slab", xyzs, _ptr(xyzs, "f", "xyzs"), float(bound),
               _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"), _ptr(out, "f", "out"),
               _ptr(inputs01, "f", "inputs01", True), _ptr(B_dev, "i", "B_dev", True), B_cap, stride, L, max_level,
-              float(S), H, gridtype, int(bool(align_corners)), interp)
+              float(S), H, gridtype, int(bool(align_corners)), interp,
+              binned_workspace.data_ptr() if binned_workspace is not None else None, embeddings.shape[0])
 
     @staticmethod
     def composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum, depth, image):

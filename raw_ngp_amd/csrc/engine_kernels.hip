@@ -13,84 +13,115 @@
 //                         (renderer.py:672), producing d sigma / d rgb directly
 //   adam                  torch.optim.Adam (main.py:245: eps 1e-15, no weight decay) in one pass
 //   near_far_v2           the torch slab test run_cuda really uses (renderer.py:139-158): /(d + 1e-15), miss -> 1e9
-#include "grid_common.hpp"
+#include "binned_common.hpp"
 #include "rng_common.hpp"
 
 namespace ngp {
 
 // ------------------------------------------------------------------ hash-grid forward into the slab
+// COUNT: also size the bins of the binned table backward (grid_backward_binned.hip: what bin_count_kernel does) --
+// the rows of all 8 corners are in registers here and the kernel waits on its gathers anyway, so the LDS histogram
+// rides along for free and the backward needs no counting pass of its own.
+template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     const float *__restrict__ xyzs, float bound, const float *__restrict__ table, const int32_t *__restrict__ offsets,
     float *__restrict__ out, float *__restrict__ inputs01, const int32_t *__restrict__ B_dev, uint32_t B_cap,
-    uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp)
+    uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w)
 {
+    extern __shared__ uint32_t hist[];
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t level = item / nchunks;
-    const uint32_t b = (item - level * nchunks) * kBlock + threadIdx.x;
+    const uint32_t b0 = (item - level * nchunks) * kBlock, b = b0 + threadIdx.x;
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
-    if (b >= B) return;
+    if (b0 >= B) return;   // whole workgroup
 
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
+    uint32_t first = 0, nbins = 0;
+    if (COUNT) {
+        first = w.chunk_base[level];
+        nbins = w.chunk_base[level + 1] - first;
+        for (uint32_t i = threadIdx.x; i < nbins; i += kBlock) hist[i] = 0;
+        __syncthreads();
+    }
     const float *__restrict__ tab = table + (size_t)(uint32_t)offsets[level] * 2;
-    float x[3];
+    const bool have = b < B;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (have) {
 #pragma unroll
-    for (uint32_t d = 0; d < 3; d++) x[d] = (xyzs[(size_t)b * 3 + d] + bound) / (2.0f * bound);
-    if (level == 0 && inputs01) {
+        for (uint32_t d = 0; d < 3; d++) x[d] = (xyzs[(size_t)b * 3 + d] + bound) / (2.0f * bound);
+        if (level == 0 && inputs01) {
 #pragma unroll
-        for (uint32_t d = 0; d < 3; d++) inputs01[(size_t)b * 3 + d] = x[d];
+            for (uint32_t d = 0; d < 3; d++) inputs01[(size_t)b * 3 + d] = x[d];
+        }
     }
     float2 *dst = reinterpret_cast<float2 *>(out) + (size_t)level * stride + b;
-    Cell<3> cl;
-    if (!locate<3>(x, g.res, align_corners, interp, cl)) {
-        *dst = make_float2(0.f, 0.f);
-        return;
-    }
+    Cell<3> cl = {};
+    const bool live = have && locate<3>(x, g.res, align_corners, interp, cl);
     // The gathers are bound by the address pipeline (one lane per clock), not by bytes: fetch the two x-neighbours of a
     // corner pair with ONE 16-byte load whenever their rows are adjacent -- always on dense levels (stride 1 along x),
     // and on hashed levels when the cell's x is even (prime_x = 1, so the two hashes differ in bit 0 only).
-    Row<2> rows[8];
-    float wts[8];
-    const uint32_t x0 = cl.c[0], x1 = min(cl.c[0] + 1u, g.res - 1u);
-#pragma unroll
-    for (uint32_t yz = 0; yz < 4; yz++) {
-        uint32_t c[3];
-#pragma unroll
-        for (uint32_t d = 1; d < 3; d++) c[d] = (yz & (1u << (d - 1))) ? min(cl.c[d] + 1u, g.res - 1u) : cl.c[d];
-        c[0] = x0;
-        const uint32_t ra = row_of<3>(g, c);
-        c[0] = x1;
-        const uint32_t rb = row_of<3>(g, c);
-        // weights in the reference's multiplication order: x factor first
-        float wa = 1.0f - cl.f[0], wb = cl.f[0];
-#pragma unroll
-        for (uint32_t d = 1; d < 3; d++) {
-            const float f = (yz & (1u << (d - 1))) ? cl.f[d] : 1.0f - cl.f[d];
-            wa *= f;
-            wb *= f;
-        }
-        const uint32_t ca = yz * 2u, cb = yz * 2u + 1u;
-        wts[ca] = wa;
-        wts[cb] = wb;
-        if (rb == ra + 1u || ra == rb + 1u) {
-            const uint32_t lo = min(ra, rb);
-            const float4 v = *reinterpret_cast<const float4 *>(tab + (size_t)lo * 2);
-            const bool a_first = ra < rb;
-            rows[ca].v[0] = a_first ? v.x : v.z;
-            rows[ca].v[1] = a_first ? v.y : v.w;
-            rows[cb].v[0] = a_first ? v.z : v.x;
-            rows[cb].v[1] = a_first ? v.w : v.y;
-        } else {
-            rows[ca].load(tab + (size_t)ra * 2);
-            rows[cb].load(tab + (size_t)rb * 2);
-        }
-    }
+    uint32_t row_id[8];
     float ax = 0.f, ay = 0.f;
+    if (live) {
+        Row<2> rows[8];
+        float wts[8];
+        const uint32_t x0 = cl.c[0], x1 = min(cl.c[0] + 1u, g.res - 1u);
 #pragma unroll
-    for (uint32_t corner = 0; corner < 8; corner++) {
-        ax = fmaf(wts[corner], rows[corner].v[0], ax);
-        ay = fmaf(wts[corner], rows[corner].v[1], ay);
+        for (uint32_t yz = 0; yz < 4; yz++) {
+            uint32_t c[3];
+#pragma unroll
+            for (uint32_t d = 1; d < 3; d++) c[d] = (yz & (1u << (d - 1))) ? min(cl.c[d] + 1u, g.res - 1u) : cl.c[d];
+            c[0] = x0;
+            const uint32_t ra = row_of<3>(g, c);
+            c[0] = x1;
+            const uint32_t rb = row_of<3>(g, c);
+            // weights in the reference's multiplication order: x factor first
+            float wa = 1.0f - cl.f[0], wb = cl.f[0];
+#pragma unroll
+            for (uint32_t d = 1; d < 3; d++) {
+                const float f = (yz & (1u << (d - 1))) ? cl.f[d] : 1.0f - cl.f[d];
+                wa *= f;
+                wb *= f;
+            }
+            const uint32_t ca = yz * 2u, cb = yz * 2u + 1u;
+            wts[ca] = wa;
+            wts[cb] = wb;
+            row_id[ca] = ra;
+            row_id[cb] = rb;
+            if (rb == ra + 1u || ra == rb + 1u) {
+                const uint32_t lo = min(ra, rb);
+                const float4 v = *reinterpret_cast<const float4 *>(tab + (size_t)lo * 2);
+                const bool a_first = ra < rb;
+                rows[ca].v[0] = a_first ? v.x : v.z;
+                rows[ca].v[1] = a_first ? v.y : v.w;
+                rows[cb].v[0] = a_first ? v.z : v.x;
+                rows[cb].v[1] = a_first ? v.w : v.y;
+            } else {
+                rows[ca].load(tab + (size_t)ra * 2);
+                rows[cb].load(tab + (size_t)rb * 2);
+            }
+        }
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; corner++) {
+            ax = fmaf(wts[corner], rows[corner].v[0], ax);
+            ay = fmaf(wts[corner], rows[corner].v[1], ay);
+        }
     }
-    *dst = make_float2(ax, ay);
+    if (have) *dst = make_float2(ax, ay);   // zeros outside [0,1]^3, like the reference
+    if (COUNT) {
+        bool emit = live;
+        if (mergeable(g, w)) {   // level-uniform; every lane of the wave gets here
+            uint32_t dist;
+            emit = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
+        }
+        if (emit) {
+#pragma unroll
+            for (uint32_t corner = 0; corner < 8; corner++) atomicAdd(&hist[row_id[corner] >> kChunkShift], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nbins; i += kBlock)
+            if (hist[i]) atomicAdd(&w.count[first + i], hist[i]);
+    }
 }
 
 // ------------------------------------------------------------------ wave scans
@@ -456,7 +487,7 @@ extern "C" int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, co
                                               const int32_t *offsets, float *out, float *inputs01, const int32_t *B_dev,
                                               uint32_t B_cap, uint32_t stride, uint32_t L, uint32_t max_level, float S,
                                               uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
-                                              ngp_stream_t stream)
+                                              void *binned_workspace, uint32_t n_rows_total, ngp_stream_t stream)
 {
     if (B_cap == 0 || max_level == 0) return NGP_OK;
     NGP_REQUIRE(xyzs && embeddings && offsets && out, "grid_encode_forward_slab: null tensor");
@@ -466,9 +497,21 @@ extern "C" int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, co
     NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_forward_slab: L must be in [1, %u]", kMaxLevels);
     NGP_REQUIRE(max_level <= L, "grid_encode_forward_slab: max_level > L");
     const uint32_t nchunks = ceil_div(B_cap, kBlock);
-    grid_forward_slab_kernel<<<dim3(nchunks * max_level), dim3(kBlock), 0, as_stream(stream)>>>(
-        xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype, align_corners != 0,
-        interp);
+    if (binned_workspace) {
+        // the workspace of ngp_x_grid_backward_binned_* for the same samples, planned (mode 2 of prepare): count here
+        NGP_REQUIRE(max_level == L && ((uintptr_t)binned_workspace & 15u) == 0 && n_rows_total > 0,
+                    "grid_encode_forward_slab: counting needs max_level == L and an aligned binned workspace");
+        const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
+        NGP_REQUIRE(n_chunks_max <= kMaxChunks, "grid_encode_forward_slab: table too large for the binned backward");
+        const WsLayout w = ws_layout(binned_workspace, n_chunks_max);
+        grid_forward_slab_kernel<true><<<dim3(nchunks * max_level), dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
+            xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
+            align_corners != 0, interp, w);
+    } else {
+        grid_forward_slab_kernel<false><<<dim3(nchunks * max_level), dim3(kBlock), 0, as_stream(stream)>>>(
+            xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
+            align_corners != 0, interp, WsLayout{});
+    }
     NGP_CHECK_LAUNCH("grid_encode_forward_slab");
     return NGP_OK;
 }

@@ -22,59 +22,13 @@
 //
 // Result: the reference's sums, each rounded once (resolution 2^-37 of the largest contribution) instead of
 // once per atomic in hardware order; bitwise reproducible except for the few multi-segment chunks.
-#include "grid_common.hpp"
+#include "binned_common.hpp"
 
 namespace ngp {
 
-constexpr uint32_t kChunkRows = 4096;    // rows per chunk: 4096 x float2 = 32 KiB of LDS
-constexpr uint32_t kChunkShift = 12;
-constexpr uint32_t kSeg = 32768;         // records per reduce work item
-constexpr uint32_t kMaxChunks = 2048;    // LDS histogram bound of the binned path (tables up to 8 M rows)
-constexpr uint32_t kSegBig = 8 * kSeg;   // ... of a heavy chunk (coarse dense levels): fewer, longer items
-constexpr uint32_t kReduceBlock = 512;
-constexpr int kHeadroomBits = 25;        // records that may land on one row without overflowing the int64 sum
-constexpr uint32_t kFillTile = 512;      // samples per fill workgroup
-constexpr uint32_t kFillBlock = 512;     // ... one per lane
-constexpr uint32_t kCountTile = 2048;    // samples per count workgroup (8 per lane)
-
-// workspace header (uint32 words); arrays sized for n_chunks_max
-struct WsLayout {
-    uint32_t *chunk_base;   // [kMaxLevels + 1] first chunk of each level; [L] = total chunks; [kMaxLevels + 1] = max |grad| bits
-    uint32_t *count;        // [n_chunks_max]
-    uint32_t *cursor;       // [n_chunks_max]
-    uint32_t *offset;       // [n_chunks_max + 1] record offsets (multiples of 4)
-    uint32_t *seg_base;     // [n_chunks_max + 1] first reduce work item of each chunk
-    uint32_t *records;      // 3 words per record
-};
-
-__host__ __device__ inline WsLayout ws_layout(void *ws, uint32_t n_chunks_max)
-{
-    WsLayout w;
-    uint32_t *p = reinterpret_cast<uint32_t *>(ws);
-    w.chunk_base = p;
-    p += kMaxLevels + 4;
-    w.count = p;
-    p += n_chunks_max;
-    w.cursor = p;
-    p += n_chunks_max;
-    w.offset = p;
-    p += n_chunks_max + 1;
-    w.seg_base = p;
-    p += n_chunks_max + 1;
-    p += (4 - ((uintptr_t)(p - reinterpret_cast<uint32_t *>(ws)) & 3)) & 3;
-    w.records = p;
-    return w;
-}
-
-static inline size_t ws_bytes(uint32_t B, uint32_t L, uint32_t n_chunks_max)
-{
-    const size_t head = (size_t)(kMaxLevels + 4 + 4 * (size_t)n_chunks_max + 2 + 4) * 4;
-    return head + ((size_t)B * L * 8 + 4 * (size_t)n_chunks_max + 8) * 12 + 64;
-}
-
 // ------------------------------------------------------------------ plan
 __global__ __launch_bounds__(1024) void bin_plan_kernel(const int32_t *__restrict__ offsets, uint32_t L,
-                                                        uint32_t n_chunks_max, WsLayout w)
+                                                        uint32_t n_chunks_max, uint32_t merge_max_res, WsLayout w)
 {
     __shared__ uint32_t total;
     if (threadIdx.x == 0) {
@@ -86,6 +40,7 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const int32_t *__restric
         }
         w.chunk_base[L] = run;
         w.chunk_base[kMaxLevels + 1] = 0;   // max |grad| of this call, as float bits
+        w.chunk_base[kMaxLevels + 2] = merge_max_res ? merge_max_res : 1024u;
         total = run;
     }
     __syncthreads();
@@ -127,35 +82,6 @@ __device__ __forceinline__ bool corner_rows(const float *__restrict__ inputs, ui
 // At 4096 rays x ~70 samples this halves the record count and removes the same-address pile-ups of the coarse levels
 // in the LDS histogram and in the reduce kernel's ds_add_u64.  Count and fill use the same lane <-> sample mapping
 // (tiles start at multiples of 16), hence see the same runs.
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t x)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, 0xf, 0xf, false);
-}
-template <int N>
-__device__ __forceinline__ float row_shr_f(float x)   // lane i <- lane i - N of its 16-lane row, 0 if none
-{
-    return __uint_as_float(dpp_u32<0x110 | N>(0u, __float_as_uint(x)));
-}
-
-constexpr uint32_t kDeadKey = 0xffffffffu;
-__device__ __forceinline__ bool mergeable(const Geom<3> &g) { return g.res <= 1024u; }
-__device__ __forceinline__ uint32_t cell_key(const Cell<3> &cl) { return cl.c[0] | (cl.c[1] << 10) | (cl.c[2] << 20); }
-
-// must be called by all lanes of the wave.  dist = lanes back to the head of my run; returns "I am the run's tail"
-__device__ __forceinline__ bool run_shape(uint32_t key, bool live, uint32_t &dist)
-{
-    const uint32_t l16 = threadIdx.x & 15u;
-    const uint32_t prev = dpp_u32<0x111>(0xfffffffeu, key), next = dpp_u32<0x101>(0xfffffffeu, key);
-    uint32_t s = (l16 == 0u || prev != key) ? l16 : 0u;
-    s = max(s, dpp_u32<0x111>(0u, s));
-    s = max(s, dpp_u32<0x112>(0u, s));
-    s = max(s, dpp_u32<0x114>(0u, s));
-    s = max(s, dpp_u32<0x118>(0u, s));
-    dist = l16 - s;
-    return live && (l16 == 15u || next != key);
-}
-
 __device__ __forceinline__ float run_sum(float v, uint32_t dist)
 {
     float t;
@@ -184,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restri
     const uint32_t nbins = w.chunk_base[level + 1] - first;
     for (uint32_t i = threadIdx.x; i < nbins; i += kBlock) hist[i] = 0;
     __syncthreads();
-    const bool merge = mergeable(g);
+    const bool merge = mergeable(g, w);
 #pragma unroll 2
     for (uint32_t k = 0; k < kCountTile / kBlock; k++) {
         const uint32_t b = b0 + k * kBlock + threadIdx.x;
@@ -207,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------ scan
-__global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w)
+__global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w, bool single_segment)
 {
     __shared__ uint32_t wave_a[16], wave_b[16];
     __shared__ uint32_t carry_a, carry_b;
@@ -220,7 +146,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w)
         const uint32_t cnt = i < n ? w.count[i] : 0u;
         const uint32_t cnt4 = (cnt + 3u) & ~3u;   // 4-record alignment: 16-byte loads in the reduce kernel
         const uint32_t seg_len = cnt > kSegBig ? kSegBig : kSeg;   // heavy chunks: 8x longer work items
-        const uint32_t seg = i < n ? max(1u, (cnt + seg_len - 1) / seg_len) : 0u;
+        const uint32_t seg = i < n ? (single_segment ? 1u : max(1u, (cnt + seg_len - 1) / seg_len)) : 0u;
         uint32_t a = cnt4, s = seg;
 #pragma unroll
         for (uint32_t d = 1; d < 64u; d <<= 1) {
@@ -308,7 +234,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
         vy[corner] = live ? wgt * gr.y : 0.0f;
     }
     bool emit = live;
-    if (mergeable(g)) {
+    if (mergeable(g, w)) {
         uint32_t dist;
         emit = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
 #pragma unroll
@@ -384,8 +310,18 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------ reduce
+// Optimiser state for the fused variant: the chunk's gradient never leaves LDS, Adam (torch.optim.Adam, as in
+// engine_kernels.hip: adam_span) is applied to the chunk's rows right there.  Needs one segment per chunk.
+struct AdamArgs {
+    float *param, *exp_avg, *exp_avg_sq;
+    const float *hyper;   // {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)}
+    float b1, b2, eps;
+};
+
+template <bool ADAM>
 __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
-                                                                 float *__restrict__ grad_table, uint32_t L, WsLayout w)
+                                                                 float *__restrict__ grad_table, uint32_t L, WsLayout w,
+                                                                 AdamArgs opt)
 {
     __shared__ unsigned long long acc[kChunkRows * 2];   // 64 KiB: int64 fixed-point sums, [row][channel]
     __shared__ uint32_t s_chunk;
@@ -408,12 +344,12 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     __syncthreads();
     const uint32_t chunk = s_chunk;
     const uint32_t cnt = w.count[chunk];
-    const uint32_t seg_len = cnt > kSegBig ? kSegBig : kSeg;
-    const uint32_t seg = item - w.seg_base[chunk];
     const uint32_t n_seg = w.seg_base[chunk + 1] - w.seg_base[chunk];
+    const uint32_t seg_len = n_seg == 1 ? max(cnt, 1u) : (cnt > kSegBig ? kSegBig : kSeg);
+    const uint32_t seg = item - w.seg_base[chunk];
     const uint32_t beg = w.offset[chunk] + seg * seg_len;                  // multiple of 4 records
     const uint32_t end = min(w.offset[chunk] + cnt, beg + seg_len);
-    if (beg >= end) return;   // empty chunk: nothing to add
+    if (!ADAM && beg >= end) return;   // empty chunk: nothing to add (the fused variant still has rows to update)
 
     // fixed-point scale: max |g| < 2^e  ->  |g * 2^k| < 2^(62 - headroom) with k = 62 - headroom - e
     int e;
@@ -458,7 +394,26 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     const uint32_t rows_here = min(kChunkRows, T - row0);
     float *dst = grad_table + ((size_t)(uint32_t)offsets[level] + row0) * 2;
     auto to_float = [&](unsigned long long q) { return (float)scalbn((double)(long long)q, -k); };
-    if (n_seg == 1) {
+    if (ADAM) {
+        const size_t base = (size_t)(uint32_t)offsets[level] + row0;
+        float2 *p2 = reinterpret_cast<float2 *>(opt.param) + base, *m2 = reinterpret_cast<float2 *>(opt.exp_avg) + base,
+               *v2 = reinterpret_cast<float2 *>(opt.exp_avg_sq) + base;
+        const float step_size = opt.hyper[0] / opt.hyper[1], rsqrt_bc2 = opt.hyper[2];
+        const float b1 = opt.b1, b2 = opt.b2, eps = opt.eps;
+        for (uint32_t i = threadIdx.x; i < rows_here; i += kReduceBlock) {
+            const float gx = to_float(acc[i * 2]), gy = to_float(acc[i * 2 + 1]);
+            float2 pp = p2[i], mm = m2[i], vv = v2[i];
+            mm.x = b1 * mm.x + (1.0f - b1) * gx;
+            vv.x = b2 * vv.x + (1.0f - b2) * gx * gx;
+            pp.x -= step_size * (mm.x / (sqrtf(vv.x) * rsqrt_bc2 + eps));
+            mm.y = b1 * mm.y + (1.0f - b1) * gy;
+            vv.y = b2 * vv.y + (1.0f - b2) * gy * gy;
+            pp.y -= step_size * (mm.y / (sqrtf(vv.y) * rsqrt_bc2 + eps));
+            p2[i] = pp;
+            m2[i] = mm;
+            v2[i] = vv;
+        }
+    } else if (n_seg == 1) {
         float2 *d2 = reinterpret_cast<float2 *>(dst);
         for (uint32_t i = threadIdx.x; i < rows_here; i += kReduceBlock) {
             float2 v = d2[i];
@@ -518,20 +473,26 @@ extern "C" int ngp_x_grid_backward_binned_prepare(const float *inputs, float in_
                                                   const int32_t *B_dev, uint32_t B, uint32_t L, uint32_t max_level,
                                                   float S, uint32_t H, uint32_t gridtype, int align_corners,
                                                   uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
-                                                  void *workspace, size_t workspace_bytes, ngp_stream_t stream)
+                                                  int single_segment, uint32_t merge_max_res, int stage, void *workspace,
+                                                  size_t workspace_bytes, ngp_stream_t stream)
 {
     if (B == 0 || max_level == 0) return NGP_OK;
-    NGP_REQUIRE(inputs, "grid_backward_binned_prepare: null tensor");
+    NGP_REQUIRE(stage >= 0 && stage <= 2, "grid_backward_binned_prepare: stage must be 0 (all), 1 (plan) or 2 (scan)");
+    NGP_REQUIRE(inputs || stage != 0, "grid_backward_binned_prepare: null tensor");
     BinnedCall c;
     const int rc = binned_setup(c, "grid_backward_binned_prepare", offsets, B, L, max_level, S, H, n_rows_total,
                                 max_level_rows, workspace, workspace_bytes);
     if (rc != NGP_OK) return rc;
     hipStream_t st = as_stream(stream);
-    bin_plan_kernel<<<1, 1024, 0, st>>>(offsets, L, c.n_chunks_max, c.w);
-    const uint32_t ct = ceil_div(B, kCountTile);
-    bin_count_kernel<<<ct * max_level, kBlock, (size_t)c.nbins_cap * 4, st>>>(inputs, offsets, B_dev, B, ct, c.lv, gridtype,
-                                                                                align_corners != 0, interp, in_bound, c.w);
-    bin_scan_kernel<<<1, 1024, 0, st>>>(L, c.w);
+    // stage 1 / 2: the counting in between is done by someone who has the rows anyway (ngp_x_grid_encode_forward_slab)
+    if (stage != 2) bin_plan_kernel<<<1, 1024, 0, st>>>(offsets, L, c.n_chunks_max, merge_max_res, c.w);
+    if (stage == 0) {
+        const uint32_t ct = ceil_div(B, kCountTile);
+        bin_count_kernel<<<ct * max_level, kBlock, (size_t)c.nbins_cap * 4, st>>>(inputs, offsets, B_dev, B, ct, c.lv,
+                                                                                    gridtype, align_corners != 0, interp,
+                                                                                    in_bound, c.w);
+    }
+    if (stage != 1) bin_scan_kernel<<<1, 1024, 0, st>>>(L, c.w, single_segment != 0);
     NGP_CHECK_LAUNCH("grid_backward_binned_prepare");
     return NGP_OK;
 }
@@ -542,10 +503,15 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
                                                 uint32_t grad_stride, uint32_t L, uint32_t max_level, float S,
                                                 uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                                 uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
-                                                size_t workspace_bytes, ngp_stream_t stream)
+                                                size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
+                                                float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
+                                                float beta2, float eps, ngp_stream_t stream)
 {
     if (B == 0 || max_level == 0) return NGP_OK;
-    NGP_REQUIRE(grad && inputs && grad_embeddings, "grid_backward_binned_apply: null tensor");
+    const bool fused = adam_param != nullptr;
+    NGP_REQUIRE(grad && inputs && (grad_embeddings || fused), "grid_backward_binned_apply: null tensor");
+    NGP_REQUIRE(!fused || (adam_exp_avg && adam_exp_avg_sq && adam_hyper && max_level == L),
+                "grid_backward_binned_apply: fused Adam needs exp_avg, exp_avg_sq, hyper and max_level == L");
     NGP_REQUIRE(grad_stride >= B, "grid_backward_binned_apply: grad_stride smaller than B");
     BinnedCall c;
     const int rc = binned_setup(c, "grid_backward_binned_apply", offsets, B, L, max_level, S, H, n_rows_total,
@@ -563,7 +529,11 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
                                                                    c.nbins_cap, c.lv, gridtype, align_corners != 0, interp,
                                                                    c.w);
     const uint32_t n_items_max = c.n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
-    bin_reduce_kernel<<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w);
+    const AdamArgs opt{adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps};
+    if (fused)   // prepared with single_segment: one workgroup owns each chunk's rows
+        bin_reduce_kernel<true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
+    else
+        bin_reduce_kernel<false><<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
     NGP_CHECK_LAUNCH("grid_backward_binned_apply");
     return NGP_OK;
 }
@@ -576,10 +546,10 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
                                                  void *workspace, size_t workspace_bytes, ngp_stream_t stream)
 {
     const int rc = ngp_x_grid_backward_binned_prepare(inputs, 0.0f, offsets, B_dev, B, L, max_level, S, H, gridtype,
-                                                      align_corners, interp, n_rows_total, max_level_rows, workspace,
+                                                      align_corners, interp, n_rows_total, max_level_rows, 0, 0, 0, workspace,
                                                       workspace_bytes, stream);
     if (rc != NGP_OK) return rc;
     return ngp_x_grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L, max_level, S, H,
                                             gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
-                                            workspace_bytes, stream);
+                                            workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, 0.0f, stream);
 }

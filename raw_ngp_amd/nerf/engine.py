@@ -104,6 +104,12 @@ class FusedTrainer:
         self.hyper = torch.zeros(4, **f32)                  # {lr, 1 - b1^t, 1/sqrt(1 - b2^t)} of the current step
         # the main stream's part of a step replayed from captured hipGraphs (one per ray slot)
         self.use_graph = bool(getattr(opt, "capture_graph", True)) and opt.lambda_tv == 0 and dev.type == "cuda"
+        # run merging in the binned backward pays while consecutive samples share cells: res * (step in [0,1]) < ~0.7
+        step01 = (2 * math.sqrt(3) / opt.max_steps) / (2 * model.bound)
+        self.merge_max_res = int(min(1024, max(16, 0.7 / step01)))
+        # Adam on the hash table fused into the table-gradient reduction: one rank, nothing else touching the gradient
+        self.fuse_adam = bool(getattr(opt, "fuse_adam", True)) and self.world_size == 1 and opt.lambda_tv == 0 \
+            and opt.lambda_wd == 0
         self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
         self._main_symbols = {"ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
                               "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
@@ -155,9 +161,10 @@ class FusedTrainer:
                                   opt.max_steps, N, m.cascade, m.grid_size, slot.nears, slot.fars, noises, ar.t_scratch,
                                   self.cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, self.occ_index,
                                   ar.chain)
-        # positions are all the table-gradient binning needs to size its bins: do that here, off the main stream
-        gb.grid_backward_binned_prepare(ar.xyzs, m.bound, m.grid_encoder.offsets, self.rows, ar.counter, self.cap, self.L,
-                                        self.L, self.S, self.H, slot.ws_grid)
+        # reset the bookkeeping of the binned table backward for this batch (stage 1: plan); the encoder's forward
+        # pass counts the records per chunk while it has the rows in registers, a scan (stage 2) follows it
+        gb.grid_backward_binned_prepare(None, 0.0, m.grid_encoder.offsets, self.rows, ar.counter, self.cap, self.L,
+                                        self.L, self.S, self.H, slot.ws_grid, merge_max_res=self.merge_max_res, stage=1)
 
     def forward_backward(self, rays_o, rays_d, gt_rgba, noises, bg_rgb=None, bg_const=0.0):
         """march -> encode -> MLP -> composite -> loss -> backward into self.table_grad / self.w_grad."""
@@ -169,10 +176,12 @@ class FusedTrainer:
         for _, op in self._field_ops(slot, gt_rgba, bg_rgb, bg_const):
             op()
 
-    def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True):
+    def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False):
         """The field part of the step as (C entry point, thunk) pairs, in launch order."""
         opt, m, ar, N, cap = self.opt, self.model, slot.arena, self.N, self.cap
         cnt, offsets = ar.counter, m.grid_encoder.offsets
+        # single GPU: the table's Adam step happens inside the reduce kernel (the gradient never reaches HBM)
+        adam = (self.table, self.t_m, self.t_v, self.hyper, *self.betas, self.eps) if fused_adam else None
 
         def loss_and_composite_backward():
             if zero_loss:
@@ -182,7 +191,11 @@ class FusedTrainer:
 
         return [
             ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
-                ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt, cap, cap, self.L, self.L, self.S, self.H)),
+                ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt, cap, cap, self.L, self.L, self.S, self.H,
+                binned_workspace=slot.ws_grid)),
+            ("ngp_x_grid_backward_binned_prepare", lambda: gb.grid_backward_binned_prepare(
+                None, 0.0, offsets, self.rows, cnt, cap, self.L, self.L, self.S, self.H, slot.ws_grid,
+                single_segment=fused_adam, stage=2)),
             ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image)),
             ("ngp_x_mlp_forward", lambda: mb.forward(self.enc, cap, ar.dirs, cnt, cap, self.mlp_image, self.sigma,
                                                      self.rgb)),
@@ -194,7 +207,7 @@ class FusedTrainer:
                                                        self.mlp_image, opt.loss_scale, self.denc, self.dws, self.ws_mlp)),
             ("ngp_x_grid_backward_binned_apply", lambda: gb.grid_backward_binned_apply(
                 self.denc, self.x01, offsets, self.table_grad, cnt, cap, cap, self.L, self.L, self.S, self.H,
-                slot.ws_grid)),
+                slot.ws_grid, adam=adam)),
         ]
 
     @torch.no_grad()
@@ -299,10 +312,15 @@ class FusedTrainer:
         ops = [("ngp_x_step_begin", lambda: eb.step_begin(self.step_ctr, self.hyper, self.lr0, float(opt.iters),
                                                            *self.betas, self.loss, self.samples_seen,
                                                            slot.arena.counter))]
-        ops += self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False)
+        ops += self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False,
+                               fused_adam=self.fuse_adam)
         if self.world_size > 1:
             ops.append(("all_reduce", self.reduce_gradients))
-        ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True)))
+        if self.fuse_adam:          # only the MLP weights are left
+            ops.append(("ngp_x_adam_step_dev", lambda: eb.adam_step_dev(self.w_flat, self.w_grad, self.w_m, self.w_v,
+                                                                         self.hyper, *self.betas, self.eps, False)))
+        else:
+            ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True)))
         return ops
 
     def _capture(self, slot, timed):

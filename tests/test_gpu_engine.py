@@ -327,3 +327,67 @@ def test_density_grid_sample_with_nothing_occupied(lib):
     xyz = torch.empty(2048, 3, device="cuda")
     e.density_grid_sample(grid, H, 0.9, 0.1, 1024, 1024, False, 1, 0, ws, idx, xyz)
     assert torch.all(idx[1024:] == -1) and torch.all(idx[:1024] >= 0) and torch.all(xyz[1024:] == 0)
+
+
+def test_fused_adam_matches_separate_adam(lib):
+    """Adam applied inside the table-gradient reduction (single GPU default) vs gradient to HBM + Adam kernel."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    tabs = []
+    for fuse in (True, False):
+        torch.manual_seed(0)
+        opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True, capture_graph=False, fuse_adam=fuse)
+        data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
+        eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
+        assert eng.fuse_adam == fuse
+        t0 = eng.table.clone()
+        for _ in range(3):
+            eng.train_step()
+        torch.cuda.synchronize()
+        tabs.append((eng.table.clone() - t0, eng.t_m.clone(), eng.t_v.clone(), float(eng.loss)))
+    (da, ma, va, la), (db, mb_, vb, lb) = tabs
+    assert float(da.abs().max()) > 1e-3                       # the table moved (3 steps of lr 1e-2)
+    np.testing.assert_allclose(la, lb, rtol=1e-3)
+    # first moments agree to the precision of the gradient sums; the parameter step is +-lr when |m|/sqrt(v) ~ 1
+    assert float((ma - mb_).abs().max()) <= 1e-3 * float(mb_.abs().max()) + 1e-12
+    assert float((da - db).abs().mean()) < 0.02 * float(db.abs().mean())
+
+
+def test_slab_forward_counts_like_the_count_kernel(lib, orc):
+    """Bin sizes of the binned backward: counted by the encoder's forward pass (stage 1 + forward + stage 2) vs by the
+    stand-alone count kernel (stage 0) -- identical workspace headers, with and without run merging."""
+    rng = np.random.default_rng(4)
+    B, L, H, bound = 20000, 16, 16, 1.0
+    offsets, scale = orc.grid_offsets(desired_resolution=2048)
+    S, rows = float(np.log2(scale)), int(offsets[-1])
+    # ray-like runs: 400 rays x 50 steps of 0.0034, plus a few points outside the box
+    o = rng.uniform(-0.8, 0.8, (400, 1, 3))
+    d = rng.normal(size=(400, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    xyz = (o + d * (np.arange(50)[None, :, None] * 0.0034)).reshape(-1, 3).astype(np.float32)
+    xyz[::997] = 1.5
+    gb, eb = lib.gridencoder_backend, lib.engine_backend
+    table = dev(rng.uniform(-1, 1, (rows, 2)).astype(np.float32))
+    n_chunks_max = rows // 4096 + L + 1
+    head_words = 64 + 4 + 4 * n_chunks_max + 2
+    for merge in (0, 300):
+        ws_a = torch.zeros(gb.backward_workspace_bytes(B, L, rows), dtype=torch.uint8, device="cuda")
+        ws_b = torch.zeros_like(ws_a)
+        cnt = torch.tensor([B, B, 0, 0], dtype=torch.int32, device="cuda")
+        gb.grid_backward_binned_prepare(dev(xyz), bound, dev(offsets), rows, cnt, B, L, L, S, H, ws_a, merge_max_res=merge)
+        gb.grid_backward_binned_prepare(None, 0.0, dev(offsets), rows, cnt, B, L, L, S, H, ws_b, merge_max_res=merge, stage=1)
+        enc, x01 = torch.empty(L, B, 2, device="cuda"), torch.empty(B, 3, device="cuda")
+        eb.grid_encode_forward_slab(dev(xyz), bound, table, dev(offsets), enc, x01, cnt, B, B, L, L, S, H,
+                                    binned_workspace=ws_b)
+        gb.grid_backward_binned_prepare(None, 0.0, dev(offsets), rows, cnt, B, L, L, S, H, ws_b, stage=2)
+        a = host(ws_a[:head_words * 4]).view(np.uint32)
+        b = host(ws_b[:head_words * 4]).view(np.uint32)
+        np.testing.assert_array_equal(a, b)
+        counts = a[68:68 + n_chunks_max]
+        assert counts.sum() > 0 and (merge == 0 or counts.sum() < 0.8 * B * L * 8)
+        # and the forward result itself is unchanged by the counting
+        enc2 = torch.empty_like(enc)
+        eb.grid_encode_forward_slab(dev(xyz), bound, table, dev(offsets), enc2, x01, cnt, B, B, L, L, S, H)
+        assert torch.equal(enc, enc2)

@@ -48,8 +48,9 @@ def main():
     cnt = torch.tensor([B, B, 0, 0], dtype=torch.int32, device=dev)
 
     def once():
-        eb.grid_encode_forward_slab(xyz, 1.0, table, offsets, enc, x01, cnt, B, B, L, L, S, H)
-        gb.grid_backward_binned_prepare(xyz, 1.0, offsets, rows, cnt, B, L, L, S, H, ws)
+        gb.grid_backward_binned_prepare(None, 0.0, offsets, rows, cnt, B, L, L, S, H, ws, merge_max_res=414, stage=1)
+        eb.grid_encode_forward_slab(xyz, 1.0, table, offsets, enc, x01, cnt, B, B, L, L, S, H, binned_workspace=ws)
+        gb.grid_backward_binned_prepare(None, 0.0, offsets, rows, cnt, B, L, L, S, H, ws, stage=2)
         gb.grid_backward_binned_apply(denc, x01, offsets, grad, cnt, B, B, L, L, S, H, ws)
 
     for _ in range(3):
