@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--roofline-kernel", default="ngp_x_grid_backward_binned", choices=sorted(ROOFLINE_KERNELS))
     ap.add_argument("--cpu-rays", type=int, default=1024)
-    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--psnr-iters", type=int, default=0, help="if > 0: keep training to this many iterations and report PSNR")
     ap.add_argument("--arena", type=int, default=0, help="sample arena capacity (0 = reference two-pass march)")
