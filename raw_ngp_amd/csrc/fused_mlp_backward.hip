@@ -149,10 +149,15 @@ __device__ __forceinline__ TileInB<WANT_SH> convert_raw(const RawTile &r, uint32
 template <int S>
 __device__ __forceinline__ half8 pack_masked(const f32x16 &a, const half8 &act)
 {
+    // mask = all ones where act > 0, built with packed 16-bit integer ops on the f16 bit patterns (a positive f16 is
+    // a positive int16; -0 is negative): clamp to {0, 1}, multiply by 0xffff
+    typedef short short8 __attribute__((ext_vector_type(8)));
     half8 o;
 #pragma unroll
-    for (int t = 0; t < 8; t++) o[t] = (_Float16)(act[t] > (_Float16)0.0f ? a[8 * S + t] : 0.0f);
-    return o;
+    for (int t = 0; t < 8; t++) o[t] = (_Float16)a[8 * S + t];
+    short8 m = __builtin_bit_cast(short8, act);
+    m = __builtin_elementwise_min(__builtin_elementwise_max(m, (short8)0), (short8)1) * (short8)-1;
+    return __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, o) & m));
 }
 
 __device__ __forceinline__ half8 identity_frag(uint32_t s, uint32_t lane)
