@@ -65,16 +65,10 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     if (live) {
         Row<2> rows[8];
         float wts[8];
-        const uint32_t x0 = cl.c[0], x1 = min(cl.c[0] + 1u, g.res - 1u);
+        const AxisTerms<3> terms = axis_terms<3>(g, cl);
 #pragma unroll
         for (uint32_t yz = 0; yz < 4; yz++) {
-            uint32_t c[3];
-#pragma unroll
-            for (uint32_t d = 1; d < 3; d++) c[d] = (yz & (1u << (d - 1))) ? min(cl.c[d] + 1u, g.res - 1u) : cl.c[d];
-            c[0] = x0;
-            const uint32_t ra = row_of<3>(g, c);
-            c[0] = x1;
-            const uint32_t rb = row_of<3>(g, c);
+            const uint32_t ra = row_from_terms<3>(g, terms, yz * 2u), rb = row_from_terms<3>(g, terms, yz * 2u + 1u);
             // weights in the reference's multiplication order: x factor first
             float wa = 1.0f - cl.f[0], wb = cl.f[0];
 #pragma unroll

@@ -65,13 +65,9 @@ __device__ __forceinline__ bool corner_rows(const float *__restrict__ inputs, ui
         if (in_bound > 0.0f) x[d] = (x[d] + in_bound) / (2.0f * in_bound);
     }
     if (!locate<3>(x, g.res, align_corners, interp, cl)) return false;
+    const AxisTerms<3> a = axis_terms<3>(g, cl);
 #pragma unroll
-    for (uint32_t corner = 0; corner < 8; corner++) {
-        uint32_t c[3];
-#pragma unroll
-        for (uint32_t d = 0; d < 3; d++) c[d] = (corner & (1u << d)) ? min(cl.c[d] + 1u, g.res - 1u) : cl.c[d];
-        rows[corner] = row_of<3>(g, c);
-    }
+    for (uint32_t corner = 0; corner < 8; corner++) rows[corner] = row_from_terms<3>(g, a, corner);
     return true;
 }
 
@@ -82,13 +78,30 @@ __device__ __forceinline__ bool corner_rows(const float *__restrict__ inputs, ui
 // At 4096 rays x ~70 samples this halves the record count and removes the same-address pile-ups of the coarse levels
 // in the LDS histogram and in the reduce kernel's ds_add_u64.  Count and fill use the same lane <-> sample mapping
 // (tiles start at multiples of 16), hence see the same runs.
-__device__ __forceinline__ float run_sum(float v, uint32_t dist)
+// segmented inclusive sum along the run: step d adds the value d lanes back when that lane belongs to my run.
+// Written as fma(shifted, flag_d, v) with flag_d in {0, 1} so that the shift and the add fuse into one
+// v_fmac_f32_dpp (16 values x 4 steps = 64 instructions per lane instead of 192)
+struct RunFlags {
+    float f1, f2, f4, f8;
+};
+__device__ __forceinline__ RunFlags run_flags(uint32_t dist)
 {
+    return {dist >= 1u ? 1.0f : 0.0f, dist >= 2u ? 1.0f : 0.0f, dist >= 4u ? 1.0f : 0.0f, dist >= 8u ? 1.0f : 0.0f};
+}
+__device__ __forceinline__ float run_sum(float v, const RunFlags &f)
+{
+#if NGP_RUNSUM_SELECT
     float t;
-    t = row_shr_f<1>(v); v += dist >= 1u ? t : 0.0f;
-    t = row_shr_f<2>(v); v += dist >= 2u ? t : 0.0f;
-    t = row_shr_f<4>(v); v += dist >= 4u ? t : 0.0f;
-    t = row_shr_f<8>(v); v += dist >= 8u ? t : 0.0f;
+    t = row_shr_f<1>(v); v += f.f1 != 0.0f ? t : 0.0f;
+    t = row_shr_f<2>(v); v += f.f2 != 0.0f ? t : 0.0f;
+    t = row_shr_f<4>(v); v += f.f4 != 0.0f ? t : 0.0f;
+    t = row_shr_f<8>(v); v += f.f8 != 0.0f ? t : 0.0f;
+#else
+    v = fmaf(row_shr_f<1>(v), f.f1, v);
+    v = fmaf(row_shr_f<2>(v), f.f2, v);
+    v = fmaf(row_shr_f<4>(v), f.f4, v);
+    v = fmaf(row_shr_f<8>(v), f.f8, v);
+#endif
     return v;
 }
 
@@ -237,10 +250,11 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     if (mergeable(g, w)) {
         uint32_t dist;
         emit = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
+        const RunFlags flags = run_flags(dist);
 #pragma unroll
         for (uint32_t corner = 0; corner < 8; corner++) {
-            vx[corner] = run_sum(vx[corner], dist);
-            vy[corner] = run_sum(vy[corner], dist);
+            vx[corner] = run_sum(vx[corner], flags);
+            vy[corner] = run_sum(vy[corner], flags);
         }
     }
     if (emit) {

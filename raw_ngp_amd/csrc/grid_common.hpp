@@ -74,12 +74,49 @@ __device__ __forceinline__ uint32_t row_of(const Geom<D> &g, const uint32_t (&c)
     return idx;
 }
 
+// Per-axis index terms of a cell's two coordinates (c and min(c + 1, res - 1)): c * prime (hashed) or c * stride
+// (dense).  The 2^D corner rows are combinations of these, so the multiplies are done D times instead of D * 2^D
+// (v_mul_lo_u32 runs at quarter rate) and the second term of an axis is the first plus the multiplier.
+template <uint32_t D>
+struct AxisTerms {
+    uint32_t t[D][2];
+};
+
+template <uint32_t D>
+__device__ __forceinline__ uint32_t row_from_terms(const Geom<D> &g, const AxisTerms<D> &a, uint32_t corner)
+{
+    uint32_t idx = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t v = a.t[d][(corner >> d) & 1u];
+        idx = g.hashed ? (idx ^ v) : (idx + v);
+    }
+    if (g.mode == 1)
+        idx &= g.T - 1u;
+    else if (g.mode == 2)
+        idx %= g.T;
+    return idx;
+}
+
 template <uint32_t D>
 struct Cell {
     uint32_t c[D];
     float f[D];
     float df[D];
 };
+
+template <uint32_t D>
+__device__ __forceinline__ AxisTerms<D> axis_terms(const Geom<D> &g, const Cell<D> &cl)
+{
+    AxisTerms<D> a;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t m = g.hashed ? kPrimes[d] : g.stride[d];
+        a.t[d][0] = cl.c[d] * m;
+        a.t[d][1] = cl.c[d] + 1u <= g.res - 1u ? a.t[d][0] + m : a.t[d][0];   // c + 1 clamped to res - 1
+    }
+    return a;
+}
 
 // false when the point is outside [0,1]^D (the reference zeroes / skips those)
 template <uint32_t D>

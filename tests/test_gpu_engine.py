@@ -343,16 +343,16 @@ def test_fused_adam_matches_separate_adam(lib):
         eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
         assert eng.fuse_adam == fuse
         t0 = eng.table.clone()
-        for _ in range(3):
-            eng.train_step()
-        torch.cuda.synchronize()
+        eng.train_step()         # ONE step: later steps amplify rounding differences (Adam moves rows with a
+        torch.cuda.synchronize()  # near-zero gradient by +-lr whichever sign the rounding gives it)
         tabs.append((eng.table.clone() - t0, eng.t_m.clone(), eng.t_v.clone(), float(eng.loss)))
     (da, ma, va, la), (db, mb_, vb, lb) = tabs
-    assert float(da.abs().max()) > 1e-3                       # the table moved (3 steps of lr 1e-2)
-    np.testing.assert_allclose(la, lb, rtol=1e-3)
-    # first moments agree to the precision of the gradient sums; the parameter step is +-lr when |m|/sqrt(v) ~ 1
-    assert float((ma - mb_).abs().max()) <= 1e-3 * float(mb_.abs().max()) + 1e-12
-    assert float((da - db).abs().mean()) < 0.02 * float(db.abs().mean())
+    assert float(da.abs().max()) > 5e-3                       # the table moved (lr 1e-2)
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    # first moments = 0.1 * gradient: equal up to the rounding of the sums
+    assert float((ma - mb_).abs().max()) <= 1e-4 * float(mb_.abs().max()) + 1e-12
+    solid = mb_.abs() > 1e-3 * mb_.abs().max()                # rows whose update direction rounding cannot flip
+    assert float((da - db)[solid].abs().max()) < 1e-3 * float(db.abs().max())
 
 
 def test_slab_forward_counts_like_the_count_kernel(lib, orc):
