@@ -143,9 +143,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--burnin", type=int, default=3000,
-                    help="untimed training steps before warm-up: throughput is quoted mid-run (iteration ~3000 of the "
-                         "5000-iteration schedule), with a learned occupancy grid, not on the all-occupied initial grid")
+    ap.add_argument("--burnin", type=int, default=-1,
+                    help="untimed training steps before warm-up.  Default: as many as it takes for the timed region to "
+                         "END at iteration --psnr-iters (5000): the metric pairs rays/s with PSNR@5k, so the throughput is "
+                         "quoted at that point of the 5000-iteration schedule (learned occupancy grid), and the PSNR is "
+                         "evaluated right after the timed steps")
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--views", type=int, default=100)
     ap.add_argument("--res", type=int, default=800)
@@ -153,7 +155,9 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--psnr-iters", type=int, default=0, help="if > 0: keep training to this many iterations and report PSNR")
+    ap.add_argument("--psnr-iters", type=int, default=5000,
+                    help="report PSNR on held-out views at this iteration (training continues to it after the timed "
+                         "region if needed; 0 = skip)")
     ap.add_argument("--arena", type=int, default=0, help="sample arena capacity (0 = reference two-pass march)")
     ap.add_argument("--torch-mlp", action="store_true", help="fp32 nn.Linear MLPs instead of the fused f16 MFMA field")
     ap.add_argument("--probe-every", type=int, default=4,
@@ -164,6 +168,8 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
     ap.add_argument("--autograd", action="store_true", help="per-op autograd path (Trainer) instead of the fused step")
     args = ap.parse_args()
+    if args.burnin < 0:
+        args.burnin = max((args.psnr_iters or 5000) - args.warmup - args.steps, 300)
 
     rank, world, local = parallel.init_from_env("cuda")
     assert world == max(args.gpus, 1) or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
