@@ -338,23 +338,38 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
                                                                  AdamArgs opt)
 {
     __shared__ unsigned long long acc[kChunkRows * 2];   // 64 KiB: int64 fixed-point sums, [row][channel]
-    __shared__ uint32_t s_chunk;
-    const uint32_t n_chunks = w.chunk_base[L];
-    const uint32_t n_items = w.seg_base[n_chunks];
-    const uint32_t item = blockIdx.x;
-    if (item >= n_items) return;
-    if (threadIdx.x == 0) {   // largest chunk with seg_base[chunk] <= item
-        uint32_t lo = 0, hi = n_chunks;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (w.seg_base[mid] <= item)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        s_chunk = lo;
-    }
+    __shared__ uint32_t s_chunk, s_level;
+    __shared__ uint32_t s_base[kMaxLevels + 1];
+    // header words the whole workgroup needs: fetched once, side by side (chains of dependent global loads -- a binary
+    // search, a level walk -- cost more than the chunk's arithmetic)
+    if (threadIdx.x <= L) s_base[threadIdx.x] = w.chunk_base[threadIdx.x];
     for (uint32_t i = threadIdx.x; i < kChunkRows * 2; i += kReduceBlock) acc[i] = 0ull;
+    __syncthreads();
+    const uint32_t n_chunks = s_base[L];
+    const uint32_t item = blockIdx.x;
+    if (ADAM) {   // one segment per chunk: the work item IS the chunk
+        if (item >= n_chunks) return;
+    } else {
+        if (item >= w.seg_base[n_chunks]) return;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t lo = item;
+        if (!ADAM) {   // largest chunk with seg_base[chunk] <= item
+            lo = 0;
+            uint32_t hi = n_chunks;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (w.seg_base[mid] <= item)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+        }
+        uint32_t level = 0;
+        while (level + 1 < L && s_base[level + 1] <= lo) level++;
+        s_chunk = lo;
+        s_level = level;
+    }
     __syncthreads();
     const uint32_t chunk = s_chunk;
     const uint32_t cnt = w.count[chunk];
@@ -364,6 +379,31 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     const uint32_t beg = w.offset[chunk] + seg * seg_len;                  // multiple of 4 records
     const uint32_t end = min(w.offset[chunk] + cnt, beg + seg_len);
     if (!ADAM && beg >= end) return;   // empty chunk: nothing to add (the fused variant still has rows to update)
+
+    // which level does this chunk belong to, and where does it start in the table
+    const uint32_t level = s_level;
+    const uint32_t row0 = (chunk - s_base[level]) << kChunkShift;
+    const uint32_t T = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t rows_here = min(kChunkRows, T - row0);
+    // fused variant: the optimiser state of this lane's rows is requested now, so that its latency hides behind the
+    // record streaming (it does not depend on the gradient)
+    constexpr uint32_t kPer = kChunkRows / kReduceBlock;
+    float2 pp[kPer], mm[kPer], vv[kPer];
+    const size_t adam_base = (size_t)(uint32_t)offsets[level] + row0;
+    if (ADAM) {
+        const float2 *p2 = reinterpret_cast<const float2 *>(opt.param) + adam_base,
+                     *m2 = reinterpret_cast<const float2 *>(opt.exp_avg) + adam_base,
+                     *v2 = reinterpret_cast<const float2 *>(opt.exp_avg_sq) + adam_base;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint32_t i = threadIdx.x + j * kReduceBlock;
+            if (i < rows_here) {
+                pp[j] = p2[i];
+                mm[j] = m2[i];
+                vv[j] = v2[i];
+            }
+        }
+    }
 
     // fixed-point scale: max |g| < 2^e  ->  |g * 2^k| < 2^(62 - headroom) with k = 62 - headroom - e
     int e;
@@ -400,32 +440,28 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     }
     __syncthreads();
 
-    // which level does this chunk belong to, and where does it start in the table
-    uint32_t level = 0;
-    while (level + 1 < L && w.chunk_base[level + 1] <= chunk) level++;
-    const uint32_t row0 = (chunk - w.chunk_base[level]) << kChunkShift;
-    const uint32_t T = (uint32_t)(offsets[level + 1] - offsets[level]);
-    const uint32_t rows_here = min(kChunkRows, T - row0);
     float *dst = grad_table + ((size_t)(uint32_t)offsets[level] + row0) * 2;
     auto to_float = [&](unsigned long long q) { return (float)scalbn((double)(long long)q, -k); };
     if (ADAM) {
-        const size_t base = (size_t)(uint32_t)offsets[level] + row0;
-        float2 *p2 = reinterpret_cast<float2 *>(opt.param) + base, *m2 = reinterpret_cast<float2 *>(opt.exp_avg) + base,
-               *v2 = reinterpret_cast<float2 *>(opt.exp_avg_sq) + base;
+        float2 *p2 = reinterpret_cast<float2 *>(opt.param) + adam_base, *m2 = reinterpret_cast<float2 *>(opt.exp_avg) + adam_base,
+               *v2 = reinterpret_cast<float2 *>(opt.exp_avg_sq) + adam_base;
         const float step_size = opt.hyper[0] / opt.hyper[1], rsqrt_bc2 = opt.hyper[2];
         const float b1 = opt.b1, b2 = opt.b2, eps = opt.eps;
-        for (uint32_t i = threadIdx.x; i < rows_here; i += kReduceBlock) {
-            const float gx = to_float(acc[i * 2]), gy = to_float(acc[i * 2 + 1]);
-            float2 pp = p2[i], mm = m2[i], vv = v2[i];
-            mm.x = b1 * mm.x + (1.0f - b1) * gx;
-            vv.x = b2 * vv.x + (1.0f - b2) * gx * gx;
-            pp.x -= step_size * (mm.x / (sqrtf(vv.x) * rsqrt_bc2 + eps));
-            mm.y = b1 * mm.y + (1.0f - b1) * gy;
-            vv.y = b2 * vv.y + (1.0f - b2) * gy * gy;
-            pp.y -= step_size * (mm.y / (sqrtf(vv.y) * rsqrt_bc2 + eps));
-            p2[i] = pp;
-            m2[i] = mm;
-            v2[i] = vv;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint32_t i = threadIdx.x + j * kReduceBlock;
+            if (i < rows_here) {
+                const float gx = to_float(acc[i * 2]), gy = to_float(acc[i * 2 + 1]);
+                mm[j].x = b1 * mm[j].x + (1.0f - b1) * gx;
+                vv[j].x = b2 * vv[j].x + (1.0f - b2) * gx * gx;
+                pp[j].x -= step_size * (mm[j].x / (sqrtf(vv[j].x) * rsqrt_bc2 + eps));
+                mm[j].y = b1 * mm[j].y + (1.0f - b1) * gy;
+                vv[j].y = b2 * vv[j].y + (1.0f - b2) * gy * gy;
+                pp[j].y -= step_size * (mm[j].y / (sqrtf(vv[j].y) * rsqrt_bc2 + eps));
+                p2[i] = pp[j];
+                m2[i] = mm[j];
+                v2[i] = vv[j];
+            }
         }
     } else if (n_seg == 1) {
         float2 *d2 = reinterpret_cast<float2 *>(dst);
