@@ -48,7 +48,8 @@ class FusedTrainer:
         assert model._fused(), "fused step needs the default field configuration"
         self.rank, self.world_size = parallel.rank(), parallel.world_size()
         self.N = N = opt.num_rays
-        self.cap = cap = int(capacity or max(opt.arena_capacity, N * 128))
+        # sample arena: ~145 samples/ray are needed while the occupancy grid is still full at bound 1; rays longer with the bound
+        self.cap = cap = int(capacity or max(opt.arena_capacity, N * 160 * int(math.ceil(model.real_bound))))
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         enc = model.grid_encoder

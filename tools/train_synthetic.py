@@ -33,18 +33,30 @@ def main():
     ap.add_argument("--torch-refresh", action="store_true", help="density-grid refresh through torch ops")
     ap.add_argument("--torch-sampler", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--write-scene", default="", help="dump the procedural scene as transforms_*.json + PNG to this directory")
+    ap.add_argument("--data", default="", help="train from a Blender-format scene directory instead (scale 1, offset 0)")
+    ap.add_argument("--bound", type=float, default=1.0, help="scene bound (2 = the reference's default: two cascades)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    opt = Options(bound=1.0, num_rays=args.rays, iters=args.iters, fp16=args.fp16, fused_mlp=args.fused_mlp,
+    opt = Options(bound=args.bound, num_rays=args.rays, iters=args.iters, fp16=args.fp16, fused_mlp=args.fused_mlp,
                   arena_capacity=args.arena, capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
                   native_grid_refresh=not args.torch_refresh)
     t0 = time.time()
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     val = SyntheticDataset(opt, dev, "val", n_views=args.val_views, H=args.res, W=args.res)
     print(f"scene rendered in {time.time() - t0:.1f}s", flush=True)
+    if args.write_scene:
+        from raw_ngp_amd.nerf.provider import write_blender_scene
+        write_blender_scene(args.write_scene, {"train": data, "val": val})
+        print(f"scene written to {args.write_scene}", flush=True)
+    if args.data:
+        from raw_ngp_amd.nerf.provider import BlenderDataset
+        data = BlenderDataset(opt, args.data, "train", device=dev, scale=1.0, offset=(0, 0, 0))
+        val = BlenderDataset(opt, args.data, "val", device=dev, scale=1.0, offset=(0, 0, 0))
+        print(f"loaded {len(data)} train / {len(val)} val frames of {data.H}x{data.W} from {args.data}", flush=True)
     model = NeRFNetwork(opt)
-    trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed, capacity=args.arena or args.rays * 160) if args.engine \
+    trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed, capacity=args.arena or None) if args.engine \
         else Trainer(opt, model, data, device=dev)
     hist = []
     done = 0
