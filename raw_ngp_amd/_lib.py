@@ -227,16 +227,21 @@ class _GridBackend:
     # D = 3, C = 2 (the field's encoder) takes the atomic-free binned scatter; everything else, or
     # use_binned_backward = False, takes the reference-shaped float-atomic kernel.
     use_binned_backward = True
-    _level_rows = {}   # (data_ptr, numel) of an offsets tensor -> rows of its largest level (one host read, cached)
+    _level_rows = {}   # id(offsets tensor) -> (weakref, rows of its largest level): one host read per tensor object
 
     @staticmethod
     def _max_level_rows(offsets):
-        key = (offsets.data_ptr(), offsets.numel())
-        val = _GridBackend._level_rows.get(key)
-        if val is None:
-            o = offsets.detach().cpu()
-            val = int((o[1:] - o[:-1]).max())
-            _GridBackend._level_rows[key] = val
+        """Rows of the largest level (sizes the per-level LDS histograms).  Cached per tensor OBJECT -- a data pointer
+        can be recycled by the allocator for a different table."""
+        import weakref
+        hit = _GridBackend._level_rows.get(id(offsets))
+        if hit is not None and hit[0]() is offsets and hit[2] == offsets._version:
+            return hit[1]
+        o = offsets.detach().cpu()
+        val = int((o[1:] - o[:-1]).max())
+        if len(_GridBackend._level_rows) > 64:
+            _GridBackend._level_rows.clear()
+        _GridBackend._level_rows[id(offsets)] = (weakref.ref(offsets), val, offsets._version)
         return val
 
     @staticmethod

@@ -230,6 +230,17 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             const uint32_t nrow = (tile + n_waves) * 32u + n;
             nxt = fetch_raw<true>(enc, stride, dirs, dsigma, drgb, nullptr, nrow, tile + n_waves < n_tiles && nrow < M, h);
         }
+        // samples behind the compositor's early stop (T < T_thresh) have exactly zero output gradients: a tile made of
+        // such samples contributes nothing to any weight gradient and its encoder gradient is zero
+        if (__ballot(cur.gs != 0.0f || cur.gr[0] != 0.0f || cur.gr[1] != 0.0f || cur.gr[2] != 0.0f) == 0ull) {
+            if (valid) {
+                half8 z;
+#pragma unroll
+                for (int t = 0; t < 8; t++) z[t] = (_Float16)0.0f;
+                d3buf[(size_t)row * 2 + h] = z;
+            }
+            continue;
+        }
         const TileInB<true> in = convert_raw<true>(cur, h);
 
         // ---------------- recompute the forward pass
@@ -418,8 +429,24 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
             const uint32_t nrow = (tile + n_waves) * 32u + n;
             nxt = fetch_raw<false>(enc, stride, nullptr, nullptr, nullptr, d3buf, nrow, tile + n_waves < n_tiles && nrow < M, h);
         }
-        const TileInB<false> in = convert_raw<false>(cur, h);
         const half8 p3 = cur.p3;
+        {   // all-zero deltas (see the view kernel): the tile's encoder gradient is zero, nothing else changes
+            typedef short short8 __attribute__((ext_vector_type(8)));
+            const short8 bits = __builtin_bit_cast(short8, p3) & (short8)0x7fff;   // -0 counts as zero
+            const bool nz = (bits[0] | bits[1] | bits[2] | bits[3] | bits[4] | bits[5] | bits[6] | bits[7]) != 0;
+            if (__ballot(nz) == 0ull) {
+                if (valid) {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) {
+                        const uint32_t level = 4 * q + 2 * h;
+                        reinterpret_cast<float2 *>(denc)[(size_t)level * stride + row] = make_float2(0.f, 0.f);
+                        reinterpret_cast<float2 *>(denc)[(size_t)(level + 1) * stride + row] = make_float2(0.f, 0.f);
+                    }
+                }
+                continue;
+            }
+        }
+        const TileInB<false> in = convert_raw<false>(cur, h);
 
         f32x16 a[2];
         half8 h1[2][2], h2[2][2];

@@ -234,28 +234,51 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     uint32_t rows[8], pos[8];
     float vx[8], vy[8];
     Cell<3> cl = {};
-    const bool live = b < B && corner_rows(inputs, b, g, align_corners, interp, cl, rows);
+    bool live = b < B;
+    if (live) {
+        float x[3];
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) x[d] = inputs[(size_t)b * 3 + d];
+        live = locate<3>(x, g.res, align_corners, interp, cl);
+    }
     float2 gr = make_float2(0.0f, 0.0f);
     if (live) gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * gstride + b];
-    bool nan = !(gr.x == gr.x && gr.y == gr.y);
+    const bool nan = !(gr.x == gr.x && gr.y == gr.y);
+    // a sample whose gradient is exactly zero at this level (behind the compositor's early stop: a third of the samples
+    // late in training) contributes nothing: no weights, and no records unless its run has a non-zero member
+    const bool active = live && (gr.x != 0.0f || gr.y != 0.0f);
 #pragma unroll
-    for (uint32_t corner = 0; corner < 8; corner++) {
-        float wgt = 1.0f;
+    for (uint32_t corner = 0; corner < 8; corner++) vx[corner] = vy[corner] = 0.0f;
+    if (active) {
 #pragma unroll
-        for (uint32_t d = 0; d < 3; d++) wgt *= (corner & (1u << d)) ? cl.f[d] : 1.0f - cl.f[d];
-        vx[corner] = live ? wgt * gr.x : 0.0f;
-        vy[corner] = live ? wgt * gr.y : 0.0f;
+        for (uint32_t corner = 0; corner < 8; corner++) {
+            float wgt = 1.0f;
+#pragma unroll
+            for (uint32_t d = 0; d < 3; d++) wgt *= (corner & (1u << d)) ? cl.f[d] : 1.0f - cl.f[d];
+            vx[corner] = wgt * gr.x;
+            vy[corner] = wgt * gr.y;
+        }
     }
-    bool emit = live;
+    // runs are shaped exactly as when the records were counted (every in-range sample), so a bin can only receive
+    // fewer records than were reserved for it, never more
+    bool emit = active;
     if (mergeable(g, w)) {
         uint32_t dist;
-        emit = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
+        const bool tail = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
         const RunFlags flags = run_flags(dist);
+        // (evaluated by every lane before the &&: a DPP scan under a divergent EXEC mask reads disabled lanes)
+        const float active_in_run = run_sum(active ? 1.0f : 0.0f, flags);
+        emit = tail && active_in_run > 0.0f;
 #pragma unroll
         for (uint32_t corner = 0; corner < 8; corner++) {
             vx[corner] = run_sum(vx[corner], flags);
             vy[corner] = run_sum(vy[corner], flags);
         }
+    }
+    if (emit) {   // only a run's last lane needs the rows (hashes)
+        const AxisTerms<3> terms = axis_terms<3>(g, cl);
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; corner++) rows[corner] = row_from_terms<3>(g, terms, corner);
     }
     if (emit) {
 #pragma unroll
@@ -372,9 +395,10 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     }
     __syncthreads();
     const uint32_t chunk = s_chunk;
-    const uint32_t cnt = w.count[chunk];
+    const uint32_t reserved = w.count[chunk];   // records counted for the chunk (what the segments were cut from)
+    const uint32_t cnt = w.cursor[chunk];       // records the fill kernel really wrote (zero-gradient runs emit none)
     const uint32_t n_seg = w.seg_base[chunk + 1] - w.seg_base[chunk];
-    const uint32_t seg_len = n_seg == 1 ? max(cnt, 1u) : (cnt > kSegBig ? kSegBig : kSeg);
+    const uint32_t seg_len = n_seg == 1 ? max(reserved, 1u) : (reserved > kSegBig ? kSegBig : kSeg);
     const uint32_t seg = item - w.seg_base[chunk];
     const uint32_t beg = w.offset[chunk] + seg * seg_len;                  // multiple of 4 records
     const uint32_t end = min(w.offset[chunk] + cnt, beg + seg_len);
