@@ -112,6 +112,7 @@ class FusedTrainer:
         self.fuse_adam = bool(getattr(opt, "fuse_adam", True)) and self.world_size == 1 and opt.lambda_tv == 0 \
             and opt.lambda_wd == 0
         self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
+        self._refresh_graph = None
         self._main_symbols = {"ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
                               "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
                               "ngp_x_composite_mse_backward", "ngp_x_adam_step_dev2", "ngp_x_step_begin",
@@ -217,9 +218,21 @@ class FusedTrainer:
         back: draw the cells (every cell for the first 16 calls, then H^3/4 uniform + H^3/4 occupied ones), evaluate
         the density there with the slab encoder + the density half of the fused MLP, EMA-max into the grid, re-pack
         the bitfield with thresh = min(mean, density_thresh)."""
+        m = self.model
+        full = m.iter_density < 16
+        if self.use_graph and not full:             # the steady-state variant has fixed launch arguments: replay it
+            if self._refresh_graph is None:
+                self._refresh_graph = self._capture_ops([lambda: self._refresh_launches(decay, False)])
+            for part in self._refresh_graph:
+                part()
+        else:
+            self._refresh_launches(decay, full)
+        m.iter_density += 1
+        m.bitfield_version = getattr(m, "bitfield_version", 0) + 1
+
+    def _refresh_launches(self, decay, full):
         m, cap = self.model, self.cap
         H, cells = m.grid_size, m.grid_size ** 3
-        full = m.iter_density < 16
         n_uni, n_occ = (cells, 0) if full else (cells // 4, cells // 4)
         total = n_uni + n_occ
         offsets = m.grid_encoder.offsets
@@ -238,8 +251,6 @@ class FusedTrainer:
             eb.density_grid_scatter(self.dg_indices[:total], self.dg_sigma[:total], total, self.dg_tmp[cas])
         eb.density_grid_update(m.density_grid, self.dg_tmp, decay, self.dg_stats)
         eb.packbits_mean(m.density_grid, self.dg_stats, m.density_thresh, m.density_bitfield)
-        m.iter_density += 1
-        m.bitfield_version = getattr(m, "bitfield_version", 0) + 1
 
     @property
     def mean_density(self):
@@ -324,6 +335,27 @@ class FusedTrainer:
             ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True)))
         return ops
 
+    def _capture_ops(self, ops):
+        """A list of thunks as one hipGraph (list with its replay callable)."""
+        if self.graph_pool is None:
+            self.graph_pool = torch.cuda.graph_pool_handle()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
+            for op in ops:
+                op()
+        self._graphs_alive.append(g)
+        return [g.replay]
+
+    def _load_slot_fast(self, slot):
+        """_load_slot (device sampler + march + binning reset) replayed from a graph: 9 launches -> 1."""
+        if not (self.use_graph and self.device_sampler and self.global_step >= 2 and self.march_mode != "index"):
+            return self._load_slot(slot)
+        key = ("load", id(slot))
+        if key not in self.graphs:
+            self.graphs[key] = self._capture_ops([lambda: self._load_slot(slot)])
+        for part in self.graphs[key]:
+            part()
+
     def _capture(self, slot, timed):
         """The step as hipGraphs.  Two kinds of op stay outside: the gradient all-reduce (RCCL, under DP) and, on the
         steps where bench.py times it with HIP events, the probed entry point (events inside a graph cannot be
@@ -367,8 +399,11 @@ class FusedTrainer:
                     torch.manual_seed(1234567 + step)
                 model.update_extra_state()
         slot = self.slots[step % len(self.slots)]
-        if batch is not None or slot.step != step:      # explicit batch, first step, or just after a grid refresh
+        if batch is not None:
             self._load_slot(slot, batch, noises)
+            slot.step = step
+        elif slot.step != step:                         # first step, or just after a grid refresh
+            self._load_slot_fast(slot)
             slot.step = step
         # the occupancy bitfield the next step marches through is final unless that step refreshes it first
         ahead = self.prefetch and batch is None and (step + 1) % opt.update_extra_interval != 0
@@ -379,7 +414,7 @@ class FusedTrainer:
             # this step does on the main stream (nxt's previous user, step - 1, is already behind this point)
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
-                self._load_slot(nxt)
+                self._load_slot_fast(nxt)
             nxt.step = step + 1
         if self.use_graph and batch is None and step >= 2:      # the first steps run eagerly (lazy init, caches)
             from .. import _lib
