@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const int32_t *__rest
     atomicMax(reinterpret_cast<int *>(tmp) + idx, __float_as_int(sigmas[i]));
 }
 
+__global__ void grid_stats_zero_kernel(float *stats)
+{
+    if (threadIdx.x < 4) stats[threadIdx.x] = 0.0f;
+}
+
 __global__ __launch_bounds__(256) void grid_update_kernel(float *__restrict__ grid, float *__restrict__ tmp, uint32_t n4,
                                                          float decay, float *__restrict__ stats)
 {
@@ -275,7 +280,9 @@ extern "C" int ngp_x_density_grid_update(float *grid, float *tmp, uint32_t n_cel
     NGP_REQUIRE(n_cells % 4 == 0 && (((uintptr_t)grid | (uintptr_t)tmp) & 15u) == 0,
                 "density_grid_update: grids must be 16-byte aligned with a multiple of 4 cells");
     hipStream_t st = as_stream(stream);
-    NGP_REQUIRE(hipMemsetAsync(stats, 0, 4 * sizeof(float), st) == hipSuccess, "density_grid_update: memset failed");
+    // a kernel, not hipMemsetAsync: as a memset NODE of a captured graph it was seen to run after the update kernel
+    // (under rocprofv3), leaving a zero mean -> threshold 0 -> an all-occupied bitfield
+    grid_stats_zero_kernel<<<dim3(1), dim3(64), 0, st>>>(stats);
     if (n_cells) {
         grid_update_kernel<<<dim3(min(ceil_div(n_cells / 4, 256u), 1024u)), dim3(256), 0, st>>>(grid, tmp, n_cells / 4,
                                                                                                decay, stats);
