@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event roofline probe (roofline: null)")
     ap.add_argument("--no-graph", action="store_true", help="fused step: launch kernels one by one (no hipGraph replay)")
     ap.add_argument("--torch-sampler", action="store_true", help="fused step: draw rays with torch ops (implies no graph)")
+    ap.add_argument("--aux", action="store_true", help="fused step: MLP-weight tail on a third stream (slower)")
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
     ap.add_argument("--autograd", action="store_true", help="per-op autograd path (Trainer) instead of the fused step")
     args = ap.parse_args()
@@ -180,12 +182,13 @@ def main():
 
     opt = Options(bound=1.0, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena,
                   fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
-                  capture_graph=not args.no_graph, device_sampler=not args.torch_sampler)
+                  capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
+                  aux_stream=args.aux)
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
     fused = not (args.autograd or args.torch_mlp)
     if fused:
-        trainer = FusedTrainer(opt, model, data, device=dev, capacity=args.arena or args.rays * 160)
+        trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed, capacity=args.arena or args.rays * 160)
     else:
         trainer = Trainer(opt, model, data, device=dev)
 

@@ -262,6 +262,10 @@ int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float *dirs, con
                        const float *drgb, const int32_t *M_dev, uint32_t M, const void *image, float loss_scale,
                        float *denc, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6,
                        void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+/* dw1..dw6 all NULL: the per-workgroup partial sums stay in `workspace` and ngp_x_mlp_reduce_dw (same M, loss_scale,
+ * workspace) produces the six gradients later -- e.g. on another stream, off the critical path. */
+int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
+                        float *dw6, const void *workspace, size_t workspace_bytes, ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Kernels of the fused training step (csrc/engine_kernels.hip; host side raw_ngp_amd/nerf/engine.py).
@@ -355,10 +359,11 @@ int ngp_x_near_far_from_aabb_v2(const float *rays_o, const float *rays_d, const 
  *   (caller evaluates the density at xyzs)
  *   ngp_x_density_grid_scatter  tmp[index] = max(tmp[index], sigma); tmp holds -1 where nothing was evaluated
  * then over all cascades:
- *   ngp_x_density_grid_update   grid = max(grid * decay, tmp) where grid >= 0 and tmp >= 0; stats[0] = sum of
- *                               clamp(grid, 0); tmp is reset to -1
- *   ngp_x_packbits_mean         ngp_packbits with thresh = min(stats[0] / cells, density_thresh); N = bytes of the
- *                               bitfield; writes stats[1] = mean density, stats[2] = thresh
+ *   ngp_x_density_grid_update   grid = max(grid * decay, tmp) where grid >= 0 and tmp >= 0; tmp is reset to -1;
+ *                               stats[4 .. 4 + 1024) = partial sums of clamp(grid, 0) (stats: 1028 floats)
+ *   ngp_x_packbits_mean         ngp_packbits with thresh = min(mean, density_thresh), mean = the partials added in a
+ *                               fixed order / cells (bitwise reproducible); N = bytes of the bitfield; writes
+ *                               stats[0] = sum, stats[1] = mean density, stats[2] = thresh
  * Nothing is read back to the host. */
 size_t ngp_x_density_grid_workspace_bytes(uint32_t H);
 int ngp_x_density_grid_sample(const float *grid_cas, uint32_t H, float span, float half, uint32_t n_uniform,

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
+    "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
     "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
     "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
@@ -486,16 +487,23 @@ class _MlpBackend:
 
     @staticmethod
     def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws, workspace=None):
-        """dws: six pre-allocated fp32 tensors shaped like the weights (overwritten).  workspace: uint8 tensor of
-        backward_workspace_bytes(M) (allocated per call when omitted)."""
+        """dws: six pre-allocated fp32 tensors shaped like the weights (overwritten), or None to leave the partial
+        sums in `workspace` for reduce_dw().  workspace: uint8 tensor of backward_workspace_bytes(M) (allocated per
+        call when omitted)."""
         nbytes = load().ngp_x_mlp_backward_workspace_bytes(M)
         ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
         if ws.numel() < nbytes or not ws.is_cuda:
             raise RuntimeError("mlp backward: workspace too small")
+        grads = [_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)] if dws is not None else [None] * 6
         _call("ngp_x_mlp_backward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"),
               _ptr(dsigma, "f", "dsigma"), _ptr(drgb, "f", "drgb"), _ptr(M_dev, "i", "M_dev", True), M,
-              image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"),
-              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], ws.data_ptr(), nbytes)
+              image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"), *grads, ws.data_ptr(), nbytes)
+
+    @staticmethod
+    def reduce_dw(M, loss_scale, dws, workspace):
+        """Second half of backward(..., dws=None): weight gradients from the partial sums left in `workspace`."""
+        _call("ngp_x_mlp_reduce_dw", workspace, M, float(loss_scale),
+              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], workspace.data_ptr(), workspace.numel())
 
 
 class _EngineBackend:

@@ -171,10 +171,7 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const int32_t *__rest
     atomicMax(reinterpret_cast<int *>(tmp) + idx, __float_as_int(sigmas[i]));
 }
 
-__global__ void grid_stats_zero_kernel(float *stats)
-{
-    if (threadIdx.x < 4) stats[threadIdx.x] = 0.0f;
-}
+constexpr uint32_t kUpdateBlocks = 1024;   // partial sums of the density mean: stats[4 .. 4 + kUpdateBlocks)
 
 __global__ __launch_bounds__(256) void grid_update_kernel(float *__restrict__ grid, float *__restrict__ tmp, uint32_t n4,
                                                          float decay, float *__restrict__ stats)
@@ -196,7 +193,9 @@ __global__ __launch_bounds__(256) void grid_update_kernel(float *__restrict__ gr
     for (uint32_t d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
     if ((threadIdx.x & 63u) == 0) wave_sum[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(stats, wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3]);
+    // one partial per block, added up in block order by the packbits kernel: no float atomics, so the threshold -- and
+    // with it the whole training run -- does not depend on the order in which blocks finish
+    if (threadIdx.x == 0) stats[4 + blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
 }
 
 // packbits (raymarching.cu:267-289) with thresh = min(mean density, density_thresh) taken from the device
@@ -205,9 +204,19 @@ __global__ __launch_bounds__(256) void packbits_mean_kernel(const float *__restr
                                                            uint8_t *__restrict__ bitfield)
 {
     const uint32_t n = blockIdx.x * 256u + threadIdx.x;
-    const float mean = stats[0] * inv_cells;
+    __shared__ float s_total;
+    if (threadIdx.x < 64u) {   // fixed summation order: lane l adds partials l, l + 64, ...; then a butterfly
+        float acc = 0.0f;
+        for (uint32_t i = threadIdx.x; i < kUpdateBlocks; i += 64u) acc += stats[4 + i];
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (threadIdx.x == 0) s_total = acc;
+    }
+    __syncthreads();
+    const float mean = s_total * inv_cells;
     const float thresh = fminf(mean, density_thresh);
     if (n == 0) {
+        stats[0] = s_total;
         stats[1] = mean;
         stats[2] = thresh;
     }
@@ -280,13 +289,9 @@ extern "C" int ngp_x_density_grid_update(float *grid, float *tmp, uint32_t n_cel
     NGP_REQUIRE(n_cells % 4 == 0 && (((uintptr_t)grid | (uintptr_t)tmp) & 15u) == 0,
                 "density_grid_update: grids must be 16-byte aligned with a multiple of 4 cells");
     hipStream_t st = as_stream(stream);
-    // a kernel, not hipMemsetAsync: as a memset NODE of a captured graph it was seen to run after the update kernel
-    // (under rocprofv3), leaving a zero mean -> threshold 0 -> an all-occupied bitfield
-    grid_stats_zero_kernel<<<dim3(1), dim3(64), 0, st>>>(stats);
-    if (n_cells) {
-        grid_update_kernel<<<dim3(min(ceil_div(n_cells / 4, 256u), 1024u)), dim3(256), 0, st>>>(grid, tmp, n_cells / 4,
-                                                                                               decay, stats);
-    }
+    // (no hipMemsetAsync here: as a memset NODE of a captured graph it was seen to run after the update kernel under
+    // rocprofv3, leaving a zero mean -> threshold 0 -> an all-occupied bitfield.  Every block writes its own partial.)
+    grid_update_kernel<<<dim3(kUpdateBlocks), dim3(256), 0, st>>>(grid, tmp, n_cells / 4, decay, stats);
     NGP_CHECK_LAUNCH("density_grid_update");
     return NGP_OK;
 }

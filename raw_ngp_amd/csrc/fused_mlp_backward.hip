@@ -637,7 +637,10 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
                                   float loss_scale, float *denc, float *dw1, float *dw2, float *dw3, float *dw4,
                                   float *dw5, float *dw6, void *workspace, size_t workspace_bytes, ngp_stream_t stream)
 {
-    NGP_REQUIRE(dw1 && dw2 && dw3 && dw4 && dw5 && dw6 && image && workspace, "mlp_backward: null tensor");
+    const bool reduce_now = dw1 != nullptr;   // all NULL: leave the per-workgroup partials for ngp_x_mlp_reduce_dw
+    NGP_REQUIRE(image && workspace, "mlp_backward: null tensor");
+    NGP_REQUIRE(reduce_now ? (dw2 && dw3 && dw4 && dw5 && dw6) : (!dw2 && !dw3 && !dw4 && !dw5 && !dw6),
+                "mlp_backward: pass all six weight-gradient tensors or none");
     NGP_REQUIRE(M == 0 || (enc && dirs && dsigma && drgb && denc), "mlp_backward: null sample tensor");
     NGP_REQUIRE(stride >= M, "mlp_backward: encoder slab stride smaller than M");
     NGP_REQUIRE(workspace_bytes >= ngp_x_mlp_backward_workspace_bytes(M), "mlp_backward: workspace too small");
@@ -653,9 +656,28 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
                                                                         loss_scale, d3buf, part_view);
     mlp_backward_grid_kernel<<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
                                                                         d3buf, denc, part_grid);
-    mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, st>>>(part_view, part_grid, blocks,
-                                                                                    1.0f / loss_scale, dw1, dw2, dw3, dw4,
-                                                                                    dw5, dw6);
+    if (reduce_now)
+        mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, st>>>(part_view, part_grid, blocks, 1.0f / loss_scale,
+                                                                              dw1, dw2, dw3, dw4, dw5, dw6);
     NGP_CHECK_LAUNCH("mlp_backward");
+    return NGP_OK;
+}
+
+// second half of ngp_x_mlp_backward when it was called without weight-gradient tensors: sum the per-workgroup
+// partial slabs the two backward kernels left in `workspace` (same M, same loss_scale)
+extern "C" int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4,
+                                   float *dw5, float *dw6, const void *workspace, size_t workspace_bytes,
+                                   ngp_stream_t stream)
+{
+    NGP_REQUIRE(dw1 && dw2 && dw3 && dw4 && dw5 && dw6 && workspace, "mlp_reduce_dw: null tensor");
+    NGP_REQUIRE(workspace_bytes >= ngp_x_mlp_backward_workspace_bytes(M), "mlp_reduce_dw: workspace too small");
+    NGP_REQUIRE(loss_scale > 0.0f, "mlp_reduce_dw: loss_scale must be positive");
+    const uint32_t blocks = mlp_bwd_blocks(max(M, 1u));
+    const float *part_view = reinterpret_cast<const float *>(reinterpret_cast<const char *>(workspace) +
+                                                             (((size_t)M * 32 + 255) & ~(size_t)255));
+    const float *part_grid = part_view + (size_t)256 * kAccFloats;
+    mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, as_stream(stream)>>>(
+        part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6);
+    NGP_CHECK_LAUNCH("mlp_reduce_dw");
     return NGP_OK;
 }

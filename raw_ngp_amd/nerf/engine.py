@@ -89,6 +89,7 @@ class FusedTrainer:
         self.slots = [_Slot(N, opt.max_steps, cap, dev, chain_cap) for _ in range(2 if self.prefetch else 1)]
         self.arena = self.slots[0].arena
         self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
+        self.aux = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         # compressed occupancy bitfield the march keeps in LDS (rebuilt after every density-grid refresh)
         self.occ_index = None
         if self.march_mode == "index" and (model.cascade * model.grid_size ** 3) % 2048 == 0:
@@ -115,8 +116,9 @@ class FusedTrainer:
         self._refresh_graph = None
         self._main_symbols = {"ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
                               "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
-                              "ngp_x_composite_mse_backward", "ngp_x_adam_step_dev2", "ngp_x_step_begin",
-                              "ngp_x_mlp_prepare"}
+                              "ngp_x_composite_mse_backward", "ngp_x_adam_step_dev2", "ngp_x_adam_step_dev",
+                              "ngp_x_step_begin", "ngp_x_mlp_prepare", "ngp_x_mlp_reduce_dw",
+                              "ngp_x_grid_backward_binned_prepare"}
         # density-grid refresh on the device (no host round trips)
         self.native_refresh = bool(getattr(opt, "native_grid_refresh", True)) and model.grid_size ** 3 % 64 == 0
         if self.native_refresh:
@@ -124,7 +126,7 @@ class FusedTrainer:
             self.dg_indices = torch.empty(cells, **i32)
             self.dg_xyzs, self.dg_sigma = torch.empty(cells, 3, **f32), torch.empty(cells, **f32)
             self.dg_tmp = torch.full_like(model.density_grid, -1.0)
-            self.dg_stats = torch.zeros(4, **f32)
+            self.dg_stats = torch.zeros(4 + 1024, **f32)
             self.dg_draw = torch.zeros(1, **i32)
             self.dg_ws = torch.empty(eb.density_grid_workspace_bytes(model.grid_size), dtype=torch.uint8, device=dev)
             self.dg_seed = ((seed * 1000) ^ 0x9E3779B97F4A7C15) & (2 ** 64 - 1)     # same on every rank
@@ -140,6 +142,7 @@ class FusedTrainer:
         self.ws_mlp = torch.empty(mb.backward_workspace_bytes(cap), dtype=torch.uint8, device=dev)
         for slot in self.slots:         # the binned backward's bookkeeping is per ray batch (prepared with the march)
             slot.ws_grid = torch.empty(gb.backward_workspace_bytes(cap, self.L, self.rows), dtype=torch.uint8, device=dev)
+        self._image_ready = False                      # the step path expects the f16 weight image of the current weights
         self.global_step = 0
         self.samples_seen = torch.zeros(1, dtype=torch.int64, device=dev)     # running total, never read per step
         self.ray_gen = torch.Generator(device=dev).manual_seed(seed * 1000 + self.rank)   # torch sampling path
@@ -178,8 +181,10 @@ class FusedTrainer:
         for _, op in self._field_ops(slot, gt_rgba, bg_rgb, bg_const):
             op()
 
-    def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False):
-        """The field part of the step as (C entry point, thunk) pairs, in launch order."""
+    def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False, split_weights=False):
+        """The field part of the step as (C entry point, thunk) pairs, in launch order.  split_weights: the step path --
+        the f16 weight image was prepared at the end of the previous step and the weight-gradient reduction is left to
+        the caller (it goes to the aux stream together with the MLP's Adam step)."""
         opt, m, ar, N, cap = self.opt, self.model, slot.arena, self.N, self.cap
         cnt, offsets = ar.counter, m.grid_encoder.offsets
         # single GPU: the table's Adam step happens inside the reduce kernel (the gradient never reaches HBM)
@@ -191,7 +196,7 @@ class FusedTrainer:
             eb.composite_mse_backward(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, self.ws,
                                       self.depth, self.image, cap, N, opt.T_thresh, self.dsigma, self.drgb, self.loss)
 
-        return [
+        ops = [
             ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
                 ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt, cap, cap, self.L, self.L, self.S, self.H,
                 binned_workspace=slot.ws_grid)),
@@ -206,11 +211,15 @@ class FusedTrainer:
                 self.image)),
             ("ngp_x_composite_mse_backward", loss_and_composite_backward),
             ("ngp_x_mlp_backward", lambda: mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap,
-                                                       self.mlp_image, opt.loss_scale, self.denc, self.dws, self.ws_mlp)),
+                                                       self.mlp_image, opt.loss_scale, self.denc,
+                                                       None if split_weights else self.dws, self.ws_mlp)),
             ("ngp_x_grid_backward_binned_apply", lambda: gb.grid_backward_binned_apply(
                 self.denc, self.x01, offsets, self.table_grad, cnt, cap, cap, self.L, self.L, self.S, self.H,
                 slot.ws_grid, adam=adam)),
         ]
+        if split_weights:
+            ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
+        return ops
 
     @torch.no_grad()
     def refresh_density_grid(self, decay=0.95):
@@ -316,24 +325,51 @@ class FusedTrainer:
         self.march(slot, slot.rays_o, slot.rays_d, slot.noises)
 
     def _step_ops(self, slot):
-        """Everything the main stream does in one step, as (name, thunk) pairs."""
+        """Everything one step does after the rays are marched, as (name, thunk, lane) triples.  Lane "aux" marks the
+        MLP-weight tail (gradient reduction, Adam, next step's f16 weight image): it depends only on the MLP backward,
+        so on one GPU it runs on a third stream beside the table's fill + reduce instead of after them."""
         opt = self.opt
         bg_const = 1.0 if opt.background in ("white", "last_sample") else 0.0
-
+        split = self.fuse_adam
         # lr / Adam bias corrections of this step, loss = 0, samples_seen += this batch's sample count
         ops = [("ngp_x_step_begin", lambda: eb.step_begin(self.step_ctr, self.hyper, self.lr0, float(opt.iters),
                                                            *self.betas, self.loss, self.samples_seen,
-                                                           slot.arena.counter))]
-        ops += self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False,
-                               fused_adam=self.fuse_adam)
+                                                           slot.arena.counter), "main")]
+        field = self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False,
+                                fused_adam=self.fuse_adam, split_weights=split)
+        prepare = ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image))
+        if split:
+            tail = [("ngp_x_mlp_reduce_dw", lambda: mb.reduce_dw(self.cap, opt.loss_scale, self.dws, self.ws_mlp)),
+                    ("ngp_x_adam_step_dev", lambda: eb.adam_step_dev(self.w_flat, self.w_grad, self.w_m, self.w_v,
+                                                                     self.hyper, *self.betas, self.eps, False)),
+                    prepare]
+            for name, op in field:
+                if name == "ngp_x_grid_backward_binned_apply":      # right after the MLP backward, beside the apply
+                    ops += [(n, o, "aux") for n, o in tail]
+                ops.append((name, op, "main"))
+            return ops
+        ops += [(n, o, "main") for n, o in field]
         if self.world_size > 1:
-            ops.append(("all_reduce", self.reduce_gradients))
-        if self.fuse_adam:          # only the MLP weights are left
-            ops.append(("ngp_x_adam_step_dev", lambda: eb.adam_step_dev(self.w_flat, self.w_grad, self.w_m, self.w_v,
-                                                                         self.hyper, *self.betas, self.eps, False)))
-        else:
-            ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True)))
-        return ops
+            ops.append(("all_reduce", self.reduce_gradients, "main"))
+        ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True), "main"))
+        return ops                                  # (this variant prepares the weight image before its MLP forward)
+
+    def _run_ops(self, ops, fork=True):
+        """Launch a run of ops on the current stream; "aux" ops go to the aux stream (fork at the first one, join at the
+        end of the run) when `fork`, else in line."""
+        main = torch.cuda.current_stream(self.device)
+        forked = False
+        for _, op, lane in ops:
+            if lane == "aux" and fork:
+                if not forked:
+                    self.aux.wait_stream(main)
+                    forked = True
+                with torch.cuda.stream(self.aux):
+                    op()
+            else:
+                op()
+        if forked:
+            main.wait_stream(self.aux)
 
     def _capture_ops(self, ops):
         """A list of thunks as one hipGraph (list with its replay callable)."""
@@ -364,24 +400,26 @@ class FusedTrainer:
         if self.graph_pool is None:
             self.graph_pool = torch.cuda.graph_pool_handle()
         eager = {"all_reduce", *(_lib.probed_symbols() if timed else ())}
+        ops = self._step_ops(slot)
+        # one graph: the aux lane may fork inside it
+        whole = not any(name in eager for name, _, _ in ops) and bool(getattr(self.opt, "aux_stream", False))
         parts, run = [], []
 
         def flush():
             if run:
-                g, ops = torch.cuda.CUDAGraph(), list(run)
+                g, seg = torch.cuda.CUDAGraph(), list(run)
                 with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
-                    for op in ops:
-                        op()
+                    self._run_ops(seg, fork=whole)
                 parts.append(g.replay)
                 self._graphs_alive.append(g)
                 run.clear()
 
-        for name, op in self._step_ops(slot):
+        for name, op, lane in ops:
             if name in eager:
                 flush()
                 parts.append(op)
             else:
-                run.append(op)
+                run.append((name, op, lane))
         flush()
         return parts
 
@@ -398,6 +436,9 @@ class FusedTrainer:
                 if self.world_size > 1:
                     torch.manual_seed(1234567 + step)
                 model.update_extra_state()
+        if not self._image_ready:                       # later steps prepare it right after their Adam step
+            mb.prepare(self.weights, self.mlp_image)
+            self._image_ready = True
         slot = self.slots[step % len(self.slots)]
         if batch is not None:
             self._load_slot(slot, batch, noises)
@@ -429,8 +470,7 @@ class FusedTrainer:
                 _lib.probe_skip(probed)                         # the call happened inside the graph
             self.last_graph_key = key
         else:
-            for _, op in self._step_ops(slot):
-                op()
+            self._run_ops(self._step_ops(slot), fork=bool(getattr(self.opt, "aux_stream", False)))
             self.last_graph_key = None
         if nxt is not None:
             main.wait_stream(self.side)                 # join

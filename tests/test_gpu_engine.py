@@ -305,7 +305,7 @@ def test_density_grid_refresh_kernels_match_oracle(lib, orc, full):
     rtmp = np.full(cells, -1.0, np.float32)
     np.maximum.at(rtmp, ridx, sig)
     np.testing.assert_array_equal(host(tmp)[0], rtmp)
-    stats = torch.zeros(4, device="cuda")
+    stats = torch.zeros(4 + 1024, device="cuda")
     e.density_grid_update(dgrid, tmp, 0.95, stats)
     rgrid, rmean = orc.density_grid_update(grid[0], rtmp, 0.95)
     np.testing.assert_array_equal(host(dgrid)[0], rgrid)
@@ -423,3 +423,28 @@ def test_binned_backward_with_zero_gradient_tails(lib, orc):
     head = host(ws[:(68 + 2 * n_chunks_max) * 4]).view(np.uint32)
     reserved, written = head[68:68 + n_chunks_max].sum(), head[68 + n_chunks_max:68 + 2 * n_chunks_max].sum()
     assert 0 < written < 0.85 * reserved
+
+
+def test_fused_training_is_bitwise_reproducible(lib):
+    """Same seed, two runs of the default single-GPU engine (graphs, side/aux streams, fused Adam): identical parameters
+    bit for bit.  No float atomics feed back into the state: table sums are 64-bit integers, weight gradients are
+    reduced in a fixed order, the density mean is added up in block order."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    out = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True)
+        data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
+        eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
+        assert eng.fuse_adam and eng.use_graph
+        for _ in range(40):
+            eng.train_step()
+        torch.cuda.synchronize()
+        out.append((eng.table.clone(), eng.w_flat.clone(), eng.model.density_bitfield.clone(), int(eng.samples_seen)))
+    assert out[0][3] == out[1][3]
+    assert torch.equal(out[0][2], out[1][2])
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][0], out[1][0])
