@@ -14,61 +14,6 @@
 
 namespace ngp {
 
-struct MlpWeights {
-    const float *w1, *w2, *w3, *w4, *w5, *w6;
-};
-
-// ------------------------------------------------------------------ weight image
-__device__ __forceinline__ float frag_elem(uint32_t f, uint32_t r, uint32_t h, uint32_t t, const MlpWeights &W)
-{
-    if (f < F_W2) {
-        const uint32_t i = f - F_W1, rb = i >> 1, s = i & 1;
-        return W.w1[(32 * rb + r) * 32 + kperm(s, h, t)];
-    }
-    if (f < F_W3) {
-        const uint32_t i = f - F_W2, rb = i >> 2, kb = (i >> 1) & 1, s = i & 1;
-        return W.w2[(32 * rb + r) * 64 + 32 * kb + kperm(s, h, t)];
-    }
-    if (f < F_W4) {
-        const uint32_t i = f - F_W3, kb = i >> 1, s = i & 1;
-        return r < 16 ? W.w3[r * 64 + 32 * kb + kperm(s, h, t)] : 0.0f;
-    }
-    if (f < F_W5) {
-        const uint32_t i = f - F_W4, rb = i >> 1, s = i & 1, k = kperm(s, h, t);
-        return k >= 1 ? W.w4[(32 * rb + r) * 31 + k - 1] : 0.0f;
-    }
-    if (f < F_W6) {
-        const uint32_t i = f - F_W5, rb = i >> 2, kb = (i >> 1) & 1, s = i & 1;
-        return W.w5[(32 * rb + r) * 64 + 32 * kb + kperm(s, h, t)];
-    }
-    if (f < T_W6) {
-        const uint32_t i = f - F_W6, kb = i >> 1, s = i & 1;
-        return r < 3 ? W.w6[r * 64 + 32 * kb + kperm(s, h, t)] : 0.0f;
-    }
-    if (f < T_W5) {
-        const uint32_t rb = f - T_W6, k = kperm(0, h, t);
-        return k < 3 ? W.w6[k * 64 + 32 * rb + r] : 0.0f;
-    }
-    if (f < T_W4) {
-        const uint32_t i = f - T_W5, rb = i >> 2, kb = (i >> 1) & 1, s = i & 1;
-        return W.w5[(32 * kb + kperm(s, h, t)) * 64 + 32 * rb + r];
-    }
-    if (f < T_W3) {
-        const uint32_t i = f - T_W4, kb = i >> 1, s = i & 1;
-        return r >= 1 ? W.w4[(32 * kb + kperm(s, h, t)) * 31 + r - 1] : 0.0f;
-    }
-    if (f < T_W2) {
-        const uint32_t rb = f - T_W3, k = kperm(0, h, t);
-        return k < 16 ? W.w3[k * 64 + 32 * rb + r] : 0.0f;
-    }
-    if (f < T_W1) {
-        const uint32_t i = f - T_W2, rb = i >> 2, kb = (i >> 1) & 1, s = i & 1;
-        return W.w2[(32 * kb + kperm(s, h, t)) * 64 + 32 * rb + r];
-    }
-    const uint32_t i = f - T_W1, kb = i >> 1, s = i & 1;
-    return W.w1[(32 * kb + kperm(s, h, t)) * 32 + r];
-}
-
 __global__ __launch_bounds__(256) void mlp_prepare_kernel(MlpWeights W, _Float16 *__restrict__ image)
 {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
