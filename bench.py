@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="fused step: launch kernels one by one (no hipGraph replay)")
     ap.add_argument("--torch-sampler", action="store_true", help="fused step: draw rays with torch ops (implies no graph)")
     ap.add_argument("--aux", action="store_true", help="fused step: MLP-weight tail on a third stream (slower)")
+    ap.add_argument("--no-fuse-adam", action="store_true",
+                    help="separate Adam pass over the table (what data-parallel ranks run), on one GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"],
                     help="data parallel: wire format of the table-gradient all-reduce")
@@ -185,7 +187,7 @@ def main():
     opt = Options(bound=1.0, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena,
                   fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
-                  aux_stream=args.aux, grad_wire=args.grad_wire)
+                  aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam)
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
     fused = not (args.autograd or args.torch_mlp)

@@ -221,7 +221,9 @@ int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, con
                                      int align_corners, uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
                                      void *workspace, size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
                                      float *adam_exp_avg_sq, const float *adam_hyper, float beta1, float beta2,
-                                     float eps, ngp_stream_t stream);
+                                     float eps, int overwrite, ngp_stream_t stream);
+/* overwrite != 0 (workspace prepared with single_segment, max_level == L): grad_embeddings = sums for EVERY row of every
+ * level (zeros where nothing landed) instead of +=, so the caller neither zeroes the gradient nor pays its read. */
 /* adam_param != NULL (single GPU, no weight decay / TV on the table): the gradient of a chunk never leaves LDS -- the
  * reduce kernel applies torch.optim.Adam to the chunk's rows of `adam_param` directly (hyper as in
  * ngp_x_adam_step_dev) and grad_embeddings is neither read nor written.  Requires a workspace prepared with

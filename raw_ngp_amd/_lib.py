@@ -46,7 +46,7 @@ _SIGNATURES = {
     "ngp_x_grid_backward_binned_prepare": [_p, _f, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _i, _u, _i, _p,
                                            ctypes.c_size_t],
     "ngp_x_grid_backward_binned_apply": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
-                                         ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f],
+                                         ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
@@ -289,7 +289,7 @@ class _GridBackend:
 
     @staticmethod
     def grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
-                                   workspace, gridtype=0, align_corners=False, interp=0, adam=None):
+                                   workspace, gridtype=0, align_corners=False, interp=0, adam=None, overwrite=False):
         """Fill + reduce on a workspace prepared for the same positions.  adam = (param, exp_avg, exp_avg_sq, hyper,
         beta1, beta2, eps): apply the optimiser inside the reduce kernel instead of writing grad_embeddings."""
         n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
@@ -302,7 +302,7 @@ class _GridBackend:
               _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings", adam is not None),
               _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
               int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets),
-              workspace.data_ptr(), workspace.numel(), *extra)
+              workspace.data_ptr(), workspace.numel(), *extra, int(bool(overwrite)))
 
     @staticmethod
     def backward_workspace_bytes(B, L, rows):

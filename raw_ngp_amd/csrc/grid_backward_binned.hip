@@ -355,11 +355,14 @@ struct AdamArgs {
     float b1, b2, eps;
 };
 
-template <bool ADAM>
+// MODE 0: grad[chunk] += sums   1: Adam on the chunk's rows (no gradient written)   2: grad[chunk] = sums, zeros included
+// (modes 1 and 2 need one segment per chunk and visit every chunk, also the ones without records)
+template <int MODE>
 __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
                                                                  float *__restrict__ grad_table, uint32_t L, WsLayout w,
                                                                  AdamArgs opt)
 {
+    constexpr bool ADAM = MODE == 1, ALL = MODE != 0;
     __shared__ unsigned long long acc[kChunkRows * 2];   // 64 KiB: int64 fixed-point sums, [row][channel]
     __shared__ uint32_t s_chunk, s_level;
     __shared__ uint32_t s_base[kMaxLevels + 1];
@@ -370,14 +373,14 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     __syncthreads();
     const uint32_t n_chunks = s_base[L];
     const uint32_t item = blockIdx.x;
-    if (ADAM) {   // one segment per chunk: the work item IS the chunk
+    if (ALL) {   // one segment per chunk: the work item IS the chunk
         if (item >= n_chunks) return;
     } else {
         if (item >= w.seg_base[n_chunks]) return;
     }
     if (threadIdx.x == 0) {
         uint32_t lo = item;
-        if (!ADAM) {   // largest chunk with seg_base[chunk] <= item
+        if (!ALL) {   // largest chunk with seg_base[chunk] <= item
             lo = 0;
             uint32_t hi = n_chunks;
             while (hi - lo > 1) {
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     const uint32_t seg = item - w.seg_base[chunk];
     const uint32_t beg = w.offset[chunk] + seg * seg_len;                  // multiple of 4 records
     const uint32_t end = min(w.offset[chunk] + cnt, beg + seg_len);
-    if (!ADAM && beg >= end) return;   // empty chunk: nothing to add (the fused variant still has rows to update)
+    if (!ALL && beg >= end) return;   // empty chunk: nothing to add (modes 1 and 2 still have rows to write)
 
     // which level does this chunk belong to, and where does it start in the table
     const uint32_t level = s_level;
@@ -487,6 +490,10 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
                 v2[i] = vv[j];
             }
         }
+    } else if (MODE == 2) {
+        float2 *d2 = reinterpret_cast<float2 *>(dst);
+        for (uint32_t i = threadIdx.x; i < rows_here; i += kReduceBlock)
+            d2[i] = make_float2(to_float(acc[i * 2]), to_float(acc[i * 2 + 1]));
     } else if (n_seg == 1) {
         float2 *d2 = reinterpret_cast<float2 *>(dst);
         for (uint32_t i = threadIdx.x; i < rows_here; i += kReduceBlock) {
@@ -579,10 +586,12 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
                                                 uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
                                                 size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
                                                 float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
-                                                float beta2, float eps, ngp_stream_t stream)
+                                                float beta2, float eps, int overwrite, ngp_stream_t stream)
 {
     if (B == 0 || max_level == 0) return NGP_OK;
     const bool fused = adam_param != nullptr;
+    NGP_REQUIRE(!(fused && overwrite), "grid_backward_binned_apply: overwrite and fused Adam exclude each other");
+    NGP_REQUIRE(!overwrite || max_level == L, "grid_backward_binned_apply: overwrite needs max_level == L");
     NGP_REQUIRE(grad && inputs && (grad_embeddings || fused), "grid_backward_binned_apply: null tensor");
     NGP_REQUIRE(!fused || (adam_exp_avg && adam_exp_avg_sq && adam_hyper && max_level == L),
                 "grid_backward_binned_apply: fused Adam needs exp_avg, exp_avg_sq, hyper and max_level == L");
@@ -605,9 +614,11 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
     const uint32_t n_items_max = c.n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
     const AdamArgs opt{adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps};
     if (fused)   // prepared with single_segment: one workgroup owns each chunk's rows
-        bin_reduce_kernel<true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
+        bin_reduce_kernel<1><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
+    else if (overwrite)
+        bin_reduce_kernel<2><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
     else
-        bin_reduce_kernel<false><<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
+        bin_reduce_kernel<0><<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
     NGP_CHECK_LAUNCH("grid_backward_binned_apply");
     return NGP_OK;
 }
@@ -625,5 +636,5 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
     if (rc != NGP_OK) return rc;
     return ngp_x_grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L, max_level, S, H,
                                             gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
-                                            workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, 0.0f, stream);
+                                            workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, 0.0f, 0, stream);
 }

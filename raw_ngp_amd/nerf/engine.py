@@ -182,7 +182,8 @@ class FusedTrainer:
         for _, op in self._field_ops(slot, gt_rgba, bg_rgb, bg_const):
             op()
 
-    def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False, split_weights=False):
+    def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False, split_weights=False,
+                   overwrite=False):
         """The field part of the step as (C entry point, thunk) pairs, in launch order.  split_weights: the step path --
         the f16 weight image was prepared at the end of the previous step and the weight-gradient reduction is left to
         the caller (it goes to the aux stream together with the MLP's Adam step)."""
@@ -203,7 +204,7 @@ class FusedTrainer:
                 binned_workspace=slot.ws_grid)),
             ("ngp_x_grid_backward_binned_prepare", lambda: gb.grid_backward_binned_prepare(
                 None, 0.0, offsets, self.rows, cnt, cap, self.L, self.L, self.S, self.H, slot.ws_grid,
-                single_segment=fused_adam, stage=2)),
+                single_segment=fused_adam or overwrite, stage=2)),
             ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image)),
             ("ngp_x_mlp_forward", lambda: mb.forward(self.enc, cap, ar.dirs, cnt, cap, self.mlp_image, self.sigma,
                                                      self.rgb)),
@@ -216,7 +217,7 @@ class FusedTrainer:
                                                        None if split_weights else self.dws, self.ws_mlp)),
             ("ngp_x_grid_backward_binned_apply", lambda: gb.grid_backward_binned_apply(
                 self.denc, self.x01, offsets, self.table_grad, cnt, cap, cap, self.L, self.L, self.S, self.H,
-                slot.ws_grid, adam=adam)),
+                slot.ws_grid, adam=adam, overwrite=overwrite)),
         ]
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
@@ -302,8 +303,8 @@ class FusedTrainer:
         if self.opt.lambda_wd > 0:
             self.model.grid_encoder.embeddings.grad = self.table_grad
             self.model.apply_weight_decay(self.opt.lambda_wd)
-        if device_hyper:
-            eb.adam_step_dev2((self.table, self.table_grad, self.t_m, self.t_v, True),
+        if device_hyper:                                # (step path: the gradient is overwritten next step, no zeroing)
+            eb.adam_step_dev2((self.table, self.table_grad, self.t_m, self.t_v, False),
                               (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
             return
         step, lr = self.global_step + 1, self.lr()
@@ -347,8 +348,10 @@ class FusedTrainer:
         ops = [("ngp_x_step_begin", lambda: eb.step_begin(self.step_ctr, self.hyper, self.lr0, float(opt.iters),
                                                            *self.betas, self.loss, self.samples_seen,
                                                            slot.arena.counter), "main")]
+        # separate Adam (data parallel, or fuse_adam off): the reduction writes every row of the gradient, so nothing
+        # has to zero it and the accumulate's read disappears (TV / weight decay are added afterwards, in optimizer_step)
         field = self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False,
-                                fused_adam=self.fuse_adam, split_weights=split)
+                                fused_adam=self.fuse_adam, split_weights=split, overwrite=not self.fuse_adam)
         prepare = ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image))
         if split:
             tail = [("ngp_x_mlp_reduce_dw", lambda: mb.reduce_dw(self.cap, opt.loss_scale, self.dws, self.ws_mlp)),
