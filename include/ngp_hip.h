@@ -267,7 +267,11 @@ int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float *dirs, con
 /* dw1..dw6 all NULL: the per-workgroup partial sums stay in `workspace` and ngp_x_mlp_reduce_dw (same M, loss_scale,
  * workspace) produces the six gradients later -- e.g. on another stream, off the critical path. */
 int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
-                        float *dw6, const void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+                        float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
+                        const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,
+                        const float *adam_hyper, float beta1, float beta2, float eps, ngp_stream_t stream);
+/* adam_param != NULL: dw1..dw6 are views of the flat buffer adam_grad (adam_n floats) and every element is also pushed
+ * through ngp_x_adam_step_dev's update of adam_param / exp_avg / exp_avg_sq as it comes out of the reduction. */
 
 /* ------------------------------------------------------------------------------------
  * Kernels of the fused training step (csrc/engine_kernels.hip; host side raw_ngp_amd/nerf/engine.py).
@@ -331,7 +335,10 @@ int ngp_x_schedule_step(uint32_t *step_counter, float *hyper, double lr0, double
 /* ... plus the other per-step scalars of the training step in the same launch: loss_out[0] = 0 (the compositor's
  * backward accumulates into it) and samples_seen[0] += sample_counter[0]; each pair may be NULL. */
 int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1, double beta2,
-                     float *loss_out, int64_t *samples_seen, const int32_t *sample_counter, ngp_stream_t stream);
+                     float *loss_out, int64_t *samples_seen, const int32_t *sample_counter, void *binned_workspace,
+                     uint32_t L, uint32_t n_rows_total, int single_segment, ngp_stream_t stream);
+/* binned_workspace != NULL: the same launch also does ngp_x_grid_backward_binned_prepare(stage 2) on that workspace
+ * (L levels, n_rows_total table rows) -- call it after the encoder's counting forward pass. */
 
 /* counter[0] += delta, stream-ordered. */
 int ngp_x_counter_add(uint32_t *counter, uint32_t delta, ngp_stream_t stream);

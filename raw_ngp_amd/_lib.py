@@ -51,7 +51,7 @@ _SIGNATURES = {
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
-    "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
+    "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f, _f, _f],
     "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
     "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
     "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
@@ -60,7 +60,7 @@ _SIGNATURES = {
     "ngp_x_near_far_from_aabb_v2": [_p, _p, _p, _u, _f, _p, _p],
     "ngp_x_adam_step_dev": [_p, _p, _p, _p, ctypes.c_uint64, _p, _f, _f, _f, _i],
     "ngp_x_schedule_step": [_p, _p, _d, _d, _d, _d],
-    "ngp_x_step_begin": [_p, _p, _d, _d, _d, _d, _p, _p, _p],
+    "ngp_x_step_begin": [_p, _p, _d, _d, _d, _d, _p, _p, _p, _p, _u, _u, _i],
     "ngp_x_adam_step_dev2": [_p, _p, _p, _p, ctypes.c_uint64, _i, _p, _p, _p, _p, ctypes.c_uint64, _i, _p, _f, _f, _f],
     "ngp_x_counter_add": [_p, _u],
     "ngp_x_sample_rays": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p],
@@ -500,10 +500,18 @@ class _MlpBackend:
               image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"), *grads, ws.data_ptr(), nbytes)
 
     @staticmethod
-    def reduce_dw(M, loss_scale, dws, workspace):
-        """Second half of backward(..., dws=None): weight gradients from the partial sums left in `workspace`."""
+    def reduce_dw(M, loss_scale, dws, workspace, adam=None):
+        """Second half of backward(..., dws=None): weight gradients from the partial sums left in `workspace`.
+        adam = (param, grad, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps) with dws views of the flat `grad`: also
+        apply Adam to the flat weights, element by element."""
+        extra = [None, None, None, None, 0, None, 0.0, 0.0, 0.0]
+        if adam is not None:
+            p_, g_, m_, v_, hyper, b1, b2, eps = adam
+            extra = [_ptr(p_, "f", "adam_param"), _ptr(g_, "f", "adam_grad"), _ptr(m_, "f", "adam_exp_avg"),
+                     _ptr(v_, "f", "adam_exp_avg_sq"), g_.numel(), _ptr(hyper, "f", "adam_hyper"), float(b1), float(b2),
+                     float(eps)]
         _call("ngp_x_mlp_reduce_dw", workspace, M, float(loss_scale),
-              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], workspace.data_ptr(), workspace.numel())
+              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], workspace.data_ptr(), workspace.numel(), *extra)
 
 
 class _EngineBackend:
@@ -562,13 +570,15 @@ class _EngineBackend:
 
     @staticmethod
     def step_begin(step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out=None, samples_seen=None,
-                   sample_counter=None):
+                   sample_counter=None, binned_workspace=None, L=0, n_rows_total=0, single_segment=False):
         if samples_seen is not None and (samples_seen.dtype != torch.int64 or not samples_seen.is_cuda):
             raise RuntimeError("samples_seen must be an int64 CUDA tensor")
         _call("ngp_x_step_begin", hyper, _ptr(step_counter, "u", "step_counter"), _ptr(hyper, "f", "hyper"), float(lr0),
               float(decay_steps), float(beta1), float(beta2), _ptr(loss_out, "f", "loss_out", True),
               samples_seen.data_ptr() if samples_seen is not None else None,
-              _ptr(sample_counter, "i", "sample_counter", True))
+              _ptr(sample_counter, "i", "sample_counter", True),
+              binned_workspace.data_ptr() if binned_workspace is not None else None, int(L), int(n_rows_total),
+              int(bool(single_segment)))
 
     @staticmethod
     def adam_step_dev2(a, b, hyper, beta1, beta2, eps):

@@ -398,9 +398,15 @@ __global__ void schedule_kernel(uint32_t *step_counter, float *hyper, double lr0
 
 __global__ void counter_add_kernel(uint32_t *counter, uint32_t delta) { counter[0] += delta; }
 
-__global__ void step_begin_kernel(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double b1, double b2,
-                                  float *loss_out, long long *samples_seen, const int32_t *sample_counter)
+// (optionally also the binned backward's scan: both are one-workgroup jobs between the encoder's forward pass and the
+// MLP, and each launch on the critical path costs ~6 us)
+__global__ __launch_bounds__(1024) void step_begin_kernel(uint32_t *step_counter, float *hyper, double lr0,
+                                                         double decay_steps, double b1, double b2, float *loss_out,
+                                                         long long *samples_seen, const int32_t *sample_counter,
+                                                         bool scan, uint32_t L, WsLayout w, bool single_segment)
 {
+    if (scan) bin_scan_block(L, w, single_segment);
+    if (threadIdx.x != 0) return;
     const uint32_t done = step_counter[0];
     const double t = (double)done + 1.0;
     const double frac = fmin((double)done / decay_steps, 1.0);
@@ -605,13 +611,23 @@ extern "C" int ngp_x_schedule_step(uint32_t *step_counter, float *hyper, double 
 
 extern "C" int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1,
                                 double beta2, float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
+                                void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment,
                                 ngp_stream_t stream)
 {
     NGP_REQUIRE(step_counter && hyper, "step_begin: null tensor");
     NGP_REQUIRE(decay_steps > 0.0, "step_begin: decay_steps must be positive");
     NGP_REQUIRE((samples_seen == nullptr) == (sample_counter == nullptr), "step_begin: samples_seen and sample_counter go together");
-    step_begin_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out,
-                                                                  reinterpret_cast<long long *>(samples_seen), sample_counter);
+    WsLayout w{};
+    if (binned_workspace) {   // = ngp_x_grid_backward_binned_prepare(stage 2) for that workspace
+        NGP_REQUIRE(L >= 1 && L <= kMaxLevels && n_rows_total > 0 && ((uintptr_t)binned_workspace & 15u) == 0,
+                    "step_begin: bad binned workspace arguments");
+        const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
+        NGP_REQUIRE(n_chunks_max <= kMaxChunks, "step_begin: table too large for the binned backward");
+        w = ws_layout(binned_workspace, n_chunks_max);
+    }
+    step_begin_kernel<<<dim3(1), dim3(binned_workspace ? 1024 : 64), 0, as_stream(stream)>>>(
+        step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out, reinterpret_cast<long long *>(samples_seen),
+        sample_counter, binned_workspace != nullptr, L, w, single_segment != 0);
     NGP_CHECK_LAUNCH("step_begin");
     return NGP_OK;
 }

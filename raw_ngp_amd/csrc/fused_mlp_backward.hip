@@ -566,12 +566,22 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
 // ---- partial-slab reduction -----------------------------------------------------------------------
 // element e of a workgroup slab: tile b = e / 1024, register v = (e / 64) % 16, lane = e % 64
 // -> dW[32*rb + o][32*cb + j] with o = (v&3) + 8(v>>2) + 4(lane>>5), j = lane & 31
+// optional: torch.optim.Adam (as engine_kernels.hip: adam_span) on the flat MLP weight buffer, element by element as the
+// gradients come out of the reduction; dw1..dw6 must then be views of `grad`
+struct MlpAdam {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq;
+    const float *hyper;   // {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)}
+    float b1, b2, eps;
+};
+
 __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restrict__ part_view,
                                                            const float *__restrict__ part_grid, uint32_t n_wg,
                                                            float inv_loss_scale, float *__restrict__ dw1,
                                                            float *__restrict__ dw2, float *__restrict__ dw3,
                                                            float *__restrict__ dw4, float *__restrict__ dw5,
-                                                           float *__restrict__ dw6)
+                                                           float *__restrict__ dw6, MlpAdam adam)
 {
     // 64 outputs per workgroup; wave q sums the slabs q, q + 4, q + 8, ... (eight loads in flight: the sum is
     // latency-bound otherwise) and the four partial sums are added in wave order -- a fixed order, so the result is
@@ -598,22 +608,34 @@ __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restr
     s *= inv_loss_scale;
     const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
     const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;
+    float *dst = nullptr;   // padding elements of the tiles have no weight behind them
     if (b < 2) {   // first-layer tiles: rb = b
         if (view) {
-            if (j >= 1) dw4[(32 * b + o) * 31 + j - 1] = s;
+            if (j >= 1) dst = &dw4[(32 * b + o) * 31 + j - 1];
         } else {
-            dw1[(32 * b + o) * 32 + j] = s;
+            dst = &dw1[(32 * b + o) * 32 + j];
         }
     } else if (b < 6) {   // 64 x 64 tiles: rb = (b-2) >> 1, cb = (b-2) & 1
         const uint32_t rb = (b - 2) >> 1, cb = (b - 2) & 1;
-        (view ? dw5 : dw2)[(32 * rb + o) * 64 + 32 * cb + j] = s;
+        dst = &(view ? dw5 : dw2)[(32 * rb + o) * 64 + 32 * cb + j];
     } else {   // last-layer tiles: cb = b - 6
         const uint32_t cb = b - 6;
         if (view) {
-            if (o < 3) dw6[o * 64 + 32 * cb + j] = s;
+            if (o < 3) dst = &dw6[o * 64 + 32 * cb + j];
         } else {
-            if (o < 16) dw3[o * 64 + 32 * cb + j] = s;
+            if (o < 16) dst = &dw3[o * 64 + 32 * cb + j];
         }
+    }
+    if (!dst) return;
+    *dst = s;
+    if (adam.param) {   // the six gradients are views of one flat buffer: Adam on the element just reduced
+        const size_t k = (size_t)(dst - adam.grad);
+        const float step_size = adam.hyper[0] / adam.hyper[1], rsqrt_bc2 = adam.hyper[2];
+        const float mi = adam.b1 * adam.exp_avg[k] + (1.0f - adam.b1) * s;
+        const float vi = adam.b2 * adam.exp_avg_sq[k] + (1.0f - adam.b2) * s * s;
+        adam.exp_avg[k] = mi;
+        adam.exp_avg_sq[k] = vi;
+        adam.param[k] -= step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + adam.eps));
     }
 }
 
@@ -658,7 +680,7 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
                                                                         d3buf, denc, part_grid);
     if (reduce_now)
         mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, st>>>(part_view, part_grid, blocks, 1.0f / loss_scale,
-                                                                              dw1, dw2, dw3, dw4, dw5, dw6);
+                                                                              dw1, dw2, dw3, dw4, dw5, dw6, MlpAdam{});
     NGP_CHECK_LAUNCH("mlp_backward");
     return NGP_OK;
 }
@@ -667,9 +689,16 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
 // partial slabs the two backward kernels left in `workspace` (same M, same loss_scale)
 extern "C" int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4,
                                    float *dw5, float *dw6, const void *workspace, size_t workspace_bytes,
+                                   float *adam_param, const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq,
+                                   uint32_t adam_n, const float *adam_hyper, float beta1, float beta2, float eps,
                                    ngp_stream_t stream)
 {
     NGP_REQUIRE(dw1 && dw2 && dw3 && dw4 && dw5 && dw6 && workspace, "mlp_reduce_dw: null tensor");
+    if (adam_param) {
+        NGP_REQUIRE(adam_grad && adam_exp_avg && adam_exp_avg_sq && adam_hyper, "mlp_reduce_dw: incomplete Adam state");
+        for (const float *d : {dw1, dw2, dw3, dw4, dw5, dw6})
+            NGP_REQUIRE(d >= adam_grad && d < adam_grad + adam_n, "mlp_reduce_dw: dw tensors must be views of adam_grad");
+    }
     NGP_REQUIRE(workspace_bytes >= ngp_x_mlp_backward_workspace_bytes(M), "mlp_reduce_dw: workspace too small");
     NGP_REQUIRE(loss_scale > 0.0f, "mlp_reduce_dw: loss_scale must be positive");
     const uint32_t blocks = mlp_bwd_blocks(max(M, 1u));
@@ -677,7 +706,8 @@ extern "C" int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, flo
                                                              (((size_t)M * 32 + 255) & ~(size_t)255));
     const float *part_grid = part_view + (size_t)256 * kAccFloats;
     mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, as_stream(stream)>>>(
-        part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6);
+        part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6,
+        MlpAdam{adam_param, adam_grad, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps});
     NGP_CHECK_LAUNCH("mlp_reduce_dw");
     return NGP_OK;
 }

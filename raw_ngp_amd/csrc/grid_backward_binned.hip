@@ -148,57 +148,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const float *__restri
 // ------------------------------------------------------------------ scan
 __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w, bool single_segment)
 {
-    __shared__ uint32_t wave_a[16], wave_b[16];
-    __shared__ uint32_t carry_a, carry_b;
-    const uint32_t n = w.chunk_base[L];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    if (tid == 0) carry_a = carry_b = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024u) {
-        const uint32_t i = base + tid;
-        const uint32_t cnt = i < n ? w.count[i] : 0u;
-        const uint32_t cnt4 = (cnt + 3u) & ~3u;   // 4-record alignment: 16-byte loads in the reduce kernel
-        const uint32_t seg_len = cnt > kSegBig ? kSegBig : kSeg;   // heavy chunks: 8x longer work items
-        const uint32_t seg = i < n ? (single_segment ? 1u : max(1u, (cnt + seg_len - 1) / seg_len)) : 0u;
-        uint32_t a = cnt4, s = seg;
-#pragma unroll
-        for (uint32_t d = 1; d < 64u; d <<= 1) {
-            const uint32_t ua = __shfl_up(a, d, 64), us = __shfl_up(s, d, 64);
-            if (lane >= d) {
-                a += ua;
-                s += us;
-            }
-        }
-        if (lane == 63u) {
-            wave_a[wid] = a;
-            wave_b[wid] = s;
-        }
-        __syncthreads();
-        uint32_t oa = 0, ob = 0, ta = 0, tb = 0;
-        for (uint32_t k = 0; k < 16u; k++) {
-            if (k < wid) {
-                oa += wave_a[k];
-                ob += wave_b[k];
-            }
-            ta += wave_a[k];
-            tb += wave_b[k];
-        }
-        const uint32_t ca = carry_a, cb = carry_b;
-        if (i < n) {
-            w.offset[i] = ca + oa + a - cnt4;
-            w.seg_base[i] = cb + ob + s - seg;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            carry_a = ca + ta;
-            carry_b = cb + tb;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        w.offset[n] = carry_a;
-        w.seg_base[n] = carry_b;
-    }
+    bin_scan_block(L, w, single_segment);
 }
 
 // ------------------------------------------------------------------ fill

@@ -223,6 +223,10 @@ class FusedTrainer:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
         return ops
 
+    @staticmethod
+    def _without(ops, name):
+        return [o for o in ops if o[0] != name]
+
     @torch.no_grad()
     def refresh_density_grid(self, decay=0.95):
         """NeRFRenderer.update_extra_state (nerf/renderer.py:811-897) as ~10 launches per cascade with nothing read
@@ -344,19 +348,25 @@ class FusedTrainer:
         opt = self.opt
         bg_const = 1.0 if opt.background in ("white", "last_sample") else 0.0
         split = self.fuse_adam
-        # lr / Adam bias corrections of this step, loss = 0, samples_seen += this batch's sample count
-        ops = [("ngp_x_step_begin", lambda: eb.step_begin(self.step_ctr, self.hyper, self.lr0, float(opt.iters),
-                                                           *self.betas, self.loss, self.samples_seen,
-                                                           slot.arena.counter), "main")]
+        # lr / Adam bias corrections of this step, loss = 0, samples_seen += this batch's sample count -- and the record
+        # offsets of the binned backward (the scan after the encoder's counting pass): one launch, right after the forward
+        begin = ("ngp_x_step_begin", lambda: eb.step_begin(
+            self.step_ctr, self.hyper, self.lr0, float(opt.iters), *self.betas, self.loss, self.samples_seen,
+            slot.arena.counter, binned_workspace=slot.ws_grid, L=self.L, n_rows_total=self.rows, single_segment=True))
+        ops = []
         # separate Adam (data parallel, or fuse_adam off): the reduction writes every row of the gradient, so nothing
         # has to zero it and the accumulate's read disappears (TV / weight decay are added afterwards, in optimizer_step)
         field = self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False,
                                 fused_adam=self.fuse_adam, split_weights=split, overwrite=not self.fuse_adam)
+        field = self._without(field, "ngp_x_grid_backward_binned_prepare")          # folded into step_begin
+        field.insert(1, begin)                                                      # right after the encoder's forward
         prepare = ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image))
         if split:
-            tail = [("ngp_x_mlp_reduce_dw", lambda: mb.reduce_dw(self.cap, opt.loss_scale, self.dws, self.ws_mlp)),
-                    ("ngp_x_adam_step_dev", lambda: eb.adam_step_dev(self.w_flat, self.w_grad, self.w_m, self.w_v,
-                                                                     self.hyper, *self.betas, self.eps, False)),
+            # weight gradients out of the partial sums and, element by element, Adam on the flat MLP weights; then the
+            # f16 weight image for the next step
+            tail = [("ngp_x_mlp_reduce_dw", lambda: mb.reduce_dw(
+                        self.cap, opt.loss_scale, self.dws, self.ws_mlp,
+                        adam=(self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps))),
                     prepare]
             for name, op in field:
                 if name == "ngp_x_grid_backward_binned_apply":      # right after the MLP backward, beside the apply
