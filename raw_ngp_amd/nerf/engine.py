@@ -1,17 +1,24 @@
 """Fused training step of the density-grid path: the reference's train_step + backward + optimiser
-(nerf/train_utils.py:481-568, :890-907; nerf/renderer.py:515-556; main.py:245,261) as one fixed sequence of
-~20 HIP kernel launches on pre-allocated buffers.
+(nerf/train_utils.py:481-568, :890-907; nerf/renderer.py:515-556; main.py:245,261) and its density-grid refresh
+(renderer.py:811-897) as a fixed sequence of HIP kernel launches on pre-allocated buffers, replayed from hipGraphs.
 
 Compared with the per-op autograd path (raw_ngp_amd.nerf.trainer.Trainer, which mirrors the reference op by op)
 the arithmetic is the same and the plumbing is not:
-  * rays are marched ONCE into a sample arena (count + scan + coalesced expand); nothing waits for the sample
-    count on the host -- every later kernel reads it from the arena's device counter
-  * the hash-grid encoder writes the level-major slab the fused MFMA MLP reads; no permutes, no concatenations
+  * ray batches are drawn on the device (Philox) and marched ONCE into a sample arena by the chain-parallel march; the
+    batch of step i+1 is prepared on a second stream while step i trains; nothing waits for a sample count on the host
+    -- every kernel reads it from the arena's device counter
+  * the hash-grid encoder writes the level-major slab the fused MFMA MLP reads (no permutes, no concatenations) and
+    counts the records of the table backward while it has the rows in registers
   * compositing runs one wave per ray; the MSE loss, the background mix and its gradient are folded into the
     compositing backward kernel
-  * the table gradient is binned and reduced in LDS (64-bit fixed point), Adam is one pass per parameter buffer
-  * autograd, GradScaler, zeros_like and the foreach optimiser are gone (their work is in the kernels)
-The density-grid refresh (every `update_extra_interval` steps) still goes through NeRFRenderer.update_extra_state.
+  * the table gradient is binned and reduced in LDS (64-bit fixed point); on one GPU Adam is applied inside that
+    reduction (the gradient never reaches HBM), under data parallelism the gradient is all-reduced first
+  * learning-rate schedule, loss, sample counters live on the device; autograd, GradScaler, zeros_like and the foreach
+    optimiser are gone (their work is in the kernels)
+  * the density-grid refresh draws its cells, evaluates, EMA-maxes and re-packs the bitfield without a host round trip
+Main stream per step (one graph): encoder forward (+count) -> step_begin (+scan) -> MLP forward -> composite -> loss +
+composite backward -> MLP backward (2) -> dW reduction (+Adam on the MLP weights) -> weight image -> fill -> reduce
+(+Adam on the table).  Same seed, same bits: no float atomic feeds back into the state.
 """
 import math
 
