@@ -12,8 +12,8 @@ constexpr uint32_t kMaxChunks = 2048;    // LDS histogram bound of the binned pa
 constexpr uint32_t kSegBig = 8 * kSeg;   // ... of a heavy chunk (coarse dense levels): fewer, longer items
 constexpr uint32_t kReduceBlock = 512;
 constexpr int kHeadroomBits = 25;        // records that may land on one row without overflowing the int64 sum
-constexpr uint32_t kFillTile = 256;      // samples per fill workgroup
-constexpr uint32_t kFillBlock = 256;     // ... one per lane
+constexpr uint32_t kFillTile = 512;      // samples per fill workgroup
+constexpr uint32_t kFillBlock = 512;     // ... one per lane
 constexpr uint32_t kCountTile = 2048;    // samples per count workgroup (8 per lane)
 
 // workspace header (uint32 words); arrays sized for n_chunks_max
