@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--no-fuse-adam", action="store_true",
                     help="separate Adam pass over the table (what data-parallel ranks run), on one GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--grad-wire", default="bf16", choices=["f32", "bf16"],
                     help="data parallel: wire format of the table-gradient all-reduce")
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
     ap.add_argument("--autograd", action="store_true", help="per-op autograd path (Trainer) instead of the fused step")

@@ -223,7 +223,9 @@ int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, con
                                      float *adam_exp_avg_sq, const float *adam_hyper, float beta1, float beta2,
                                      float eps, int overwrite, ngp_stream_t stream);
 /* overwrite != 0 (workspace prepared with single_segment, max_level == L): grad_embeddings = sums for EVERY row of every
- * level (zeros where nothing landed) instead of +=, so the caller neither zeroes the gradient nor pays its read. */
+ * level (zeros where nothing landed) instead of +=, so the caller neither zeroes the gradient nor pays its read.
+ * overwrite == 2: the same, stored as bfloat16 (round to nearest even) -- grad_embeddings then points to
+ * n_rows_total * C 16-bit values, the wire format of the data-parallel gradient exchange. */
 /* adam_param != NULL (single GPU, no weight decay / TV on the table): the gradient of a chunk never leaves LDS -- the
  * reduce kernel applies torch.optim.Adam to the chunk's rows of `adam_param` directly (hyper as in
  * ngp_x_adam_step_dev) and grad_embeddings is neither read nor written.  Requires a workspace prepared with
@@ -322,11 +324,13 @@ int ngp_x_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq
  * from a captured graph. */
 int ngp_x_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, const float *hyper,
                         float beta1, float beta2, float eps, int zero_grad, ngp_stream_t stream);
-/* Two parameter tensors in one launch (the hash table and the flat MLP weights). */
+/* Two parameter tensors in one launch (the hash table and the flat MLP weights).  grad_a_bf16 != 0: grad_a points
+ * to n_a bfloat16 values (the data-parallel wire format written by ngp_x_grid_backward_binned_apply with
+ * overwrite = 2 and averaged over the ranks in place); it is then never zeroed. */
 int ngp_x_adam_step_dev2(float *param_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a, uint64_t n_a,
                          int zero_grad_a, float *param_b, float *grad_b, float *exp_avg_b, float *exp_avg_sq_b,
                          uint64_t n_b, int zero_grad_b, const float *hyper, float beta1, float beta2, float eps,
-                         ngp_stream_t stream);
+                         int grad_a_bf16, ngp_stream_t stream);
 
 /* Device-side scheduler: t = step_counter[0] steps are done; writes hyper = {lr0 * 0.1^min(t/decay_steps, 1)
  * (the LambdaLR of main.py:261), 1 - beta1^(t+1), 1/sqrt(1 - beta2^(t+1))} and increments the counter. */

@@ -61,7 +61,7 @@ _SIGNATURES = {
     "ngp_x_adam_step_dev": [_p, _p, _p, _p, ctypes.c_uint64, _p, _f, _f, _f, _i],
     "ngp_x_schedule_step": [_p, _p, _d, _d, _d, _d],
     "ngp_x_step_begin": [_p, _p, _d, _d, _d, _d, _p, _p, _p, _p, _u, _u, _i],
-    "ngp_x_adam_step_dev2": [_p, _p, _p, _p, ctypes.c_uint64, _i, _p, _p, _p, _p, ctypes.c_uint64, _i, _p, _f, _f, _f],
+    "ngp_x_adam_step_dev2": [_p, _p, _p, _p, ctypes.c_uint64, _i, _p, _p, _p, _p, ctypes.c_uint64, _i, _p, _f, _f, _f, _i],
     "ngp_x_counter_add": [_p, _u],
     "ngp_x_sample_rays": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p],
     "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
@@ -113,7 +113,8 @@ def declared_symbols():
             "ngp_x_density_grid_workspace_bytes"] + list(_SIGNATURES)
 
 
-_DT = {"f": torch.float32, "i": torch.int32, "b": torch.uint8, "u": torch.int32}   # counters: int32 storage
+_DT = {"f": torch.float32, "i": torch.int32, "b": torch.uint8, "u": torch.int32,   # counters: int32 storage
+       "h": torch.bfloat16}
 
 
 def _ptr(t, kind, name, optional=False):
@@ -291,18 +292,23 @@ class _GridBackend:
     def grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
                                    workspace, gridtype=0, align_corners=False, interp=0, adam=None, overwrite=False):
         """Fill + reduce on a workspace prepared for the same positions.  adam = (param, exp_avg, exp_avg_sq, hyper,
-        beta1, beta2, eps): apply the optimiser inside the reduce kernel instead of writing grad_embeddings."""
+        beta1, beta2, eps): apply the optimiser inside the reduce kernel instead of writing grad_embeddings.
+        overwrite: grad_embeddings = sums for every row (no +=); a bfloat16 grad_embeddings selects the 16-bit store."""
         n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
+        wire16 = grad_embeddings is not None and grad_embeddings.dtype == torch.bfloat16
+        if wire16 and not overwrite:
+            raise RuntimeError("a bfloat16 grad_embeddings needs overwrite=True")
         extra = [None, None, None, None, 0.0, 0.0, 0.0]
         if adam is not None:
             p_, m_, v_, hyper, b1, b2, eps = adam
             extra = [_ptr(p_, "f", "adam_param"), _ptr(m_, "f", "adam_exp_avg"), _ptr(v_, "f", "adam_exp_avg_sq"),
                      _ptr(hyper, "f", "adam_hyper"), float(b1), float(b2), float(eps)]
         _call("ngp_x_grid_backward_binned_apply", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
-              _ptr(offsets, "i", "offsets"), _ptr(grad_embeddings, "f", "grad_embeddings", adam is not None),
+              _ptr(offsets, "i", "offsets"),
+              _ptr(grad_embeddings, "h" if wire16 else "f", "grad_embeddings", adam is not None),
               _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
               int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets),
-              workspace.data_ptr(), workspace.numel(), *extra, int(bool(overwrite)))
+              workspace.data_ptr(), workspace.numel(), *extra, 2 if wire16 else int(bool(overwrite)))
 
     @staticmethod
     def backward_workspace_bytes(B, L, rows):
@@ -582,12 +588,17 @@ class _EngineBackend:
 
     @staticmethod
     def adam_step_dev2(a, b, hyper, beta1, beta2, eps):
-        """a, b = (param, grad, exp_avg, exp_avg_sq, zero_grad) of two tensors updated by one launch."""
+        """a, b = (param, grad, exp_avg, exp_avg_sq, zero_grad) of two tensors updated by one launch; a's gradient may
+        be bfloat16 (the data-parallel wire format)."""
         args = []
+        a16 = a[1].dtype == torch.bfloat16
         for name, (p_, g_, m_, v_, z_) in (("a", a), ("b", b)):
-            args += [_ptr(p_, "f", f"param_{name}"), _ptr(g_, "f", f"grad_{name}"), _ptr(m_, "f", f"exp_avg_{name}"),
-                     _ptr(v_, "f", f"exp_avg_sq_{name}"), p_.numel(), int(bool(z_))]
-        _call("ngp_x_adam_step_dev2", hyper, *args, _ptr(hyper, "f", "hyper"), float(beta1), float(beta2), float(eps))
+            if g_.numel() != p_.numel():
+                raise RuntimeError(f"grad_{name} and param_{name} differ in size")
+            args += [_ptr(p_, "f", f"param_{name}"), _ptr(g_, "h" if a16 and name == "a" else "f", f"grad_{name}"),
+                     _ptr(m_, "f", f"exp_avg_{name}"), _ptr(v_, "f", f"exp_avg_sq_{name}"), p_.numel(), int(bool(z_))]
+        _call("ngp_x_adam_step_dev2", hyper, *args, _ptr(hyper, "f", "hyper"), float(beta1), float(beta2), float(eps),
+              int(a16))
 
     @staticmethod
     def counter_add(counter, delta=1):

@@ -321,15 +321,25 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
 // ------------------------------------------------------------------ Adam
 // torch.optim.Adam(step): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 //                         p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),  bc_i = 1 - b_i^step
+// G16: the gradient is stored as bfloat16 (the data-parallel wire format; never zeroed here)
+template <bool G16 = false>
 __device__ __forceinline__ void adam_span(float *__restrict__ p, const float *g, float *__restrict__ m,
                                           float *__restrict__ v, size_t n4, size_t n, float lr, float b1, float b2,
                                           float eps, float bc1, float rsqrt_bc2, bool zero_grad, float *g_mut, size_t tid,
                                           size_t nthreads)
 {
     const float step_size = lr / bc1;
+    const uint16_t *g16 = reinterpret_cast<const uint16_t *>(g);
     for (size_t i = tid; i < n4; i += nthreads) {
         float4 pp = reinterpret_cast<float4 *>(p)[i];
-        const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+        float4 gg;
+        if (G16) {
+            const uint2 u = reinterpret_cast<const uint2 *>(g)[i];
+            gg = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                             __uint_as_float(u.y & 0xffff0000u));
+        } else {
+            gg = reinterpret_cast<const float4 *>(g)[i];
+        }
         float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
 #define NGP_ADAM1(c)                                                       \
     mm.c = b1 * mm.c + (1.0f - b1) * gg.c;                                 \
@@ -339,15 +349,15 @@ __device__ __forceinline__ void adam_span(float *__restrict__ p, const float *g,
         reinterpret_cast<float4 *>(p)[i] = pp;
         reinterpret_cast<float4 *>(m)[i] = mm;
         reinterpret_cast<float4 *>(v)[i] = vv;
-        if (zero_grad) reinterpret_cast<float4 *>(g_mut)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!G16 && zero_grad) reinterpret_cast<float4 *>(g_mut)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (size_t i = n4 * 4 + tid; i < n; i += nthreads) {   // tail
-        const float gi = g[i];
+        const float gi = G16 ? __uint_as_float((uint32_t)g16[i] << 16) : g[i];
         const float mi = b1 * m[i] + (1.0f - b1) * gi, vi = b2 * v[i] + (1.0f - b2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
         p[i] -= step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + eps));
-        if (zero_grad) g_mut[i] = 0.0f;
+        if (!G16 && zero_grad) g_mut[i] = 0.0f;
     }
 }
 
@@ -372,14 +382,19 @@ struct AdamTensor {
 };
 
 // blocks [0, blocks_a) update tensor a, the rest tensor b
+template <bool A16>
 __global__ __launch_bounds__(256) void adam2_kernel(AdamTensor a, AdamTensor b, uint32_t blocks_a, float b1, float b2,
                                                     float eps, const float *__restrict__ hyper)
 {
     const bool first = blockIdx.x < blocks_a;
     const AdamTensor t = first ? a : b;
     const uint32_t blk = first ? blockIdx.x : blockIdx.x - blocks_a, nblk = first ? blocks_a : gridDim.x - blocks_a;
-    adam_span(t.p, t.g, t.m, t.v, t.n / 4, t.n, hyper[0], b1, b2, eps, hyper[1], hyper[2], t.zero_grad, t.g,
-              (size_t)blk * 256 + threadIdx.x, (size_t)nblk * 256);
+    if (A16 && first)
+        adam_span<true>(t.p, t.g, t.m, t.v, t.n / 4, t.n, hyper[0], b1, b2, eps, hyper[1], hyper[2], false, t.g,
+                        (size_t)blk * 256 + threadIdx.x, (size_t)nblk * 256);
+    else
+        adam_span(t.p, t.g, t.m, t.v, t.n / 4, t.n, hyper[0], b1, b2, eps, hyper[1], hyper[2], t.zero_grad, t.g,
+                  (size_t)blk * 256 + threadIdx.x, (size_t)nblk * 256);
 }
 
 // ------------------------------------------------------------------ step state on the device
@@ -635,9 +650,10 @@ extern "C" int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0
 extern "C" int ngp_x_adam_step_dev2(float *param_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a, uint64_t n_a,
                                     int zero_grad_a, float *param_b, float *grad_b, float *exp_avg_b,
                                     float *exp_avg_sq_b, uint64_t n_b, int zero_grad_b, const float *hyper, float beta1,
-                                    float beta2, float eps, ngp_stream_t stream)
+                                    float beta2, float eps, int grad_a_bf16, ngp_stream_t stream)
 {
     NGP_REQUIRE(n_a > 0 && n_b > 0, "adam_step_dev2: empty tensor (use adam_step_dev)");
+    NGP_REQUIRE(!(grad_a_bf16 && zero_grad_a), "adam_step_dev2: a bfloat16 gradient is not zeroed");
     NGP_REQUIRE(param_a && grad_a && exp_avg_a && exp_avg_sq_a && param_b && grad_b && exp_avg_b && exp_avg_sq_b && hyper,
                 "adam_step_dev2: null tensor");
     NGP_REQUIRE((((uintptr_t)param_a | (uintptr_t)grad_a | (uintptr_t)exp_avg_a | (uintptr_t)exp_avg_sq_a |
@@ -647,7 +663,10 @@ extern "C" int ngp_x_adam_step_dev2(float *param_a, float *grad_a, float *exp_av
     const uint32_t ba = blocks_for(n_a), bb = blocks_for(n_b);
     const AdamTensor a{param_a, grad_a, exp_avg_a, exp_avg_sq_a, (size_t)n_a, zero_grad_a != 0};
     const AdamTensor b{param_b, grad_b, exp_avg_b, exp_avg_sq_b, (size_t)n_b, zero_grad_b != 0};
-    adam2_kernel<<<dim3(ba + bb), dim3(256), 0, as_stream(stream)>>>(a, b, ba, beta1, beta2, eps, hyper);
+    if (grad_a_bf16)
+        adam2_kernel<true><<<dim3(ba + bb), dim3(256), 0, as_stream(stream)>>>(a, b, ba, beta1, beta2, eps, hyper);
+    else
+        adam2_kernel<false><<<dim3(ba + bb), dim3(256), 0, as_stream(stream)>>>(a, b, ba, beta1, beta2, eps, hyper);
     NGP_CHECK_LAUNCH("adam_step_dev2");
     return NGP_OK;
 }

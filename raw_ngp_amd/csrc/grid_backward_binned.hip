@@ -306,6 +306,7 @@ struct AdamArgs {
 };
 
 // MODE 0: grad[chunk] += sums   1: Adam on the chunk's rows (no gradient written)   2: grad[chunk] = sums, zeros included
+// MODE 3: as 2, but the gradient is stored as bfloat16 (round to nearest even): the data-parallel wire format
 // (modes 1 and 2 need one segment per chunk and visit every chunk, also the ones without records)
 template <int MODE>
 __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
@@ -444,6 +445,14 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
         float2 *d2 = reinterpret_cast<float2 *>(dst);
         for (uint32_t i = threadIdx.x; i < rows_here; i += kReduceBlock)
             d2[i] = make_float2(to_float(acc[i * 2]), to_float(acc[i * 2 + 1]));
+    } else if (MODE == 3) {
+        uint32_t *d16 = reinterpret_cast<uint32_t *>(grad_table) + ((size_t)(uint32_t)offsets[level] + row0);
+        auto bf16 = [](float f) {
+            const uint32_t u = __float_as_uint(f);
+            return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+        };
+        for (uint32_t i = threadIdx.x; i < rows_here; i += kReduceBlock)
+            d16[i] = bf16(to_float(acc[i * 2])) | (bf16(to_float(acc[i * 2 + 1])) << 16);
     } else if (n_seg == 1) {
         float2 *d2 = reinterpret_cast<float2 *>(dst);
         for (uint32_t i = threadIdx.x; i < rows_here; i += kReduceBlock) {
@@ -565,6 +574,8 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
     const AdamArgs opt{adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps};
     if (fused)   // prepared with single_segment: one workgroup owns each chunk's rows
         bin_reduce_kernel<1><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
+    else if (overwrite == 2)
+        bin_reduce_kernel<3><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
     else if (overwrite)
         bin_reduce_kernel<2><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
     else

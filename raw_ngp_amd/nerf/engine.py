@@ -121,7 +121,12 @@ class FusedTrainer:
             and opt.lambda_wd == 0
         self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
         self._refresh_graph = None
-        self._wire = None
+        # 16-bit wire format of the table gradient under data parallelism: the reduce kernel stores bfloat16, RCCL
+        # averages it in place, Adam reads it -- no conversion passes, half the bytes on xGMI
+        self.wire16 = getattr(opt, "grad_wire", "f32") == "bf16" and not self.fuse_adam \
+            and opt.lambda_tv == 0 and opt.lambda_wd == 0
+        self._wire = torch.zeros(self.table_grad.shape, dtype=torch.bfloat16, device=dev) if self.wire16 else None
+        self._pending = None
         self._main_symbols = {"ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
                               "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
                               "ngp_x_composite_mse_backward", "ngp_x_adam_step_dev2", "ngp_x_adam_step_dev",
@@ -223,8 +228,8 @@ class FusedTrainer:
                                                        self.mlp_image, opt.loss_scale, self.denc,
                                                        None if split_weights else self.dws, self.ws_mlp)),
             ("ngp_x_grid_backward_binned_apply", lambda: gb.grid_backward_binned_apply(
-                self.denc, self.x01, offsets, self.table_grad, cnt, cap, cap, self.L, self.L, self.S, self.H,
-                slot.ws_grid, adam=adam, overwrite=overwrite)),
+                self.denc, self.x01, offsets, self._wire if overwrite and self.wire16 else self.table_grad, cnt, cap, cap,
+                self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite)),
         ]
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
@@ -278,32 +283,33 @@ class FusedTrainer:
     def mean_density(self):
         return float(self.dg_stats[1]) if self.native_refresh else float(self.model.mean_density)   # host read
 
-    def reduce_gradients(self):
+    def reduce_gradients(self, wire=False, part="all"):
         """Ray-batch data parallelism: average the table and MLP gradients over the ranks (RCCL over xGMI).
-        The table gradient is reduced in place as one 46.5 MiB collective; AVG folds the division into it."""
-        if self.world_size > 1:
-            dist = torch.distributed
-            if self.opt.grad_wire == "bf16" and dist.get_backend() == "nccl":
-                # optional 16-bit wire format for the 46.5 MiB table gradient (half the all-reduce time; the sum is
-                # formed in bf16, ~3 significant digits -- Adam normalises the magnitude anyway).  Off by default.
-                if self._wire is None:
-                    self._wire = torch.empty(self.table_grad.shape, dtype=torch.bfloat16, device=self.device)
-                self._wire.copy_(self.table_grad)
-                big = dist.all_reduce(self._wire, op=dist.ReduceOp.AVG, async_op=True)
-                small = dist.all_reduce(self.w_grad, op=dist.ReduceOp.AVG, async_op=True)
+        The table gradient is reduced in place as one collective (46.5 MiB, or 23 MiB in bfloat16); AVG folds the
+        division into it.  wire: the step path's gradient buffer (bfloat16 when grad_wire == "bf16").
+        part "weights" only starts the small collective (the step path issues it right after the MLP backward, so it
+        travels while the table gradient is still being binned), "table" runs the big one and waits for both."""
+        if self.world_size == 1:
+            return
+        dist = torch.distributed
+        # grad_wire "bf16": the table gradient already IS bfloat16 (the sum over ranks is formed in bf16, ~3 significant
+        # digits -- Adam normalises the magnitude anyway)
+        table = self._wire if wire and self.wire16 else self.table_grad
+        if dist.get_backend() == "nccl":
+            if part in ("all", "weights"):
+                self._pending = dist.all_reduce(self.w_grad, op=dist.ReduceOp.AVG, async_op=True)
+            if part in ("all", "table"):
+                big = dist.all_reduce(table, op=dist.ReduceOp.AVG, async_op=True)
                 big.wait()
-                small.wait()
-                self.table_grad.copy_(self._wire)
-            elif dist.get_backend() == "nccl":
-                big = dist.all_reduce(self.table_grad, op=dist.ReduceOp.AVG, async_op=True)
-                small = dist.all_reduce(self.w_grad, op=dist.ReduceOp.AVG, async_op=True)
-                big.wait()
-                small.wait()
-            else:                                   # gloo (rehearsal): no AVG
-                dist.all_reduce(self.table_grad)
+                self._pending.wait()
+                self._pending = None
+        else:                                       # gloo (rehearsal): no AVG
+            if part in ("all", "weights"):
                 dist.all_reduce(self.w_grad)
-                self.table_grad.div_(self.world_size)
                 self.w_grad.div_(self.world_size)
+            if part in ("all", "table"):
+                dist.all_reduce(table)
+                table.div_(self.world_size)
 
     def optimizer_step(self, device_hyper=False):
         """Adam on the table and the MLP weights.  device_hyper: learning rate and bias corrections come from
@@ -315,7 +321,7 @@ class FusedTrainer:
             self.model.grid_encoder.embeddings.grad = self.table_grad
             self.model.apply_weight_decay(self.opt.lambda_wd)
         if device_hyper:                                # (step path: the gradient is overwritten next step, no zeroing)
-            eb.adam_step_dev2((self.table, self.table_grad, self.t_m, self.t_v, False),
+            eb.adam_step_dev2((self.table, self._wire if self.wire16 else self.table_grad, self.t_m, self.t_v, False),
                               (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
             return
         step, lr = self.global_step + 1, self.lr()
@@ -380,9 +386,12 @@ class FusedTrainer:
                     ops += [(n, o, "aux") for n, o in tail]
                 ops.append((name, op, "main"))
             return ops
-        ops += [(n, o, "main") for n, o in field]
+        for name, op in field:
+            ops.append((name, op, "main"))
+            if name == "ngp_x_mlp_backward" and self.world_size > 1:        # the 53 KiB of MLP gradients leave early
+                ops.append(("all_reduce", lambda: self.reduce_gradients(part="weights"), "main"))
         if self.world_size > 1:
-            ops.append(("all_reduce", self.reduce_gradients, "main"))
+            ops.append(("all_reduce", lambda: self.reduce_gradients(wire=True, part="table"), "main"))
         ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True), "main"))
         return ops                                  # (this variant prepares the weight image before its MLP forward)
 

@@ -448,3 +448,44 @@ def test_fused_training_is_bitwise_reproducible(lib):
     assert torch.equal(out[0][2], out[1][2])
     assert torch.equal(out[0][1], out[1][1])
     assert torch.equal(out[0][0], out[1][0])
+
+
+def test_bf16_wire_gradient_store_and_adam(lib, orc):
+    """Data-parallel wire format: the overwrite-mode reduction can store the table gradient as bfloat16 (round to
+    nearest even == torch's conversion of the f32 result, bit for bit), and Adam reads it as if it were widened."""
+    rng = np.random.default_rng(21)
+    L, H, B = 16, 16, 20000
+    offsets, scale = orc.grid_offsets(desired_resolution=2048)
+    S, rows = float(np.log2(scale)), int(offsets[-1])
+    x01 = dev(rng.uniform(0, 1, (B, 3)).astype(np.float32))
+    grad = dev(rng.normal(size=(L, B, 2)).astype(np.float32))
+    gb, e = lib.gridencoder_backend, lib.engine_backend
+    cnt = torch.tensor([B, B, 0, 0], dtype=torch.int32, device="cuda")
+    outs, off = [], dev(offsets)
+    for dtype in (torch.float32, torch.bfloat16):
+        ws = torch.zeros(gb.backward_workspace_bytes(B, L, rows), dtype=torch.uint8, device="cuda")
+        out = torch.full((rows, 2), 7.0, dtype=dtype, device="cuda")          # every row must be overwritten
+        gb.grid_backward_binned_prepare(x01, 0.0, off, rows, cnt, B, L, L, S, H, ws, single_segment=True)
+        gb.grid_backward_binned_apply(grad, x01, off, out, cnt, B, B, L, L, S, H, ws, overwrite=True)
+        outs.append(out)
+    g32, g16 = outs
+    assert float(g32.abs().max()) > 0 and float((g32 == 0).float().mean()) > 0.01
+    assert torch.equal(g16.view(torch.int16), g32.to(torch.bfloat16).view(torch.int16))
+    with pytest.raises(RuntimeError, match="overwrite"):
+        gb.grid_backward_binned_apply(grad, x01, off, g16, cnt, B, B, L, L, S, H, ws)
+
+    torch.manual_seed(3)
+    n, nb = rows * 2, 1027
+    hyper = torch.tensor([1e-2, 1 - 0.9, 1 / np.sqrt(1 - 0.999), 0.0], dtype=torch.float32, device="cuda")
+    res = []
+    for g in (g16, g16.float()):
+        p, m, v = torch.randn(n, device="cuda", generator=torch.Generator("cuda").manual_seed(5)).view(rows, 2), \
+            torch.zeros(rows, 2, device="cuda"), torch.zeros(rows, 2, device="cuda")
+        pb, gb_, mb_, vb = torch.ones(nb, device="cuda"), torch.full((nb,), 0.5, device="cuda"), \
+            torch.zeros(nb, device="cuda"), torch.zeros(nb, device="cuda")
+        e.adam_step_dev2((p, g, m, v, False), (pb, gb_, mb_, vb, True), hyper, 0.9, 0.999, 1e-15)
+        assert float(gb_.abs().max()) == 0.0                                   # b's gradient zeroed as asked
+        res.append((p, m, v, pb))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.equal(g16.view(torch.int16), g32.to(torch.bfloat16).view(torch.int16))     # a's gradient untouched
