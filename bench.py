@@ -13,7 +13,10 @@ torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
               are over and the occupancy grid has converged (metric definition):
               setup, not part of W or K.
   roofline  = the dominant kernel of the step, timed live with HIP events around each of its launches
-              inside the timed region; algorithmic bytes per sample from SURVEY.md section 8d.
+              inside the timed region; algorithmic bytes per sample from SURVEY.md section 8d.  On one GPU that
+              launch also applies Adam to the table (fused into its reduce kernel): the optimiser's 24 B per
+              table entry are then part of its algorithmic bytes (`optimizer_bytes_per_launch`; the figure without
+              them is `frac_grid_only`).
   cpu_baseline = the same step restated on the CPU oracle (oracle/ngp_oracle.c kernels + torch CPU MLPs and
               Adam) on a bounded ray sample, all host cores (kind "port": the reference has no CPU path for
               the encoders and its CUDA kernels cannot be built here).
@@ -259,14 +262,24 @@ def main():
         launches, units, ksec = probe
         roof = None
         if launches:
-            ach = units * bytes_per_sample / ksec / 1e9
+            # one GPU: the same launch also runs Adam on the table (inside the reduce kernel): its algorithmic bytes are
+            # the read + write of parameter, exp_avg and exp_avg_sq -- 24 B per table entry, the gradient never
+            # reaches HBM (SURVEY 8d prices a separate optimiser pass at 28 B)
+            fused_adam = fused and getattr(trainer, "fuse_adam", False) and args.roofline_kernel == "ngp_x_grid_backward_binned"
+            opt_bytes = 24 * trainer.table.numel() if fused_adam else 0
+            grid_only = units * bytes_per_sample / ksec / 1e9
+            ach = (units * bytes_per_sample + launches * opt_bytes) / ksec / 1e9
             per_sample = PMC_TRAFFIC_BYTES_PER_SAMPLE.get(args.roofline_kernel)
-            traffic = round(per_sample * units / launches) if per_sample else None
-            roof = {"bound": "hbm", "kernel": args.roofline_kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+            traffic = round(per_sample * units / launches + opt_bytes) if per_sample else None
+            roof = {"bound": "hbm", "kernel": args.roofline_kernel + (" + Adam on the table (fused)" if fused_adam else ""),
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_grid_traffic.csv, scaled by samples)",
+                    "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_grid_traffic.csv, scaled by samples"
+                                    + (", plus the optimiser's 24 B per table entry" if fused_adam else "") + ")",
                     "launches": launches, "timed_every": args.probe_every, "avg_us": round(ksec / launches * 1e6, 2),
-                    "bytes_per_sample": bytes_per_sample, "samples_per_launch": round(units / launches)}
+                    "bytes_per_sample": bytes_per_sample, "samples_per_launch": round(units / launches),
+                    "optimizer_bytes_per_launch": opt_bytes, "achieved_grid_only": round(grid_only, 1),
+                    "frac_grid_only": round(grid_only / HBM_PEAK_GBPS, 4)}
         roof_fwd = None
         if fused and probe_fwd[0]:
             per_launch = samples / max(args.steps, 1)

@@ -184,6 +184,19 @@ def main():
         outp = ren.run(torch.from_numpy(ro), torch.from_numpy(rd), bg_color=None, perturb=False)
     np.savez(os.path.join(args.out, "run_analytic.npz"), rays_o=ro, rays_d=rd, num_steps=np.array([64, 32, 16]),
              image=outp["image"].numpy(), depth=outp["depth"].numpy(), weights_sum=outp["weights_sum"].numpy())
+    # ---------------------------------------------------------------- pose refinement (barf/camera.py)
+    import barf.camera as CAM
+    prng = np.random.default_rng(11)
+    wu = prng.normal(size=(48, 6)).astype(np.float32)
+    wu[:8, :3] *= 1e-4                       # small-angle branch
+    wu[8:16, :3] *= 1e-9
+    wu[16] = 0.0
+    wu[40:, :3] *= 2.0                       # up to a few radians
+    a34 = CAM.lie.se3_to_SE3(torch.from_numpy(prng.normal(size=(48, 6)).astype(np.float32)))
+    with torch.no_grad():
+        SE3 = CAM.lie.se3_to_SE3(torch.from_numpy(wu))
+        comp = CAM.pose.compose([SE3, a34])
+    np.savez(os.path.join(args.out, "pose_lie.npz"), wu=wu, SE3=SE3.numpy(), other=a34.numpy(), composed=comp.numpy())
     print("fixtures written to", args.out)
     for f in sorted(os.listdir(args.out)):
         print("  ", f, os.path.getsize(os.path.join(args.out, f)))

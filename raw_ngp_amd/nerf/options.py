@@ -44,6 +44,10 @@ class Options:
     density_activation: str = "clamped_exp"
     rfield: bool = False
     pose_opt: str = "none"
+    c_lr: float = 1e-3           # pose refinement (main.py:110-113)
+    noise: float = 0.0
+    identity: bool = False
+    scale: float = 1.0
     start_annealing: float = 0.0
     end_annealing: float = 0.33
     beta: float = 2.0

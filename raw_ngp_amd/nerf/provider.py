@@ -55,7 +55,9 @@ class BlenderDataset:
         from PIL import Image
         self.opt, self.device, self.training = opt, torch.device(device), ttype in ("train", "all", "trainval")
         self.root_path, self.downscale = root, downscale
-        self.scale = getattr(opt, "scale", 0.33) if scale is None else scale
+        self.scale = getattr(opt, "scale", 1.0) if scale is None else scale
+        if self.scale == -1:                    # "--data_format nerf cannot auto-choose --scale" (provider.py:106-108)
+            self.scale = 1.0
         self.offset = getattr(opt, "offset", (0, 0, 0)) if offset is None else offset
         if not os.path.exists(os.path.join(root, "transforms_train.json")):
             raise NotImplementedError(f"[BlenderDataset] cannot find transforms_train.json under {root}")
@@ -118,16 +120,30 @@ class BlenderDataset:
     def __len__(self):
         return self.poses.shape[0]
 
-    def sample_rays(self, num_rays, generator=None):
-        """random_image_batch collate: every ray picks its own (view, pixel)."""
+    def sample_rays(self, num_rays, generator=None, pose_fn=None):
+        """random_image_batch collate: every ray picks its own (view, pixel).  pose_fn(poses, index): the pose
+        optimiser's hook (provider.py:298-300); `self.ldirs` [V,3], when set, yields per-ray light directions
+        (colmap_provider.py:619-620)."""
         V = self.poses.shape[0]
         index = torch.randint(0, V, size=(num_rays,), device=self.device, generator=generator)
-        rays = get_rays(self.poses[index], self.intrinsics, self.H, self.W, num_rays, generator=generator)
+        poses = self.poses[index]
+        if pose_fn is not None:
+            poses = pose_fn(poses, index)
+        ldirs = getattr(self, "ldirs", None)
+        rays = get_rays(poses, self.intrinsics, self.H, self.W, num_rays, generator=generator,
+                        ldirs=ldirs[index] if ldirs is not None else None)
         images = self.images[index, rays["j"], rays["i"]].float() / 255
-        return {"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "images": images, "index": index,
-                "H": self.H, "W": self.W}
+        out = {"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "images": images, "index": index,
+               "H": self.H, "W": self.W}
+        if ldirs is not None:
+            out["rays_ldir"] = rays["rays_ldir"]
+        return out
 
     def view(self, v):
+        ldirs = getattr(self, "ldirs", None)
         rays = get_rays(self.poses[v:v + 1], self.intrinsics, self.H, self.W, -1)
-        return {"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "images": self.images[v].float() / 255,
-                "H": self.H, "W": self.W}
+        out = {"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "images": self.images[v].float() / 255,
+               "H": self.H, "W": self.W}
+        if ldirs is not None:           # one light per image: the inference march repeats it per sample
+            out["rays_ldir"] = ldirs[v:v + 1]
+        return out

@@ -247,7 +247,9 @@ class NeRFRenderer(nn.Module):
 
         if self.training:
             xyzs, dirs, ts, rays, ldirs = self._march_train(rays_o, rays_d, rays_ldir, nears, fars, perturb)
-            dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)
+            # (the floor only matters for the arena's unused rows, which may hold zeros: 0/0 there would reach the
+            # weight gradients of a torch MLP as NaN * 0)
+            dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True).clamp_min(1e-30)
             with amp:
                 outputs = self(xyzs, dirs, ldirs, shading=shading)
             sigmas, rgbs = outputs["sigma"], outputs["color"]

@@ -6,6 +6,9 @@ its logging / checkpoint / tensorboard machinery (out of scope):
   density-grid refresh every `update_extra_interval` steps -> random (view, pixel) rays -> render ->
   MSE against rgb*a + bg*(1-a) -> backward -> optional TV / weight-decay gradients -> Adam(eps 1e-15)
   -> lr = lr0 * 0.1^(step/iters).
+With `opt.pose_opt != "none"` (train_utils.py:397, :488-489, :891-909): one se(3) correction per training camera
+(nerf/pose.py) refines the poses the rays are cast from, the level-window annealing value follows step / iters, and
+the pose optimiser steps beside the field's while annealing < end_annealing.
 Data parallelism (one process per GPU, ray-batch sharding, gradient all-reduce over RCCL) lives in
 raw_ngp_amd/parallel.py and is applied here when a process group is initialised.
 """
@@ -32,6 +35,11 @@ class Trainer:
         self.reducer = parallel.GradReducer(self.model) if self.world_size > 1 else None
         if self.world_size > 1:
             parallel.broadcast_module(self.model)
+        self.pose_optimizer = None
+        if opt.pose_opt != "none":
+            from .pose import CameraOptimizer
+            self.pose_optimizer = CameraOptimizer(len(dataset), device, opt, seed=seed)
+        self.annealing = 0.0
         self.last_loss = None
         self.last_num_points = 0
 
@@ -49,12 +57,22 @@ class Trainer:
             if self.world_size > 1:
                 torch.manual_seed(1234567 + self.global_step)      # identical jitter on every rank
             model.update_extra_state()
-        data = self.data.sample_rays(opt.num_rays, self.ray_gen)
+        refine = self.pose_optimizer is not None
+        if refine:
+            self.annealing = min(max(self.global_step / opt.iters, 0.0), 1.0)
+            model.update_annealing(self.annealing)
+            self.pose_optimizer.update_annealing(self.annealing)
+            data = self.data.sample_rays(opt.num_rays, self.ray_gen, pose_fn=self.pose_optimizer)
+        else:
+            data = self.data.sample_rays(opt.num_rays, self.ray_gen)
+        pose_step = refine and self.annealing < opt.end_annealing
         images = data["images"]
         bg = self.bg_color(images.shape[0])
         gt = images[..., :3] * images[..., 3:] + bg * (1 - images[..., 3:]) if images.shape[-1] == 4 else images
 
         self.optimizer.zero_grad(set_to_none=True)
+        if pose_step:
+            self.pose_optimizer.optimizer.zero_grad(set_to_none=True)
         out = model.render(data["rays_o"], data["rays_d"], rays_ldir=data.get("rays_ldir"), bg_color=bg, perturb=True)
         loss = self.criterion(out["image"], gt).mean(-1).mean()
         if "proposal_loss" in out and opt.lambda_proposal > 0:
@@ -73,8 +91,17 @@ class Trainer:
         if opt.lambda_wd > 0:
             model.apply_weight_decay(opt.lambda_wd)
         self.scaler.step(self.optimizer)
+        if pose_step:
+            if self.world_size > 1:
+                for p in self.pose_optimizer.parameters():
+                    if p.grad is not None:
+                        torch.distributed.all_reduce(p.grad)
+                        p.grad.div_(self.world_size)
+            self.scaler.step(self.pose_optimizer.optimizer)
         self.scaler.update()
         self.scheduler.step()
+        if pose_step:
+            self.pose_optimizer.lr_scheduler.step()
         self.global_step += 1
         self.last_loss = loss.detach()
         self.last_num_points = out.get("num_points", 0)
@@ -101,7 +128,9 @@ class Trainer:
             data = dataset.view(v)
             preds = []
             for s in range(0, data["rays_o"].shape[0], chunk):
-                out = self.model.render(data["rays_o"][s:s + chunk], data["rays_d"][s:s + chunk], bg_color=0,
+                ld = data.get("rays_ldir")
+                out = self.model.render(data["rays_o"][s:s + chunk], data["rays_d"][s:s + chunk],
+                                        rays_ldir=ld, bg_color=0,
                                         perturb=False)
                 preds.append(out["image"])
             pred = torch.cat(preds, 0).view(data["H"], data["W"], 3)

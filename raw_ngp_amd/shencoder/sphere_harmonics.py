@@ -57,7 +57,8 @@ class SHEncoder(nn.Module):
     def forward(self, inputs, size=1):
         """inputs [..., 3] in [-size, size]; normalised to unit length before encoding."""
         inputs = inputs / size
-        inputs = inputs / torch.norm(inputs, dim=-1, keepdim=True)
+        # (floor: unused rows of a fixed-capacity sample arena hold zero vectors; valid directions are unaffected)
+        inputs = inputs / torch.norm(inputs, dim=-1, keepdim=True).clamp_min(1e-30)
         lead = list(inputs.shape[:-1])
         flat = inputs.reshape(-1, self.input_dim)
         out = sh_encode(flat, self.degree, flat.requires_grad)

@@ -1,0 +1,69 @@
+"""SURVEY 8f row 3 end to end: light-direction conditioning + se(3) pose refinement through the native kernels.
+
+The per-kernel parity of the pieces this exercises is in test_gpu_parity.py (grid Jacobian dy_dx and input backward,
+SH backward, segmented ray-gradient sum, march with ldirs); this test checks the glue: gradients reach the se(3)
+parameters with the right sign and scale -- perturbed cameras move back towards the truth while the field trains."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(pose_opt, rfield, iters, arena=0, views=24, noise=0.03):
+    from raw_ngp_amd.nerf import pose as P
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    from raw_ngp_amd.nerf.trainer import Trainer
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=2048, iters=iters, rfield=rfield, pose_opt=pose_opt, noise=noise,
+                  arena_capacity=arena)
+    data = SyntheticDataset(opt, dev, "train", n_views=views, H=128, W=128)
+    if rfield:
+        data.ldirs = torch.from_numpy(P.synthetic_light_dirs(views)).to(dev)
+    return P, data, Trainer(opt, NeRFNetwork(opt), data, dev)
+
+
+def test_pose_refinement_pulls_perturbed_cameras_back():
+    P, data, tr = _setup("barf", True, iters=1500)
+    co = tr.pose_optimizer
+    rot0, trans0 = P.pose_error(co.get_refined_poses(data.poses), data.poses)
+    assert rot0 > 1.5
+    first = None
+    for it in range(1500):
+        loss = tr.train_step()
+        if it == 20:
+            first = float(loss)
+    rot1, trans1 = P.pose_error(co.get_refined_poses(data.poses), data.poses)
+    assert torch.isfinite(co.se3_refine.weight).all()
+    assert float(tr.last_loss) < 0.2 * first
+    assert rot1 < 0.6 * rot0, (rot0, rot1)
+    # (500 pose steps at this size mostly fix the rotations; camera centres follow later: tools/pose_refine.py
+    #  --iters 6000 takes them from 0.045 to 0.025)
+    assert trans1 < 1.5 * trans0, (trans0, trans1)
+    # the pose optimiser stops once the annealing window is over (train_utils.py:891-909)
+    assert tr.annealing >= tr.opt.end_annealing
+    frozen = co.se3_refine.weight.detach().clone()
+    tr.train_step()
+    assert torch.equal(frozen, co.se3_refine.weight.detach())
+
+
+@pytest.mark.parametrize("pose_opt,rfield,arena", [("baangp", False, 0), ("barf", True, 2048 * 160), ("none", True, 0)])
+def test_config4_variants_train_without_nans(pose_opt, rfield, arena):
+    """Level windows (BAA-NGP), the fixed-capacity sample arena (whose unused rows hold zero directions) and the
+    light-conditioned view MLP each take a few steps with finite parameters and a falling loss."""
+    P, data, tr = _setup(pose_opt, rfield, iters=200, arena=arena, views=8)
+    losses = [float(tr.train_step()) for _ in range(60)]
+    for name, p in tr.model.named_parameters():
+        assert torch.isfinite(p).all(), name
+    assert np.isfinite(losses).all() and np.mean(losses[-10:]) < np.mean(losses[:10])
+    if rfield:
+        assert tr.model.view_mlp.net[0].weight.shape == (80, 47)
+        val = data.view(0)
+        tr.model.eval()
+        with torch.no_grad():
+            out = tr.model.render(val["rays_o"][:4096], val["rays_d"][:4096], rays_ldir=val["rays_ldir"], bg_color=0,
+                                  perturb=False)
+        assert torch.isfinite(out["image"]).all()

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Config-4-style run of the hot path (SURVEY 8d "Config 4", 8f row 3) on the procedural scene: light-direction
+conditioning (rfield: second SH call, 47 -> 80 -> 80 -> 3 view MLP), se(3) pose refinement from perturbed cameras with
+BARF / BAA-NGP level windows.  Rays carry gradients, so the encoders' input Jacobians (dy_dx), the SH backward and the
+marcher's segmented ray-gradient sum are all live.  Prints the pose error before / after and the step rate.
+
+    python tools/pose_refine.py --iters 3000 --noise 0.03
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raw_ngp_amd.nerf.options import Options  # noqa: E402
+from raw_ngp_amd.nerf.network import NeRFNetwork  # noqa: E402
+from raw_ngp_amd.nerf.scene import SyntheticDataset  # noqa: E402
+from raw_ngp_amd.nerf.trainer import Trainer  # noqa: E402
+from raw_ngp_amd.nerf import pose as P  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=3000)
+    ap.add_argument("--noise", type=float, default=0.03)
+    ap.add_argument("--views", type=int, default=40)
+    ap.add_argument("--res", type=int, default=200)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--pose-opt", default="barf", choices=["barf", "baangp", "none"])
+    ap.add_argument("--no-rfield", action="store_true")
+    ap.add_argument("--c-lr", type=float, default=1e-3)
+    ap.add_argument("--log-every", type=int, default=500)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--arena", type=int, default=0, help="sample-arena rows (0 = the reference's two-call march)")
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    torch.manual_seed(args.seed)
+    opt = Options(bound=1.0, num_rays=args.rays, iters=args.iters, rfield=not args.no_rfield, pose_opt=args.pose_opt,
+                  noise=args.noise, c_lr=args.c_lr, arena_capacity=args.arena)
+    data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
+    if opt.rfield:
+        data.ldirs = torch.from_numpy(P.synthetic_light_dirs(args.views)).to(dev)
+    model = NeRFNetwork(opt)
+    trainer = Trainer(opt, model, data, dev, seed=args.seed)
+    co = trainer.pose_optimizer
+    report = {"config": vars(args)}
+    if co is not None:
+        report["pose_error_start"] = P.pose_error(co.get_refined_poses(data.poses), data.poses)
+    t0, last = time.time(), 0
+    for it in range(args.iters):
+        trainer.train_step()
+        if args.log_every and (it + 1) % args.log_every == 0:
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            err = P.pose_error(co.get_refined_poses(data.poses), data.poses) if co is not None else None
+            print(f"[{it + 1}] loss {float(trainer.last_loss):.5f} samples {trainer.last_num_points} "
+                  f"{(it + 1 - last) / dt:.0f} steps/s pose error (deg, dist) {err}", flush=True)
+            t0, last = time.time(), it + 1
+    # steady-state step rate
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(50):
+        trainer.train_step()
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) / 50 * 1e3
+    report.update(ms_per_step=round(ms, 3), rays_per_s=round(args.rays / ms * 1e3),
+                  samples_per_step=int(trainer.last_num_points))
+    if co is not None:
+        report["pose_error_end"] = P.pose_error(co.get_refined_poses(data.poses), data.poses)
+    print(json.dumps(report))
+
+
+if __name__ == "__main__":
+    main()
