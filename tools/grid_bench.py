@@ -62,6 +62,30 @@ def main():
     torch.cuda.synchronize()
     print(f"{B} samples, {(time.perf_counter() - t1) / args.iters * 1e6:.1f} us per forward + binned backward")
 
+    # the encoder's forward alone, three ways (HIP events around each launch)
+    x01c = ((xyz + 1.0) * 0.5).contiguous()
+    variants = {
+        "slab + count (engine)": lambda: eb.grid_encode_forward_slab(xyz, 1.0, table, offsets, enc, x01, cnt, B, B, L, L, S,
+                                                                      H, binned_workspace=ws),
+        "slab": lambda: eb.grid_encode_forward_slab(xyz, 1.0, table, offsets, enc, x01, cnt, B, B, L, L, S, H),
+        "ngp_grid_encode_forward (reference API)": lambda: gb.grid_encode_forward(x01c, table, offsets, enc, B, 3, 2, L, L,
+                                                                                    S, H, None, 0, False, 0),
+    }
+    for name, fn in variants.items():
+        times = []
+        for i in range(args.iters + 3):
+            if "count" in name:
+                gb.grid_backward_binned_prepare(None, 0.0, offsets, rows, cnt, B, L, L, S, H, ws, merge_max_res=414, stage=1)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            if i >= 3:
+                times.append(a.elapsed_time(b) * 1e3)
+        us = float(np.median(times))
+        print(f"forward {name}: {us:.1f} us, {B * 1164 / us / 1e6:.2f} TB/s algorithmic ({B * 1164 / us / 1e6 / 8:.3f} of 8 TB/s)")
+
 
 if __name__ == "__main__":
     main()
