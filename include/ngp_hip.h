@@ -271,9 +271,12 @@ int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float *dirs, con
 int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
                         float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
                         const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,
-                        const float *adam_hyper, float beta1, float beta2, float eps, ngp_stream_t stream);
+                        const float *adam_hyper, float beta1, float beta2, float eps, void *adam_image,
+                        ngp_stream_t stream);
 /* adam_param != NULL: dw1..dw6 are views of the flat buffer adam_grad (adam_n floats) and every element is also pushed
- * through ngp_x_adam_step_dev's update of adam_param / exp_avg / exp_avg_sq as it comes out of the reduction. */
+ * through ngp_x_adam_step_dev's update of adam_param / exp_avg / exp_avg_sq as it comes out of the reduction.
+ * adam_image != NULL (an image ngp_x_mlp_prepare has filled once): each updated weight is also written, as f16, to its
+ * two places in the operand image, so the next forward needs no prepare pass. */
 
 /* ------------------------------------------------------------------------------------
  * Kernels of the fused training step (csrc/engine_kernels.hip; host side raw_ngp_amd/nerf/engine.py).

@@ -51,7 +51,7 @@ _SIGNATURES = {
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
-    "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f, _f, _f],
+    "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f, _f, _f, _p],
     "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
     "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
     "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
@@ -506,10 +506,11 @@ class _MlpBackend:
               image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"), *grads, ws.data_ptr(), nbytes)
 
     @staticmethod
-    def reduce_dw(M, loss_scale, dws, workspace, adam=None):
+    def reduce_dw(M, loss_scale, dws, workspace, adam=None, image=None):
         """Second half of backward(..., dws=None): weight gradients from the partial sums left in `workspace`.
         adam = (param, grad, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps) with dws views of the flat `grad`: also
-        apply Adam to the flat weights, element by element."""
+        apply Adam to the flat weights, element by element; image (a prepared operand image): keep it in step with the
+        updated weights."""
         extra = [None, None, None, None, 0, None, 0.0, 0.0, 0.0]
         if adam is not None:
             p_, g_, m_, v_, hyper, b1, b2, eps = adam
@@ -517,7 +518,8 @@ class _MlpBackend:
                      _ptr(v_, "f", "adam_exp_avg_sq"), g_.numel(), _ptr(hyper, "f", "adam_hyper"), float(b1), float(b2),
                      float(eps)]
         _call("ngp_x_mlp_reduce_dw", workspace, M, float(loss_scale),
-              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], workspace.data_ptr(), workspace.numel(), *extra)
+              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], workspace.data_ptr(), workspace.numel(), *extra,
+              image.data_ptr() if image is not None else None)
 
 
 class _EngineBackend:

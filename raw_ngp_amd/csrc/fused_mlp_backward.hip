@@ -574,6 +574,7 @@ struct MlpAdam {
     float *exp_avg, *exp_avg_sq;
     const float *hyper;   // {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)}
     float b1, b2, eps;
+    _Float16 *image;      // optional: the f16 operand image (ngp_x_mlp_prepare) is patched with the new weight
 };
 
 __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restrict__ part_view,
@@ -609,21 +610,38 @@ __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restr
     const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
     const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;
     float *dst = nullptr;   // padding elements of the tiles have no weight behind them
+    uint32_t pos_f = 0, pos_t = 0;   // the weight's two places in the f16 operand image (as-is and transposed block)
     if (b < 2) {   // first-layer tiles: rb = b
         if (view) {
-            if (j >= 1) dst = &dw4[(32 * b + o) * 31 + j - 1];
+            if (j >= 1) {
+                dst = &dw4[(32 * b + o) * 31 + j - 1];
+                pos_f = frag_pos(F_W4 + b * 2, o, j);
+                pos_t = frag_pos(T_W4 + b * 2, j, o);
+            }
         } else {
             dst = &dw1[(32 * b + o) * 32 + j];
+            pos_f = frag_pos(F_W1 + b * 2, o, j);
+            pos_t = frag_pos(T_W1 + b * 2, j, o);
         }
     } else if (b < 6) {   // 64 x 64 tiles: rb = (b-2) >> 1, cb = (b-2) & 1
         const uint32_t rb = (b - 2) >> 1, cb = (b - 2) & 1;
         dst = &(view ? dw5 : dw2)[(32 * rb + o) * 64 + 32 * cb + j];
+        pos_f = frag_pos((view ? F_W5 : F_W2) + rb * 4 + cb * 2, o, j);
+        pos_t = frag_pos((view ? T_W5 : T_W2) + cb * 4 + rb * 2, j, o);
     } else {   // last-layer tiles: cb = b - 6
         const uint32_t cb = b - 6;
         if (view) {
-            if (o < 3) dst = &dw6[o * 64 + 32 * cb + j];
+            if (o < 3) {
+                dst = &dw6[o * 64 + 32 * cb + j];
+                pos_f = frag_pos(F_W6 + cb * 2, o, j);
+                pos_t = frag_pos(T_W6 + cb, j, o);
+            }
         } else {
-            if (o < 16) dst = &dw3[o * 64 + 32 * cb + j];
+            if (o < 16) {
+                dst = &dw3[o * 64 + 32 * cb + j];
+                pos_f = frag_pos(F_W3 + cb * 2, o, j);
+                pos_t = frag_pos(T_W3 + cb, j, o);
+            }
         }
     }
     if (!dst) return;
@@ -635,7 +653,12 @@ __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restr
         const float vi = adam.b2 * adam.exp_avg_sq[k] + (1.0f - adam.b2) * s * s;
         adam.exp_avg[k] = mi;
         adam.exp_avg_sq[k] = vi;
-        adam.param[k] -= step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + adam.eps));
+        const float p = adam.param[k] - step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + adam.eps));
+        adam.param[k] = p;
+        if (adam.image) {   // next step's operand image without a prepare pass (its padding entries never change)
+            adam.image[pos_f] = (_Float16)p;
+            adam.image[pos_t] = (_Float16)p;
+        }
     }
 }
 
@@ -691,9 +714,10 @@ extern "C" int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, flo
                                    float *dw5, float *dw6, const void *workspace, size_t workspace_bytes,
                                    float *adam_param, const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq,
                                    uint32_t adam_n, const float *adam_hyper, float beta1, float beta2, float eps,
-                                   ngp_stream_t stream)
+                                   void *adam_image, ngp_stream_t stream)
 {
     NGP_REQUIRE(dw1 && dw2 && dw3 && dw4 && dw5 && dw6 && workspace, "mlp_reduce_dw: null tensor");
+    NGP_REQUIRE(!adam_image || adam_param, "mlp_reduce_dw: the operand image is only patched together with Adam");
     if (adam_param) {
         NGP_REQUIRE(adam_grad && adam_exp_avg && adam_exp_avg_sq && adam_hyper, "mlp_reduce_dw: incomplete Adam state");
         for (const float *d : {dw1, dw2, dw3, dw4, dw5, dw6})
@@ -707,7 +731,8 @@ extern "C" int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, flo
     const float *part_grid = part_view + (size_t)256 * kAccFloats;
     mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, as_stream(stream)>>>(
         part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6,
-        MlpAdam{adam_param, adam_grad, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps});
+        MlpAdam{adam_param, adam_grad, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps,
+                reinterpret_cast<_Float16 *>(adam_image)});
     NGP_CHECK_LAUNCH("mlp_reduce_dw");
     return NGP_OK;
 }

@@ -129,4 +129,12 @@ __device__ __forceinline__ float frag_elem(uint32_t f, uint32_t r, uint32_t h, u
     return W.w1[(32 * kb + kperm(s, h, t)) * 32 + r];
 }
 
+// inverse of the map above: where element M[r][k] (k < 32) of the 32 x 32 block whose first fragment is `f` lives in
+// the image (index in halfs); the block's second k-step, when it has one, is fragment f + 1
+__host__ __device__ constexpr uint32_t frag_pos(uint32_t f, uint32_t r, uint32_t k)
+{
+    const uint32_t s = k >> 4, h = (k >> 2) & 1u, t = ((k >> 3) & 1u) * 4u + (k & 3u);
+    return ((f + s) * 64u + r + 32u * h) * 8u + t;
+}
+
 }  // namespace ngp

@@ -375,12 +375,12 @@ class FusedTrainer:
         field.insert(1, begin)                                                      # right after the encoder's forward
         prepare = ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image))
         if split:
-            # weight gradients out of the partial sums and, element by element, Adam on the flat MLP weights; then the
-            # f16 weight image for the next step
+            # weight gradients out of the partial sums and, element by element, Adam on the flat MLP weights and the new
+            # value's two entries in the f16 operand image (so the next step needs no prepare pass)
             tail = [("ngp_x_mlp_reduce_dw", lambda: mb.reduce_dw(
                         self.cap, opt.loss_scale, self.dws, self.ws_mlp,
-                        adam=(self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps))),
-                    prepare]
+                        adam=(self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps),
+                        image=self.mlp_image))]
             for name, op in field:
                 if name == "ngp_x_grid_backward_binned_apply":      # right after the MLP backward, beside the apply
                     ops += [(n, o, "aux") for n, o in tail]

@@ -489,3 +489,26 @@ def test_bf16_wire_gradient_store_and_adam(lib, orc):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert torch.equal(g16.view(torch.int16), g32.to(torch.bfloat16).view(torch.int16))     # a's gradient untouched
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_operand_image_follows_the_weights_without_a_prepare_pass(lib, graph):
+    """The fused step's weight tail (dW reduction + Adam) also rewrites each weight's two entries of the f16 MFMA operand
+    image; after any number of steps the image must be what ngp_x_mlp_prepare builds from the current weights."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True, capture_graph=graph)
+    data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
+    eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
+    assert eng.fuse_adam
+    w0 = eng.w_flat.clone()
+    for _ in range(7):          # crosses no grid refresh after the first step, so no prepare call in between
+        eng.train_step()
+    torch.cuda.synchronize()
+    assert float((eng.w_flat - w0).abs().max()) > 1e-3
+    fresh = torch.zeros_like(eng.mlp_image)
+    lib.mlp_backend.prepare(eng.weights, fresh)
+    assert torch.equal(fresh, eng.mlp_image)
