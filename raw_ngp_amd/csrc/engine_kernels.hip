@@ -420,14 +420,19 @@ __global__ __launch_bounds__(1024) void step_begin_kernel(uint32_t *step_counter
                                                          long long *samples_seen, const int32_t *sample_counter,
                                                          bool scan, uint32_t L, WsLayout w, bool single_segment)
 {
-    if (scan) bin_scan_block(L, w, single_segment);
-    if (threadIdx.x != 0) return;
+    // the three scalars cost a double-precision pow each (~1 us on a lone lane): three different waves take one each
+    // while the others already wait on the scan's first loads
     const uint32_t done = step_counter[0];
-    const double t = (double)done + 1.0;
-    const double frac = fmin((double)done / decay_steps, 1.0);
-    hyper[0] = (float)(lr0 * pow(0.1, frac));
-    hyper[1] = (float)(1.0 - pow(b1, t));
-    hyper[2] = (float)(1.0 / sqrt(1.0 - pow(b2, t)));
+    const uint32_t nw = blockDim.x >> 6, wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) {
+        const double t = (double)done + 1.0;
+        if (wid == nw - 1) hyper[0] = (float)(lr0 * pow(0.1, fmin((double)done / decay_steps, 1.0)));
+        if (wid == (nw >= 2 ? nw - 2 : 0)) hyper[1] = (float)(1.0 - pow(b1, t));
+        if (wid == (nw >= 3 ? nw - 3 : 0)) hyper[2] = (float)(1.0 / sqrt(1.0 - pow(b2, t)));
+    }
+    if (scan) bin_scan_block(L, w, single_segment);
+    __syncthreads();   // every wave has read the step counter
+    if (threadIdx.x != 0) return;
     step_counter[0] = done + 1u;
     if (loss_out) loss_out[0] = 0.0f;
     if (samples_seen && sample_counter) samples_seen[0] += (long long)sample_counter[0];
