@@ -285,14 +285,15 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     if ((threadIdx.x & 63u) == 0 && __float_as_uint(gmax) > __builtin_nontemporal_load(&w.chunk_base[kMaxLevels + 1]))
         atomicMax(&w.chunk_base[kMaxLevels + 1], __float_as_uint(gmax));
     __syncthreads();
-    // consecutive lanes -> consecutive records of one chunk (until the chunk changes)
-    for (uint32_t j = threadIdx.x; j < total; j += kFillBlock) {
-        const StageRec r = stage[j];
-        const uint32_t bin = r.key >> kChunkShift;
-        uint32_t *dst = w.records + (size_t)(gbase[bin] + (j - lbase[bin])) * 3;
-        dst[0] = r.key & (kChunkRows - 1u);
-        dst[1] = r.vx;
-        dst[2] = r.vy;
+    // consecutive lanes -> consecutive WORDS of the record stream of one chunk (until the chunk changes): every store
+    // instruction covers 256 contiguous bytes instead of 64 words 12 bytes apart
+    const uint32_t *stage_u = reinterpret_cast<const uint32_t *>(stage);
+    for (uint32_t q = threadIdx.x; q < total * 3u; q += kFillBlock) {
+        const uint32_t j = __umulhi(q, 0xAAAAAAABu) >> 1, comp = q - j * 3u;   // q / 3
+        const uint32_t key = stage_u[j * 3u];
+        const uint32_t bin = key >> kChunkShift;
+        const uint32_t val = comp == 0u ? (key & (kChunkRows - 1u)) : stage_u[q];
+        w.records[(size_t)(gbase[bin] + (j - lbase[bin])) * 3 + comp] = val;
     }
 }
 
