@@ -174,12 +174,16 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--grad-wire", default="bf16", choices=["f32", "bf16"],
                     help="data parallel: wire format of the table-gradient all-reduce")
+    ap.add_argument("--dp-rehearsal", action="store_true",
+                    help="one GPU: run the data-parallel step (separate Adam, RCCL collectives on a one-rank group)")
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
     ap.add_argument("--autograd", action="store_true", help="per-op autograd path (Trainer) instead of the fused step")
     args = ap.parse_args()
     if args.burnin < 0:
         args.burnin = max((args.psnr_iters or 5000) - args.warmup - args.steps, 300)
 
+    if args.dp_rehearsal:
+        os.environ["NGP_DP_REHEARSAL"] = "1"
     rank, world, local = parallel.init_from_env("cuda")
     assert world == max(args.gpus, 1) or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local)
@@ -190,7 +194,8 @@ def main():
     opt = Options(bound=1.0, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena,
                   fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
-                  aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam)
+                  aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
+                  dp_rehearsal=args.dp_rehearsal)
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
     fused = not (args.autograd or args.torch_mlp)
@@ -303,7 +308,7 @@ def main():
                                    + ("fp32 nn.Linear MLPs" if args.torch_mlp else "fused tiny-MLP (configs[2])"),
                        "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
                        "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
-                       "parallelism": f"dp{world}", "grad_wire": args.grad_wire if world > 1 else None, "replicas_in_sync": in_sync, "step": "fused" if fused else "autograd",
+                       "parallelism": f"dp{world}", "grad_wire": args.grad_wire if (world > 1 or args.dp_rehearsal) else None, "replicas_in_sync": in_sync, "step": "fused" if fused else "autograd",
                        "graph": bool(fused and trainer.use_graph), "prefetch": bool(fused and trainer.prefetch),
                        "device_sampler": bool(fused and trainer.device_sampler),
                        "host_enqueue_ms_per_step": round(host / max(args.steps, 1) * 1e3, 4),

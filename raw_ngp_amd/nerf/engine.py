@@ -54,6 +54,8 @@ class FusedTrainer:
         opt.fused_mlp = True
         assert model._fused(), "fused step needs the default field configuration"
         self.rank, self.world_size = parallel.rank(), parallel.world_size()
+        # data-parallel step (separate Adam pass, gradient collectives); `dp_rehearsal` runs it on one rank as well
+        self.dp = self.world_size > 1 or (bool(getattr(opt, "dp_rehearsal", False)) and parallel.is_dist())
         self.N = N = opt.num_rays
         # sample arena: ~145 samples/ray are needed while the occupancy grid is still full at bound 1; rays longer with the bound
         self.cap = cap = int(capacity or max(opt.arena_capacity, N * 160 * int(math.ceil(model.real_bound))))
@@ -117,7 +119,7 @@ class FusedTrainer:
         step01 = (2 * math.sqrt(3) / opt.max_steps) / (2 * model.bound)
         self.merge_max_res = int(min(1024, max(16, 0.7 / step01)))
         # Adam on the hash table fused into the table-gradient reduction: one rank, nothing else touching the gradient
-        self.fuse_adam = bool(getattr(opt, "fuse_adam", True)) and self.world_size == 1 and opt.lambda_tv == 0 \
+        self.fuse_adam = bool(getattr(opt, "fuse_adam", True)) and not self.dp and opt.lambda_tv == 0 \
             and opt.lambda_wd == 0
         self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
         self._refresh_graph = None
@@ -125,8 +127,12 @@ class FusedTrainer:
         # averages it in place, Adam reads it -- no conversion passes, half the bytes on xGMI
         self.wire16 = getattr(opt, "grad_wire", "f32") == "bf16" and not self.fuse_adam \
             and opt.lambda_tv == 0 and opt.lambda_wd == 0
-        self._wire = torch.zeros(self.table_grad.shape, dtype=torch.bfloat16, device=dev) if self.wire16 else None
-        self._pending = None
+        self._wire = self._wire_flat = self._wire_w = None
+        if self.wire16:     # table gradient, then the MLP gradients (converted by two tiny copies): ONE collective
+            n_t = self.table_grad.numel()
+            self._wire_flat = torch.zeros(n_t + self.w_grad.numel(), dtype=torch.bfloat16, device=dev)
+            self._wire = self._wire_flat[:n_t].view(self.table_grad.shape)
+            self._wire_w = self._wire_flat[n_t:]
         self._main_symbols = {"ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
                               "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
                               "ngp_x_composite_mse_backward", "ngp_x_adam_step_dev2", "ngp_x_adam_step_dev",
@@ -283,33 +289,35 @@ class FusedTrainer:
     def mean_density(self):
         return float(self.dg_stats[1]) if self.native_refresh else float(self.model.mean_density)   # host read
 
-    def reduce_gradients(self, wire=False, part="all"):
+    def reduce_gradients(self, wire=False):
         """Ray-batch data parallelism: average the table and MLP gradients over the ranks (RCCL over xGMI).
-        The table gradient is reduced in place as one collective (46.5 MiB, or 23 MiB in bfloat16); AVG folds the
-        division into it.  wire: the step path's gradient buffer (bfloat16 when grad_wire == "bf16").
-        part "weights" only starts the small collective (the step path issues it right after the MLP backward, so it
-        travels while the table gradient is still being binned), "table" runs the big one and waits for both."""
-        if self.world_size == 1:
+        The table gradient is reduced in place (46.5 MiB, or 23 MiB in bfloat16) and the 53 KiB of MLP gradients ride in
+        the same launch (f32: one ncclGroup; bf16: appended to the wire buffer); AVG folds the division into it.
+        wire: the step path's gradient buffer (bfloat16 when grad_wire == "bf16")."""
+        if not self.dp:
             return
         dist = torch.distributed
         # grad_wire "bf16": the table gradient already IS bfloat16 (the sum over ranks is formed in bf16, ~3 significant
         # digits -- Adam normalises the magnitude anyway)
-        table = self._wire if wire and self.wire16 else self.table_grad
+        if wire and self.wire16:
+            # one bfloat16 buffer holds both gradients (the step path packs / unpacks the MLP part around this call)
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(self._wire_flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self._wire_flat)
+                self._wire_flat.div_(self.world_size)
+            return
         if dist.get_backend() == "nccl":
-            if part in ("all", "weights"):
-                self._pending = dist.all_reduce(self.w_grad, op=dist.ReduceOp.AVG, async_op=True)
-            if part in ("all", "table"):
-                big = dist.all_reduce(table, op=dist.ReduceOp.AVG, async_op=True)
-                big.wait()
-                self._pending.wait()
-                self._pending = None
+            # blocking collectives (async_op=False) are enqueued on the CURRENT stream by ProcessGroupNCCL: no hop to its
+            # internal stream and back (every such event wait costs 15-20 us here); both tensors in one ncclGroup
+            with dist._coalescing_manager(device=self.device):
+                dist.all_reduce(self.table_grad, op=dist.ReduceOp.AVG)
+                dist.all_reduce(self.w_grad, op=dist.ReduceOp.AVG)
         else:                                       # gloo (rehearsal): no AVG
-            if part in ("all", "weights"):
-                dist.all_reduce(self.w_grad)
-                self.w_grad.div_(self.world_size)
-            if part in ("all", "table"):
-                dist.all_reduce(table)
-                table.div_(self.world_size)
+            dist.all_reduce(self.w_grad)
+            self.w_grad.div_(self.world_size)
+            dist.all_reduce(self.table_grad)
+            self.table_grad.div_(self.world_size)
 
     def optimizer_step(self, device_hyper=False):
         """Adam on the table and the MLP weights.  device_hyper: learning rate and bias corrections come from
@@ -386,12 +394,13 @@ class FusedTrainer:
                     ops += [(n, o, "aux") for n, o in tail]
                 ops.append((name, op, "main"))
             return ops
-        for name, op in field:
-            ops.append((name, op, "main"))
-            if name == "ngp_x_mlp_backward" and self.world_size > 1:        # the 53 KiB of MLP gradients leave early
-                ops.append(("all_reduce", lambda: self.reduce_gradients(part="weights"), "main"))
-        if self.world_size > 1:
-            ops.append(("all_reduce", lambda: self.reduce_gradients(wire=True, part="table"), "main"))
+        ops += [(n, o, "main") for n, o in field]
+        if self.dp:
+            if self.wire16:
+                ops.append(("wire_pack", lambda: self._wire_w.copy_(self.w_grad), "main"))
+            ops.append(("all_reduce", lambda: self.reduce_gradients(wire=True), "main"))
+            if self.wire16:
+                ops.append(("wire_unpack", lambda: self.w_grad.copy_(self._wire_w), "main"))
         ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True), "main"))
         return ops                                  # (this variant prepares the weight image before its MLP forward)
 

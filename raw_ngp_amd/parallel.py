@@ -32,6 +32,12 @@ def init_from_env(device_type="cuda"):
     reduces through gloo (RCCL wants one device per rank)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if ws <= 1:
+        if os.environ.get("NGP_DP_REHEARSAL") == "1" and device_type == "cuda" and not is_dist():
+            # one-rank RCCL group: lets a single GPU run the data-parallel step (real collectives, nothing to average)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         return 0, 1, 0
     r, lr = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
