@@ -316,6 +316,13 @@ int ngp_x_composite_mse_backward(const float *gt_rgba, const float *bg_rgb, floa
                                  const float *rgbs, const float *ts, const int32_t *rays, const float *weights_sum,
                                  const float *depth, const float *image, uint32_t M, uint32_t N, float T_thresh,
                                  float *grad_sigmas, float *grad_rgbs, float *loss_out, ngp_stream_t stream);
+/* ngp_x_composite_rays_train_forward + ngp_x_composite_mse_backward in one launch (what a training step needs): each
+ * wave composites its ray, writes weights_sum / depth / image (no per-sample weights) and runs the loss backward with
+ * the totals it still holds.  Same bits as the two calls. */
+int ngp_x_composite_mse_train(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *sigmas,
+                              const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
+                              float T_thresh, float *weights_sum, float *depth, float *image, float *grad_sigmas,
+                              float *grad_rgbs, float *loss_out, ngp_stream_t stream);
 
 /* One torch.optim.Adam step (no amsgrad, no weight decay; main.py:245 uses eps 1e-15) over a flat fp32
  * tensor in a single pass; `step` counts from 1; zero_grad != 0 clears `grad` afterwards. */

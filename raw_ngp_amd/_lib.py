@@ -56,6 +56,7 @@ _SIGNATURES = {
     "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
     "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
     "ngp_x_composite_mse_backward": [_p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p],
+    "ngp_x_composite_mse_train": [_p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
     "ngp_x_adam_step": [_p, _p, _p, _p, ctypes.c_uint64, _f, _d, _d, _f, _u, _i],
     "ngp_x_near_far_from_aabb_v2": [_p, _p, _p, _u, _f, _p, _p],
     "ngp_x_adam_step_dev": [_p, _p, _p, _p, ctypes.c_uint64, _p, _f, _f, _f, _i],
@@ -557,6 +558,15 @@ class _EngineBackend:
               float(bg_const), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"),
               _ptr(rays, "i", "rays"), _ptr(weights_sum, "f", "weights_sum"), _ptr(depth, "f", "depth"),
               _ptr(image, "f", "image"), M, N, float(T_thresh), _ptr(grad_sigmas, "f", "grad_sigmas"),
+              _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
+
+    @staticmethod
+    def composite_mse_train(gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, M, N, T_thresh, weights_sum, depth, image,
+                            grad_sigmas, grad_rgbs, loss_out):
+        _call("ngp_x_composite_mse_train", rays, _ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
+              float(bg_const), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"),
+              _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
+              _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
               _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
 
     @staticmethod

@@ -205,6 +205,9 @@ __global__ __launch_bounds__(256) void composite_forward_wave_kernel(
 //         but every sample of the ray is written: zeros after the early stop)
 // MODE 1: gradients of the MSE loss  mean_{n,c} ((image + (1 - ws) bg - gt)^2)  with gt = rgb*a + bg*(1-a);
 //         also accumulates the loss value into loss_out[0]
+// MODE 2: MODE 1 with the forward pass inside: each wave first composites its ray (the arithmetic of
+//         composite_forward_wave_kernel, so the totals are the same bits), writes weights_sum / depth / image and goes
+//         straight into the backward -- the training step needs no separate forward launch
 constexpr uint32_t kCompBwdBlock = 1024;   // 16 rays per workgroup: one loss atomic per workgroup (same-address
                                            // global atomics serialise: 4096 of them cost ~60 us)
 template <int MODE>
@@ -212,23 +215,63 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
     const float *__restrict__ grad_weights, const float *__restrict__ grad_weights_sum,
     const float *__restrict__ grad_depth, const float *__restrict__ grad_image, const float *__restrict__ gt_rgba,
     const float *__restrict__ bg_rgb, float bg_const, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
-    const float *__restrict__ ts, const int32_t *__restrict__ rays, const float *__restrict__ weights_sum,
-    const float *__restrict__ depth, const float *__restrict__ image, uint32_t M, uint32_t N, float T_thresh,
-    float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs, float *__restrict__ loss_out)
+    const float *__restrict__ ts, const int32_t *__restrict__ rays, const float *weights_sum, const float *depth,
+    const float *image, uint32_t M, uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
+    float *__restrict__ grad_rgbs, float *__restrict__ loss_out, float *ws_out, float *depth_out, float *image_out)
 {
     __shared__ float ray_err[kCompBwdBlock / 64];
     const uint32_t n = (blockIdx.x * kCompBwdBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (MODE == 1) {   // the whole workgroup passes the barrier before any wave leaves
+    if (MODE >= 1) {   // the whole workgroup passes the barrier before any wave leaves
         if (lane == 0) ray_err[threadIdx.x >> 6] = 0.0f;
     }
     const bool in_range = n < N;
     const uint32_t nn = in_range ? n : 0u;
     const uint32_t off = (uint32_t)rays[(size_t)nn * 2], cnt = (uint32_t)rays[(size_t)nn * 2 + 1];
     const bool live = in_range && cnt != 0 && off + cnt <= M;
-    const float rF = image[(size_t)nn * 3], gF = image[(size_t)nn * 3 + 1], bF = image[(size_t)nn * 3 + 2];
-    const float wsF = weights_sum[nn], dF = depth[nn];
+    float rF, gF, bF, wsF, dF;
+    if (MODE == 2) {
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0;
+        if (live) {
+            for (uint32_t base = 0; base < cnt; base += 64u) {
+                const uint32_t i = off + base + lane;
+                const bool have = base + lane < cnt;
+                float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f;
+                if (have) {
+                    const float2 tt = reinterpret_cast<const float2 *>(ts)[i];
+                    alpha = 1.0f - __expf(-sigmas[i] * tt.y);
+                    t = tt.x;
+                    c0 = rgbs[(size_t)i * 3];
+                    c1 = rgbs[(size_t)i * 3 + 1];
+                    c2 = rgbs[(size_t)i * 3 + 2];
+                }
+                const float Tb = T * wave_excl_prod(1.0f - alpha, lane);
+                const float Ta = Tb * (1.0f - alpha);
+                const unsigned long long hit = __ballot(have && Ta < T_thresh);
+                const uint32_t last = hit ? (uint32_t)__ffsll((long long)hit) - 1u : 63u;
+                const float w = (have && lane <= last) ? alpha * Tb : 0.0f;
+                r += wave_sum(w * c0);
+                g += wave_sum(w * c1);
+                b += wave_sum(w * c2);
+                ws += wave_sum(w);
+                d += wave_sum(w * t);
+                T = __shfl(Ta, min(last, 63u), 64);
+                if (hit != 0ull) break;   // wave-uniform
+            }
+        }
+        rF = r, gF = g, bF = b, wsF = ws, dF = d;
+        if (lane == 0 && in_range) {
+            ws_out[n] = ws;
+            depth_out[n] = d;
+            image_out[(size_t)n * 3] = r;
+            image_out[(size_t)n * 3 + 1] = g;
+            image_out[(size_t)n * 3 + 2] = b;
+        }
+    } else {
+        rF = image[(size_t)nn * 3], gF = image[(size_t)nn * 3 + 1], bF = image[(size_t)nn * 3 + 2];
+        wsF = weights_sum[nn], dF = depth[nn];
+    }
     float gr, gg, gb, gws, gd;
-    if (MODE == 1) {
+    if (MODE >= 1) {
         const float4 px = reinterpret_cast<const float4 *>(gt_rgba)[nn];
         const float b0 = bg_rgb ? bg_rgb[(size_t)nn * 3] : bg_const, b1 = bg_rgb ? bg_rgb[(size_t)nn * 3 + 1] : bg_const,
                     b2 = bg_rgb ? bg_rgb[(size_t)nn * 3 + 2] : bg_const;
@@ -563,7 +606,7 @@ extern "C" int ngp_x_composite_rays_train_backward(const float *grad_weights, co
                 "x_composite_rays_train_backward: null tensor");
     composite_backward_wave_kernel<0><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
         grad_weights, grad_weights_sum, grad_depth, grad_image, nullptr, nullptr, 0.0f, sigmas, rgbs, ts, rays,
-        weights_sum, depth, image, M, N, T_thresh, grad_sigmas, grad_rgbs, nullptr);
+        weights_sum, depth, image, M, N, T_thresh, grad_sigmas, grad_rgbs, nullptr, nullptr, nullptr, nullptr);
     NGP_CHECK_LAUNCH("x_composite_rays_train_backward");
     return NGP_OK;
 }
@@ -580,8 +623,24 @@ extern "C" int ngp_x_composite_mse_backward(const float *gt_rgba, const float *b
     NGP_REQUIRE(((uintptr_t)gt_rgba & 15u) == 0, "composite_mse_backward: gt_rgba must be 16-byte aligned");
     composite_backward_wave_kernel<1><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
         nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, weights_sum, depth, image, M,
-        N, T_thresh, grad_sigmas, grad_rgbs, loss_out);
+        N, T_thresh, grad_sigmas, grad_rgbs, loss_out, nullptr, nullptr, nullptr);
     NGP_CHECK_LAUNCH("composite_mse_backward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_composite_mse_train(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *sigmas,
+                                         const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
+                                         float T_thresh, float *weights_sum, float *depth, float *image,
+                                         float *grad_sigmas, float *grad_rgbs, float *loss_out, ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(gt_rgba && rays && weights_sum && depth && image && loss_out, "composite_mse_train: null tensor");
+    NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && grad_sigmas && grad_rgbs), "composite_mse_train: null sample tensor");
+    NGP_REQUIRE(((uintptr_t)gt_rgba & 15u) == 0, "composite_mse_train: gt_rgba must be 16-byte aligned");
+    composite_backward_wave_kernel<2><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
+        nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, nullptr, nullptr, nullptr, M,
+        N, T_thresh, grad_sigmas, grad_rgbs, loss_out, weights_sum, depth, image);
+    NGP_CHECK_LAUNCH("composite_mse_train");
     return NGP_OK;
 }
 

@@ -21,6 +21,7 @@ composite backward -> MLP backward (2) -> dW reduction (+Adam on the MLP weights
 (+Adam on the table).  Same seed, same bits: no float atomic feeds back into the state.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -135,7 +136,7 @@ class FusedTrainer:
             self._wire_w = self._wire_flat[n_t:]
         self._main_symbols = {"ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
                               "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
-                              "ngp_x_composite_mse_backward", "ngp_x_adam_step_dev2", "ngp_x_adam_step_dev",
+                              "ngp_x_composite_mse_backward", "ngp_x_composite_mse_train", "ngp_x_adam_step_dev2", "ngp_x_adam_step_dev",
                               "ngp_x_step_begin", "ngp_x_mlp_prepare", "ngp_x_mlp_reduce_dw",
                               "ngp_x_grid_backward_binned_prepare"}
         # density-grid refresh on the device (no host round trips)
@@ -201,7 +202,7 @@ class FusedTrainer:
             op()
 
     def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False, split_weights=False,
-                   overwrite=False):
+                   overwrite=False, fuse_composite=False):
         """The field part of the step as (C entry point, thunk) pairs, in launch order.  split_weights: the step path --
         the f16 weight image was prepared at the end of the previous step and the weight-gradient reduction is left to
         the caller (it goes to the aux stream together with the MLP's Adam step)."""
@@ -215,6 +216,12 @@ class FusedTrainer:
                 self.loss.zero_()
             eb.composite_mse_backward(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, self.ws,
                                       self.depth, self.image, cap, N, opt.T_thresh, self.dsigma, self.drgb, self.loss)
+
+        def composite_train():      # forward + loss + backward of the compositor in one launch (the step path)
+            if zero_loss:
+                self.loss.zero_()
+            eb.composite_mse_train(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh,
+                                   self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss)
 
         ops = [
             ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
@@ -239,6 +246,10 @@ class FusedTrainer:
         ]
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
+        if fuse_composite:
+            ops = [o for o in ops if o[0] != "ngp_x_composite_rays_train_forward"]
+            ops = [("ngp_x_composite_mse_train", composite_train) if o[0] == "ngp_x_composite_mse_backward" else o
+                   for o in ops]
         return ops
 
     @staticmethod
@@ -378,7 +389,8 @@ class FusedTrainer:
         # separate Adam (data parallel, or fuse_adam off): the reduction writes every row of the gradient, so nothing
         # has to zero it and the accumulate's read disappears (TV / weight decay are added afterwards, in optimizer_step)
         field = self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False,
-                                fused_adam=self.fuse_adam, split_weights=split, overwrite=not self.fuse_adam)
+                                fused_adam=self.fuse_adam, split_weights=split, overwrite=not self.fuse_adam,
+                                fuse_composite=True)
         field = self._without(field, "ngp_x_grid_backward_binned_prepare")          # folded into step_begin
         field.insert(1, begin)                                                      # right after the encoder's forward
         prepare = ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image))

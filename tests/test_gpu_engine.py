@@ -512,3 +512,34 @@ def test_operand_image_follows_the_weights_without_a_prepare_pass(lib, graph):
     fresh = torch.zeros_like(eng.mlp_image)
     lib.mlp_backend.prepare(eng.weights, fresh)
     assert torch.equal(fresh, eng.mlp_image)
+
+
+@pytest.mark.parametrize("T_thresh,random_bg", [(1e-4, True), (1e-8, False), (0.3, True)])
+def test_fused_compositor_step_is_the_two_calls(lib, T_thresh, random_bg):
+    """ngp_x_composite_mse_train = forward + MSE backward in one launch: ray totals, loss and both gradients must be the
+    bits the two separate entry points produce (early stops included: T_thresh 0.3 stops most rays early)."""
+    rng = np.random.default_rng(31)
+    N = 1700
+    sig, rgb, ts, rays, M = synth_samples(rng, N)
+    rays[5, 1] = 0                                  # an empty ray
+    gt = dev(rng.uniform(0, 1, (N, 4)).astype(np.float32))
+    bg = dev(rng.uniform(0, 1, (N, 3)).astype(np.float32)) if random_bg else None
+    e = lib.engine_backend
+    dsig, drgb, dts, drays = dev(sig), dev(rgb), dev(ts), dev(rays)
+
+    def buffers():
+        return (torch.full((N,), 9.0, device="cuda"), torch.full((N,), 9.0, device="cuda"),
+                torch.full((N, 3), 9.0, device="cuda"), torch.full((M,), 9.0, device="cuda"),
+                torch.full((M, 3), 9.0, device="cuda"), torch.zeros(1, device="cuda"))
+    ws_a, dep_a, img_a, gs_a, gc_a, lo_a = buffers()
+    w = torch.empty(M, device="cuda")
+    e.composite_rays_train_forward(dsig, drgb, dts, drays, M, N, T_thresh, w, ws_a, dep_a, img_a)
+    e.composite_mse_backward(gt, bg, 1.0, dsig, drgb, dts, drays, ws_a, dep_a, img_a, M, N, T_thresh, gs_a, gc_a, lo_a)
+    ws_b, dep_b, img_b, gs_b, gc_b, lo_b = buffers()
+    e.composite_mse_train(gt, bg, 1.0, dsig, drgb, dts, drays, M, N, T_thresh, ws_b, dep_b, img_b, gs_b, gc_b, lo_b)
+    for a, b in ((ws_a, ws_b), (dep_a, dep_b), (img_a, img_b), (gs_a, gs_b), (gc_a, gc_b)):
+        assert torch.equal(a, b)
+    # (the loss value is a float atomic per workgroup: same terms, arrival order not fixed)
+    np.testing.assert_allclose(float(lo_a), float(lo_b), rtol=1e-6)
+    live = gs_a[gs_a != 9.0]                       # rows of some ray (the kernels write every sample of a live ray)
+    assert float(lo_a) > 0 and live.numel() > 0 and float(live.abs().sum()) > 0
