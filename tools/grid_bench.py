@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raw_ngp_amd import _lib  # noqa: E402
 from raw_ngp_amd._lib import engine_backend as eb, gridencoder_backend as gb  # noqa: E402
-from oracle import oracle as orc  # noqa: E402  (level table only)
+from raw_ngp_amd.gridencoder.grid import level_table  # noqa: E402
 
 
 def main():
@@ -35,7 +35,8 @@ def main():
     t = t0 + dt * torch.arange(K, device=dev).float()[None]
     xyz = (o[:, None] + d[:, None] * t[..., None]).reshape(-1, 3).clamp(-0.999, 0.999).contiguous()
     B = xyz.shape[0]
-    offsets_np, scale = orc.grid_offsets(desired_resolution=2048)
+    scale = float(np.exp2(np.log2(2048 / 16) / 15))
+    offsets_np = level_table(3, 16, scale, 16, 19)
     offsets = torch.from_numpy(offsets_np).to(dev)
     L, H, S = 16, 16, float(np.log2(scale))
     rows = int(offsets_np[-1])
