@@ -21,7 +21,6 @@ composite backward -> MLP backward (2) -> dW reduction (+Adam on the MLP weights
 (+Adam on the table).  Same seed, same bits: no float atomic feeds back into the state.
 """
 import math
-import os
 
 import numpy as np
 import torch
