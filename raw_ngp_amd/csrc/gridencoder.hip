@@ -20,11 +20,12 @@ template <uint32_t D, uint32_t C, bool JAC>
 __global__ __launch_bounds__(kBlock) void grid_forward_kernel(
     const float *__restrict__ inputs, const float *__restrict__ table, const int32_t *__restrict__ offsets,
     float *__restrict__ outputs, float *__restrict__ dy_dx, uint32_t B, uint32_t L, uint32_t nchunks,
-    LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp)
+    uint32_t max_level, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp)
 {
-    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t level = item / nchunks;
-    const uint32_t b = (item - level * nchunks) * kBlock + threadIdx.x;
+    uint32_t level, chunk;
+    snake_level_tile(blockIdx.x, nchunks, max_level, level, chunk);
+    if (level == kNoLevel) return;
+    const uint32_t b = chunk * kBlock + threadIdx.x;
     if (b >= B) return;
 
     const Geom<D> g = make_geom<D>(offsets, level, lv.res[level], gridtype);
@@ -274,13 +275,13 @@ static void launch_forward(const float *inputs, const float *table, const int32_
                            uint32_t gridtype, bool align, uint32_t interp, hipStream_t st)
 {
     const uint32_t nchunks = ceil_div(B, kBlock);
-    const dim3 grid(nchunks * max_level);
+    const dim3 grid(snake_blocks(max_level, nchunks));
     if (dy_dx)
         grid_forward_kernel<D, C, true><<<grid, kBlock, 0, st>>>(inputs, table, offsets, outputs, dy_dx, B, L,
-                                                                 nchunks, lv, gridtype, align, interp);
+                                                                 nchunks, max_level, lv, gridtype, align, interp);
     else
         grid_forward_kernel<D, C, false><<<grid, kBlock, 0, st>>>(inputs, table, offsets, outputs, dy_dx, B, L,
-                                                                  nchunks, lv, gridtype, align, interp);
+                                                                  nchunks, max_level, lv, gridtype, align, interp);
 }
 
 template <uint32_t D, uint32_t C>

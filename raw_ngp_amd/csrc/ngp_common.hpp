@@ -49,4 +49,32 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n)
     return base + i;
 }
 
+// Placement of per-level work: `n_levels` runs of `per_level` tiles.  The finest levels of a hash grid cost 5-10 x a
+// coarse one (every corner is its own cache line), so handing XCD k two NEIGHBOURING levels (xcd_remap over a
+// level-major item list) leaves XCD 7 with the two most expensive ones.  Snake instead: XCD k takes levels k, 15-k,
+// 16+k, 31-k, ... -- a level still lives in one L2, and cheap levels are paired with expensive ones.
+// Launch snake_blocks(n_levels, per_level) workgroups; level == kNoLevel means "nothing to do".
+constexpr uint32_t kNoLevel = 0xffffffffu;
+// (fewer than 8 levels: one level per XCD would idle the rest -- keep the contiguous split there)
+__host__ __device__ inline uint32_t snake_rounds(uint32_t n_levels) { return (n_levels + 7u) / 8u; }
+static inline uint32_t snake_blocks(uint32_t n_levels, uint32_t per_level)
+{
+    return n_levels < 8u ? n_levels * per_level : 8u * snake_rounds(n_levels) * per_level;
+}
+__device__ __forceinline__ void snake_level_tile(uint32_t bid, uint32_t per_level, uint32_t n_levels, uint32_t &level,
+                                                 uint32_t &tile)
+{
+    if (n_levels < 8u) {
+        const uint32_t item = xcd_remap(bid, n_levels * per_level);
+        level = item / per_level;
+        tile = item - level * per_level;
+        return;
+    }
+    const uint32_t k = bid & 7u, i = bid >> 3;        // XCD, index within the XCD
+    const uint32_t round = i / per_level;
+    tile = i - round * per_level;
+    level = (round >> 1) * 16u + ((round & 1u) ? 15u - k : k);
+    if (level >= n_levels) level = kNoLevel;
+}
+
 }  // namespace ngp
