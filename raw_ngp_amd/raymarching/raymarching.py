@@ -147,6 +147,25 @@ def _ray_gradients(ctx, dL_dxyzs, dL_ddirs):
     return g_o, g_d
 
 
+# march_rays_train: one chain-parallel pass into a cached scratch arena instead of the reference's two serial passes
+# (count, then write).  Set to False for the literal two-call protocol of the C ABI.
+single_pass = True
+_SCRATCH = {}
+
+
+def _scratch_arena(N, max_steps, bound, dev, with_ldirs):
+    import math
+    key = (dev.index, N, max_steps, int(math.ceil(bound)), with_ldirs)
+    ar = _SCRATCH.get(key)
+    if ar is None:
+        if len(_SCRATCH) >= 2:          # training + evaluation shapes at most; drop the oldest
+            _SCRATCH.pop(next(iter(_SCRATCH)))
+        ar = MarchArena(N, max_steps, N * max_steps, dev, with_ldirs=with_ldirs,
+                        chain_cap=max_steps * int(math.ceil(bound)) + 2)
+        _SCRATCH[key] = ar
+    return ar
+
+
 class _march_rays_train(Function):
     @staticmethod
     @custom_fwd(**_FWD32)
@@ -160,10 +179,24 @@ class _march_rays_train(Function):
         N = rays_o.shape[0]
         dev, dt = rays_o.device, rays_o.dtype
 
-        counter = torch.zeros(1, dtype=torch.int32, device=dev)
         noises = _noises(perturb, N, rays_o)
-        rays = torch.empty(N, 2, dtype=torch.int32, device=dev)
         args = (rays_o, rays_d, rays_ldir, bitfield, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars)
+        if single_pass and N > 0 and max_steps * int(-(-bound // 1)) + 2 < 65536:      # (chain codes are 16-bit)
+            # one chain-parallel march into a worst-case scratch arena (a ray has at most max_steps samples), then
+            # exact-size copies: the same bits as the two calls below (tests compare them), ~ 8 x less marching
+            ar = _scratch_arena(N, max_steps, bound, dev, rays_ldir is not None)
+            get_backend().march_rays_train_arena(*args, noises, ar.t_scratch, ar.capacity, ar.xyzs, ar.dirs, ar.ts,
+                                                 ar.ldirs, ar.rays, ar.counter, ar.ray_idx, None, ar.chain)
+            written, needed, chain_overflow = ar.counter[:3].tolist()                         # host sync
+            if chain_overflow == 0 and written == needed:
+                M = written
+                xyzs, dirs, ts = ar.xyzs[:M].clone(), ar.dirs[:M].clone(), ar.ts[:M].clone()
+                ldirs = ar.ldirs[:M].clone() if rays_ldir is not None else None
+                rays = ar.rays[:N].clone()
+                ctx.save_for_backward(rays, ts)
+                return xyzs, dirs, ts, rays, ldirs
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        rays = torch.empty(N, 2, dtype=torch.int32, device=dev)
         get_backend().march_rays_train(*args, None, None, None, None, rays, counter, noises)   # count + scan
         M = counter.item()                                                                     # host sync
 

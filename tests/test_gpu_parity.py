@@ -514,3 +514,28 @@ def test_ray_gradient_segment_sum(be, orc):
     be.raymarching_backend.march_rays_train_backward(dev(gx), dev(gd), dev(ts), dev(rays), N, M, go, gdd)
     np.testing.assert_allclose(host(go), ro, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(host(gdd), rd, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("case", MARCH_CASES, ids=lambda c: f"N{c[0]}H{c[1]}C{c[3]}b{c[4]}c{int(c[5])}g{c[6] > 0}")
+def test_march_function_single_pass_equals_two_calls(be, orc, case):
+    """The autograd op `march_rays_train` marches once (chain-parallel, scratch arena) instead of calling the C ABI twice:
+    sizes, contents and the ray gradients of its backward must be identical to the literal two-call protocol."""
+    from raw_ngp_amd import raymarching as rm
+    N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
+    bits, o, d, ld, nears, fars, _ = march_inputs(orc, case, seed=4)
+    outs = []
+    for single in (True, False):
+        rm.raymarching.single_pass = single
+        try:
+            torch.manual_seed(7)                                  # same perturbation noise in both runs
+            ro, rd = dev(o).requires_grad_(True), dev(d).requires_grad_(True)
+            xyzs, dirs, ts, rays, ldirs = rm.march_rays_train(ro, rd, dev(ld) if ldir else None, bound, contract, dev(bits),
+                                                              C, H, dev(nears), dev(fars), True, dt_gamma, max_steps)
+            (xyzs.sum() * 2.0 + (dirs * dirs).sum()).backward()
+            outs.append((xyzs, dirs, ts, rays, ldirs, ro.grad, rd.grad))
+        finally:
+            rm.raymarching.single_pass = True
+    a, b = outs
+    assert a[0].shape[0] == b[0].shape[0] == int(b[3][:, 1].sum()) > 0
+    for x, y in zip(a, b):
+        assert (x is None and y is None) or torch.equal(x, y)
