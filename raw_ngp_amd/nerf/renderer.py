@@ -235,8 +235,14 @@ class NeRFRenderer(nn.Module):
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
         N, device = rays_o.shape[0], rays_o.device
         aabb = self.aabb_train if self.training else self.aabb_infer
-        nears, fars = near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
-        nears, fars = nears.squeeze(-1), fars.squeeze(-1)
+        if rays_o.is_cuda:      # the same slab test as one kernel (tested against the torch expression; the per-row
+            from .._lib import engine_backend                      # amax / amin reductions cost 0.6 ms on this stack)
+            nears, fars = torch.empty(N, device=device), torch.empty(N, device=device)
+            engine_backend.near_far_from_aabb_v2(rays_o.detach().float(), rays_d.detach().float(), aabb, N, self.min_near,
+                                                 nears, fars)
+        else:
+            nears, fars = near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+            nears, fars = nears.squeeze(-1), fars.squeeze(-1)
         if cam_near_far is not None:
             nears = torch.maximum(nears, cam_near_far[:, 0])
             fars = torch.minimum(fars, cam_near_far[:, 1])

@@ -276,6 +276,14 @@ class _march_rays_train_arena(Function):
 march_rays_train_arena = _march_rays_train_arena.apply
 
 
+wave_compositing = True
+
+
+def _engine():
+    from .._lib import engine_backend
+    return engine_backend
+
+
 class _composite_rays_train(Function):
     @staticmethod
     @custom_fwd(**_FWD32)
@@ -289,8 +297,10 @@ class _composite_rays_train(Function):
         weights_sum = torch.empty(N, dtype=dt, device=dev)
         depth = torch.empty(N, dtype=dt, device=dev)
         image = torch.empty(N, 3, dtype=dt, device=dev)
-        get_backend().composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum,
-                                                   depth, image)
+        # wave-per-ray kernels (ngp_x_*): same contract as the reference-shaped thread-per-ray ones of the C ABI
+        # (ngp_composite_rays_train_*; `wave_compositing = False` selects those), ~ 10 x faster on ray-ordered samples
+        fwd = _engine().composite_rays_train_forward if wave_compositing else get_backend().composite_rays_train_forward
+        fwd(sigmas, rgbs, ts.contiguous(), rays, M, N, T_thresh, weights, weights_sum, depth, image)
         ctx.save_for_backward(sigmas, rgbs, ts, rays, weights_sum, depth, image)
         ctx.dims = (M, N, T_thresh)
         return weights, weights_sum, depth, image
@@ -302,10 +312,11 @@ class _composite_rays_train(Function):
         M, N, T_thresh = ctx.dims
         grad_sigmas = torch.zeros_like(sigmas)
         grad_rgbs = torch.zeros_like(rgbs)
-        get_backend().composite_rays_train_backward(grad_weights.contiguous(), grad_weights_sum.contiguous(),
-                                                    grad_depth.contiguous(), grad_image.contiguous(), sigmas, rgbs,
-                                                    ts, rays, weights_sum, depth, image, M, N, T_thresh,
-                                                    grad_sigmas, grad_rgbs)
+        bwd = _engine().composite_rays_train_backward if wave_compositing else get_backend().composite_rays_train_backward
+        if M > 0:
+            bwd(grad_weights.contiguous(), grad_weights_sum.contiguous(), grad_depth.contiguous(),
+                grad_image.contiguous(), sigmas, rgbs, ts.contiguous(), rays, weights_sum, depth, image, M, N, T_thresh,
+                grad_sigmas, grad_rgbs)
         return grad_sigmas, grad_rgbs, None, None, None
 
 
