@@ -67,3 +67,22 @@ def test_config4_variants_train_without_nans(pose_opt, rfield, arena):
             out = tr.model.render(val["rays_o"][:4096], val["rays_d"][:4096], rays_ldir=val["rays_ldir"], bg_color=0,
                                   perturb=False)
         assert torch.isfinite(out["image"]).all()
+
+
+def test_split_k_linear_matches_nn_linear():
+    """The tall-matrix Linear of the torch MLP path: same forward, same gradients as nn.Linear up to the regrouped sum."""
+    from raw_ngp_amd.nerf.network import _SplitKLinear
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for M, i, o in ((163_841, 47, 80), (20_000, 80, 3)):
+        x = torch.randn(M, i, device="cuda", generator=g, requires_grad=True)
+        w = torch.randn(o, i, device="cuda", generator=g, requires_grad=True)
+        dy = torch.randn(M, o, device="cuda", generator=g)
+        y = _SplitKLinear.apply(x, w)
+        y.backward(dy)
+        x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+        y2 = torch.nn.functional.linear(x2, w2)
+        y2.backward(dy)
+        assert torch.equal(y, y2)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        scale = float(w2.grad.abs().max())
+        assert float((w.grad - w2.grad).abs().max()) <= 2e-5 * scale
