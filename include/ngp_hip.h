@@ -234,7 +234,14 @@ int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, con
 /* grad_inputs[b, d] = sum_{l, ch} grad[l, b, ch] * dy_dx[b, l, d, ch] -- the second half of
  * ngp_grid_encode_backward (gridencoder.cu:352-378) on its own. */
 int ngp_x_grid_input_backward(const float *grad, const float *dy_dx, float *grad_inputs, uint32_t B, uint32_t D,
-                              uint32_t C, uint32_t L, ngp_stream_t stream);
+                              uint32_t C, uint32_t L, int level_major, ngp_stream_t stream);
+/* ngp_grid_encode_forward with the Jacobian stored level-major, dy_dx[level, b, d, ch], when level_major != 0 (pass the
+ * same flag to ngp_x_grid_input_backward): with one (sample, level) per lane the reference layout [b, level, d, ch] makes
+ * every lane write D*C floats 384 bytes apart (L = 16, D = 3, C = 2); level-major the wave writes one contiguous run. */
+int ngp_x_grid_encode_forward_jac(const float *inputs, const float *embeddings, const int32_t *offsets, float *outputs,
+                                  uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                  float *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int level_major,
+                                  ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused tiny-MLP field (csrc/fused_mlp*.hip): replaces the six nn.Linear GEMMs + slicing / cat /

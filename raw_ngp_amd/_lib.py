@@ -47,7 +47,8 @@ _SIGNATURES = {
                                            ctypes.c_size_t],
     "ngp_x_grid_backward_binned_apply": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
                                          ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i],
-    "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u],
+    "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u, _i],
+    "ngp_x_grid_encode_forward_jac": [_p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _p, _u, _i, _u, _i],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
@@ -248,8 +249,21 @@ class _GridBackend:
         return val
 
     @staticmethod
+    def level_major_jacobian(B, D, C, L):
+        """True when the op pair keeps dy_dx level-major (the route that does not go through the reference-shaped
+        ngp_grid_encode_backward, which reads the reference layout)."""
+        return bool(_GridBackend.use_binned_backward and D == 3 and C == 2 and B * L * 8 < 2 ** 32)
+
+    @staticmethod
+    def grid_encode_forward_jac(inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, H, dy_dx, gridtype,
+                                align_corners, interp, level_major):
+        _call("ngp_x_grid_encode_forward_jac", inputs, _ptr(inputs, "f", "inputs"), _ptr(embeddings, "f", "embeddings"),
+              _ptr(offsets, "i", "offsets"), _ptr(outputs, "f", "outputs"), B, D, C, L, max_level, float(S), H,
+              _ptr(dy_dx, "f", "dy_dx"), gridtype, int(bool(align_corners)), interp, int(bool(level_major)))
+
+    @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S, H, dy_dx,
-                             grad_inputs, gridtype, align_corners, interp):
+                             grad_inputs, gridtype, align_corners, interp, dy_dx_level_major=False):
         if _GridBackend.use_binned_backward and D == 3 and C == 2 and B * L * 8 < 2 ** 32:
             rows = embeddings.shape[0]
             nbytes = load().ngp_x_grid_backward_workspace_bytes(B, L, rows)
@@ -260,8 +274,10 @@ class _GridBackend:
                   _GridBackend._max_level_rows(offsets), ws.data_ptr(), nbytes)
             if dy_dx is not None and grad_inputs is not None:
                 _call("ngp_x_grid_input_backward", grad, _ptr(grad, "f", "grad"), _ptr(dy_dx, "f", "dy_dx"),
-                      _ptr(grad_inputs, "f", "grad_inputs"), B, D, C, L)
+                      _ptr(grad_inputs, "f", "grad_inputs"), B, D, C, L, int(bool(dy_dx_level_major)))
             return
+        if dy_dx_level_major:
+            raise RuntimeError("a level-major dy_dx needs the binned backward route")
         _call("ngp_grid_encode_backward", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
               _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"),
               _ptr(grad_embeddings, "f", "grad_embeddings"), B, D, C, L, max_level, float(S), H,

@@ -16,7 +16,9 @@
 namespace ngp {
 
 // ------------------------------------------------------------------ forward
-template <uint32_t D, uint32_t C, bool JAC>
+// LM: the Jacobian is stored level-major, dy_dx[level, b, d, ch] (a private layout between the two x_ entry points: the
+// lanes of a wave then write one contiguous run instead of 6 floats every 384 bytes)
+template <uint32_t D, uint32_t C, bool JAC, bool LM = false>
 __global__ __launch_bounds__(kBlock) void grid_forward_kernel(
     const float *__restrict__ inputs, const float *__restrict__ table, const int32_t *__restrict__ offsets,
     float *__restrict__ outputs, float *__restrict__ dy_dx, uint32_t B, uint32_t L, uint32_t nchunks,
@@ -36,7 +38,9 @@ __global__ __launch_bounds__(kBlock) void grid_forward_kernel(
     for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
 
     float *out = outputs + ((size_t)level * B + b) * C;
-    float *jac = JAC ? dy_dx + (size_t)b * L * D * C + (size_t)level * D * C : nullptr;
+    float *jac = !JAC ? nullptr
+                 : LM ? dy_dx + ((size_t)level * B + b) * D * C
+                      : dy_dx + (size_t)b * L * D * C + (size_t)level * D * C;
 
     Cell<D> cl;
     if (!locate<D>(x, g.res, align_corners, interp, cl)) {
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void grid_backward_atomic_kernel(
 }
 
 // grad_inputs[b, d] = sum_{l, ch} grad[l, b, ch] * dy_dx[b, l, d, ch]   (all L levels)
-template <uint32_t D, uint32_t C>
+template <uint32_t D, uint32_t C, bool LM = false>
 __global__ __launch_bounds__(kBlock) void grid_input_backward_kernel(const float *__restrict__ grad,
                                                                      const float *__restrict__ dy_dx,
                                                                      float *__restrict__ grad_inputs, uint32_t B,
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void grid_input_backward_kernel(const float
     float r = 0.0f;
     for (uint32_t l = 0; l < L; l++) {
         const float *gl = grad + ((size_t)l * B + b) * C;
-        const float *jl = jac + (size_t)l * D * C + d * C;
+        const float *jl = LM ? dy_dx + (((size_t)l * B + b) * D + d) * C : jac + (size_t)l * D * C + d * C;
 #pragma unroll
         for (uint32_t ch = 0; ch < C; ch++) r = fmaf(gl[ch], jl[ch], r);
     }
@@ -272,11 +276,14 @@ __global__ __launch_bounds__(kBlock) void grid_wd_kernel(const float *__restrict
 template <uint32_t D, uint32_t C>
 static void launch_forward(const float *inputs, const float *table, const int32_t *offsets, float *outputs,
                            float *dy_dx, uint32_t B, uint32_t L, uint32_t max_level, const LevelRes &lv,
-                           uint32_t gridtype, bool align, uint32_t interp, hipStream_t st)
+                           uint32_t gridtype, bool align, uint32_t interp, bool lm, hipStream_t st)
 {
     const uint32_t nchunks = ceil_div(B, kBlock);
     const dim3 grid(snake_blocks(max_level, nchunks));
-    if (dy_dx)
+    if (dy_dx && lm)
+        grid_forward_kernel<D, C, true, true><<<grid, kBlock, 0, st>>>(inputs, table, offsets, outputs, dy_dx, B, L,
+                                                                       nchunks, max_level, lv, gridtype, align, interp);
+    else if (dy_dx)
         grid_forward_kernel<D, C, true><<<grid, kBlock, 0, st>>>(inputs, table, offsets, outputs, dy_dx, B, L,
                                                                  nchunks, max_level, lv, gridtype, align, interp);
     else
@@ -349,8 +356,25 @@ extern "C" int ngp_grid_encode_forward(const float *inputs, const float *embeddi
     NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_forward: L must be in [1, %u]", kMaxLevels);
     NGP_REQUIRE(max_level <= L, "grid_encode_forward: max_level > L");
     NGP_DISPATCH_DC(launch_forward, inputs, embeddings, offsets, outputs, dy_dx, B, L, max_level, lv, gridtype,
-                    align_corners != 0, interp, as_stream(stream));
+                    align_corners != 0, interp, false, as_stream(stream));
     NGP_CHECK_LAUNCH("grid_encode_forward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_grid_encode_forward_jac(const float *inputs, const float *embeddings, const int32_t *offsets,
+                                             float *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                             uint32_t max_level, float S, uint32_t H, float *dy_dx, uint32_t gridtype,
+                                             int align_corners, uint32_t interp, int level_major, ngp_stream_t stream)
+{
+    if (B == 0 || max_level == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && embeddings && offsets && outputs && dy_dx, "grid_encode_forward_jac: null tensor");
+    if (int e = check_dc("grid_encode_forward_jac", D, C)) return e;
+    LevelRes lv;
+    NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_forward_jac: L must be in [1, %u]", kMaxLevels);
+    NGP_REQUIRE(max_level <= L, "grid_encode_forward_jac: max_level > L");
+    NGP_DISPATCH_DC(launch_forward, inputs, embeddings, offsets, outputs, dy_dx, B, L, max_level, lv, gridtype,
+                    align_corners != 0, interp, level_major != 0, as_stream(stream));
+    NGP_CHECK_LAUNCH("grid_encode_forward_jac");
     return NGP_OK;
 }
 
@@ -375,18 +399,22 @@ extern "C" int ngp_grid_encode_backward(const float *grad, const float *inputs, 
 
 template <uint32_t D, uint32_t C>
 static void launch_input_backward(const float *grad, const float *dy_dx, float *grad_inputs, uint32_t B, uint32_t L,
-                                  hipStream_t st)
+                                  bool lm, hipStream_t st)
 {
-    grid_input_backward_kernel<D, C><<<dim3(ceil_div(B * D, kBlock)), kBlock, 0, st>>>(grad, dy_dx, grad_inputs, B, L);
+    const dim3 grid(ceil_div(B * D, kBlock));
+    if (lm)
+        grid_input_backward_kernel<D, C, true><<<grid, kBlock, 0, st>>>(grad, dy_dx, grad_inputs, B, L);
+    else
+        grid_input_backward_kernel<D, C, false><<<grid, kBlock, 0, st>>>(grad, dy_dx, grad_inputs, B, L);
 }
 
 extern "C" int ngp_x_grid_input_backward(const float *grad, const float *dy_dx, float *grad_inputs, uint32_t B,
-                                         uint32_t D, uint32_t C, uint32_t L, ngp_stream_t stream)
+                                         uint32_t D, uint32_t C, uint32_t L, int level_major, ngp_stream_t stream)
 {
     if (B == 0) return NGP_OK;
     NGP_REQUIRE(grad && dy_dx && grad_inputs, "grid_input_backward: null tensor");
     if (int e = check_dc("grid_input_backward", D, C)) return e;
-    NGP_DISPATCH_DC(launch_input_backward, grad, dy_dx, grad_inputs, B, L, as_stream(stream));
+    NGP_DISPATCH_DC(launch_input_backward, grad, dy_dx, grad_inputs, B, L, level_major != 0, as_stream(stream));
     NGP_CHECK_LAUNCH("grid_input_backward");
     return NGP_OK;
 }

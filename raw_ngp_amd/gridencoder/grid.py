@@ -36,9 +36,15 @@ class _grid_encode(Function):
         alloc = torch.zeros if max_level < L else torch.empty
         outputs = alloc(L, B, C, device=inputs.device, dtype=embeddings.dtype)
         dy_dx = alloc(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
-
-        _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, H, dy_dx,
-                                     gridtype, align_corners, interpolation)
+        # the Jacobian is private to this op: level-major [L, B, D*C] where the backward route allows it (coalesced)
+        lm = calc_grad_inputs and _backend.level_major_jacobian(B, D, C, L)
+        if lm:
+            _backend.grid_encode_forward_jac(inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, H, dy_dx,
+                                             gridtype, align_corners, interpolation, True)
+        else:
+            _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, H, dy_dx,
+                                         gridtype, align_corners, interpolation)
+        ctx.lm = lm
 
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = (B, D, C, L, S, H, gridtype, interpolation, max_level)
@@ -63,7 +69,8 @@ class _grid_encode(Function):
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
 
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S,
-                                      H, dy_dx, grad_inputs, gridtype, ctx.align_corners, interpolation)
+                                      H, dy_dx, grad_inputs, gridtype, ctx.align_corners, interpolation,
+                                      dy_dx_level_major=ctx.lm)
 
         if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
