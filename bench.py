@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--grad-wire", default="bf16", choices=["f32", "bf16"],
                     help="data parallel: wire format of the table-gradient all-reduce")
+    ap.add_argument("--graph-collective", action="store_true",
+                    help="data parallel: capture the RCCL all-reduce inside the step graph (experimental, off by default)")
     ap.add_argument("--dp-rehearsal", action="store_true",
                     help="one GPU: run the data-parallel step (separate Adam, RCCL collectives on a one-rank group)")
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
@@ -195,7 +197,7 @@ def main():
                   fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
                   aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
-                  dp_rehearsal=args.dp_rehearsal)
+                  dp_rehearsal=args.dp_rehearsal, graph_collective=args.graph_collective)
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
     fused = not (args.autograd or args.torch_mlp)

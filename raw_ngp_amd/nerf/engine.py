@@ -459,7 +459,9 @@ class FusedTrainer:
         from .. import _lib
         if self.graph_pool is None:
             self.graph_pool = torch.cuda.graph_pool_handle()
-        eager = {"all_reduce", *(_lib.probed_symbols() if timed else ())}
+        # (graph_collective: capture the RCCL call inside the step graph -- opt-in, verified on a one-rank group only)
+        eager = {*(() if getattr(self.opt, "graph_collective", False) else ("all_reduce",)),
+                 *(_lib.probed_symbols() if timed else ())}
         ops = self._step_ops(slot)
         # one graph: the aux lane may fork inside it
         whole = not any(name in eager for name, _, _ in ops) and bool(getattr(self.opt, "aux_stream", False))

@@ -62,6 +62,7 @@ class Options:
     loss_scale: float = 1024.0    # static loss scale of the fused MLP backward (f16 deltas)
     arena_capacity: int = 0       # > 0: sample arena (no host sync per step); 0 = reference 2-pass protocol
     native_grid_refresh: bool = True  # fused engine: density-grid refresh as device kernels (no host syncs)
+    graph_collective: bool = False  # data parallel: capture the gradient all-reduce inside the step graph (experimental)
     dp_rehearsal: bool = False    # run the data-parallel step on ONE rank (needs an initialised process group)
     grad_wire: str = "bf16"       # data parallel: wire format of the table-gradient all-reduce (f32 | bf16)
     aux_stream: bool = False      # fused engine: MLP-weight tail (dW reduction, Adam, f16 image) on a third stream
