@@ -34,13 +34,12 @@ def main():
     ap.add_argument("--c-lr", type=float, default=1e-3)
     ap.add_argument("--log-every", type=int, default=500)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--fp16", action="store_true", help="the reference's --fp16: autocast + GradScaler around the torch MLPs")
     ap.add_argument("--arena", type=int, default=0, help="sample-arena rows (0 = the reference's two-call march)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     torch.manual_seed(args.seed)
     opt = Options(bound=1.0, num_rays=args.rays, iters=args.iters, rfield=not args.no_rfield, pose_opt=args.pose_opt,
-                  noise=args.noise, c_lr=args.c_lr, arena_capacity=args.arena, fp16=args.fp16)
+                  noise=args.noise, c_lr=args.c_lr, arena_capacity=args.arena)
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     if opt.rfield:
         data.ldirs = torch.from_numpy(P.synthetic_light_dirs(args.views)).to(dev)
