@@ -122,6 +122,7 @@ class FusedTrainer:
             and opt.lambda_wd == 0
         self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
         self._refresh_graph = None
+        self._eval_slot = None
         # 16-bit wire format of the table gradient under data parallelism: the reduce kernel stores bfloat16, RCCL
         # averages it in place, Adam reads it -- no conversion passes, half the bytes on xGMI
         self.wire16 = getattr(opt, "grad_wire", "f32") == "bf16" and not self.fuse_adam \
@@ -172,18 +173,21 @@ class FusedTrainer:
     def lr(self):
         return self.lr0 * 0.1 ** min(self.global_step / self.opt.iters, 1)
 
-    def march(self, slot, rays_o, rays_d, noises):
+    def march(self, slot, rays_o, rays_d, noises, aabb=None, plan=True):
         """rays -> sample arena of `slot` (near/far, count, scan, expand); runs on the current stream."""
         opt, m, ar, N = self.opt, self.model, slot.arena, self.N
         version = getattr(m, "bitfield_version", 0)
         if self.occ_index is not None and version != self._occ_version:      # the bitfield was re-packed
             rb.build_occupancy_index(m.density_bitfield, m.cascade, m.grid_size, self.occ_index)
             self._occ_version = version
-        eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train, N, m.min_near, slot.nears, slot.fars)
+        eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train if aabb is None else aabb, N, m.min_near, slot.nears,
+                                 slot.fars)
         rb.march_rays_train_arena(rays_o, rays_d, None, m.density_bitfield, m.real_bound, opt.contract, opt.dt_gamma,
                                   opt.max_steps, N, m.cascade, m.grid_size, slot.nears, slot.fars, noises, ar.t_scratch,
                                   self.cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, self.occ_index,
                                   ar.chain)
+        if not plan:
+            return
         # reset the bookkeeping of the binned table backward for this batch (stage 1: plan); the encoder's forward
         # pass counts the records per chunk while it has the rows in registers, a scan (stage 2) follows it
         gb.grid_backward_binned_prepare(None, 0.0, m.grid_encoder.offsets, self.rows, ar.counter, self.cap, self.L,
@@ -553,6 +557,71 @@ class FusedTrainer:
                       + (f" (ARENA OVERFLOW: {needed} > {self.cap})" if needed > self.cap else ""), flush=True)
 
     @torch.no_grad()
-    def evaluate(self, dataset, max_views=None, chunk=1 << 16):
+    def render_rays(self, rays_o, rays_d, bg_const=0.0):
+        """Images for evaluation out of the TRAINING kernels, forward only: per block of N rays one chain-parallel march
+        (no jitter), slab encoder, fused MLP, wave compositor -- instead of the reference's alive-ray loop
+        (renderer.py:573-616: up to max_steps rounds of march_rays / field / composite_rays with a host sync each).
+        Same sample positions, same T_thresh rule; ~ 10 x faster.  Returns (image [T,3], overflowed: bool)."""
+        opt, m, N, cap = self.opt, self.model, self.N, self.cap
+        if self._eval_slot is None:
+            chain_cap = self.slots[0].arena.chain[0].shape[0] if self.slots[0].arena.chain is not None else 0
+            self._eval_slot = _Slot(N, opt.max_steps, cap, self.device, chain_cap)
+            self._eval_slot.noises.zero_()
+        slot, ar = self._eval_slot, self._eval_slot.arena
+        mb.prepare(self.weights, self.mlp_image)
+        total = rays_o.shape[0]
+        out = torch.empty(total, 3, device=self.device)
+        # image rays are coherent: a block of N neighbouring pixels can need more samples than the arena holds (training
+        # batches are random pixels, most of which miss the object).  So a block carries `real` rays and N - real rays
+        # that miss the volume; `real` halves when a block overflows and recovers when blocks are light (one 16-byte
+        # read of the sample counter per block).
+        miss_o = torch.tensor([0.0, 0.0, 1e3 * m.bound], device=self.device)
+        miss_d = torch.tensor([0.0, 0.0, 1.0], device=self.device)
+        real, s = N, 0
+        while s < total:
+            n = min(real, total - s)
+            slot.rays_o[:n].copy_(rays_o[s:s + n])
+            slot.rays_d[:n].copy_(rays_d[s:s + n])
+            if n < N:
+                slot.rays_o[n:] = miss_o
+                slot.rays_d[n:] = miss_d
+            self.march(slot, slot.rays_o, slot.rays_d, slot.noises, aabb=m.aabb_infer, plan=False)
+            needed = int(ar.counter[1])                                     # host read
+            if needed > cap:
+                if real == 1:
+                    return out, True
+                real = max(1, real // 2)
+                continue
+            eb.grid_encode_forward_slab(ar.xyzs, m.bound, self.table, m.grid_encoder.offsets, self.enc, None, ar.counter,
+                                        cap, cap, self.L, self.L, self.S, self.H)
+            mb.forward(self.enc, cap, ar.dirs, ar.counter, cap, self.mlp_image, self.sigma, self.rgb)
+            eb.composite_rays_train_forward(self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.weights_buf,
+                                            self.ws, self.depth, self.image)
+            out[s:s + n] = self.image[:n] + (1.0 - self.ws[:n, None]) * bg_const
+            s += n
+            if needed < cap // 4 and real < N:
+                real = min(N, real * 2)
+        return out, False
+
+    @torch.no_grad()
+    def evaluate(self, dataset, max_views=None, chunk=1 << 16, fast=True):
+        """PSNR over held-out views (train_utils.py:221-233).  fast: render with render_rays; a view whose samples do
+        not fit the arena falls back to the reference-shaped inference loop."""
+        from . import utils
         from .trainer import Trainer
-        return Trainer.evaluate(self, dataset, max_views, chunk)
+        if not fast or self.opt.background == "random":
+            return Trainer.evaluate(self, dataset, max_views, chunk)
+        self.model.eval()
+        meter = utils.PSNRMeter()
+        n = len(dataset) if max_views is None else min(max_views, len(dataset))
+        for v in range(n):
+            data = dataset.view(v)
+            pred, overflow = self.render_rays(data["rays_o"].contiguous(), data["rays_d"].contiguous(), 0.0)
+            if overflow:
+                preds = [self.model.render(data["rays_o"][s:s + chunk], data["rays_d"][s:s + chunk], bg_color=0,
+                                           perturb=False)["image"] for s in range(0, pred.shape[0], chunk)]
+                pred = torch.cat(preds, 0)
+            img = data["images"]
+            gt = img[..., :3] * img[..., 3:] if img.shape[-1] == 4 else img
+            meter.update(pred.view(data["H"], data["W"], 3).clamp(0, 1), gt)
+        return meter.measure()

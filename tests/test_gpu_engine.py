@@ -543,3 +543,30 @@ def test_fused_compositor_step_is_the_two_calls(lib, T_thresh, random_bg):
     np.testing.assert_allclose(float(lo_a), float(lo_b), rtol=1e-6)
     live = gs_a[gs_a != 9.0]                       # rows of some ray (the kernels write every sample of a live ray)
     assert float(lo_a) > 0 and live.numel() > 0 and float(live.abs().sum()) > 0
+
+
+def test_fast_evaluation_renders_what_the_inference_loop_renders(lib):
+    """FusedTrainer.render_rays (training kernels, forward only, adaptive block size for coherent image rays) against the
+    reference-shaped alive-ray loop on the same model: same image to 1e-3, same PSNR; training is undisturbed."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=1024, iters=500, fused_mlp=True)
+    dev_ = torch.device("cuda")
+    data = SyntheticDataset(opt, dev_, "train", n_views=8, H=128, W=128)
+    val = SyntheticDataset(opt, dev_, "val", n_views=2, H=160, W=160)
+    eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 64)   # small arena: blocks shrink
+    eng.train(300)
+    d = val.view(0)
+    eng.model.eval()
+    with torch.no_grad():
+        ref = eng.model.render(d["rays_o"], d["rays_d"], bg_color=0, perturb=False)["image"]
+    img, overflow = eng.render_rays(d["rays_o"].contiguous(), d["rays_d"].contiguous(), 0.0)
+    assert not overflow
+    assert float((img - ref).abs().max()) < 2e-3 and float(ref.max()) > 0.2
+    assert abs(eng.evaluate(val, fast=True) - eng.evaluate(val, fast=False)) < 0.02
+    before = eng.global_step
+    eng.train(5)
+    assert eng.global_step == before + 5 and torch.isfinite(eng.loss).all()
