@@ -205,6 +205,9 @@ def main():
         trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed, capacity=args.arena or args.rays * 160)
     else:
         trainer = Trainer(opt, model, data, device=dev)
+    # the reference's -O preset marks cells no training camera sees as never-to-sample (train_utils.py: mark_untrained)
+    trainer.model.mark_untrained_grid(data)
+    untrained_cells = int((trainer.model.density_grid < 0).sum())
 
     # set before the step is captured into graphs: the engine keeps the probed entry point out of them
     arg_idx, bytes_per_sample = ROOFLINE_KERNELS[args.roofline_kernel]
@@ -314,7 +317,7 @@ def main():
                        "graph": bool(fused and trainer.use_graph), "prefetch": bool(fused and trainer.prefetch),
                        "device_sampler": bool(fused and trainer.device_sampler),
                        "host_enqueue_ms_per_step": round(host / max(args.steps, 1) * 1e3, 4),
-                       "arena_capacity": trainer.cap if fused else 0, "arena_overflow": bool(fused and overflow)},
+                       "untrained_cells": untrained_cells, "arena_capacity": trainer.cap if fused else 0, "arena_overflow": bool(fused and overflow)},
             "roofline": roof, "roofline_forward": roof_fwd, "cpu_baseline": cpu,
         }
         if psnr is not None:
