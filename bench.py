@@ -49,6 +49,11 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29
 # MI355X guide prescribes): 469 MB / 204 800.  rocprofv3's counter mode cannot run this script (it crashes in the
 # profiler's dispatch hook), so the figure is carried over from tools/grid_bench.py, which drives the same kernels.
 PMC_TRAFFIC_BYTES_PER_SAMPLE = {"ngp_x_grid_backward_binned": 2290.0}
+# with Adam fused into the reduce kernel (one GPU) the gradient's accumulate traffic disappears and the optimiser state
+# appears: bin_reduce_kernel<1> measures FETCH 2 x 156.1 MB (streaming loads, doubled as above) + WRITE 143.1 MB = 455 MB
+# on 204 800 samples, of which 24 B x 12.2 M table entries = 293 MB do not depend on the sample count:
+# (count 10.3 + fill 200.3 + records read back 162.6) MB / 204 800 = 1 822 B/sample, plus 293 MB per launch
+PMC_FUSED_TRAFFIC_BYTES_PER_SAMPLE = 1822.0
 # slab forward, same passes: FETCH 63.7 MB (8-byte gathers, counted as reported) + WRITE 28.0 MB on 204 800 samples
 PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 448.0
 FWD_BYTES_PER_SAMPLE = 12 + 16 * (64 + 8)      # 1164 B/sample, SURVEY.md section 8d
@@ -280,6 +285,8 @@ def main():
             grid_only = units * bytes_per_sample / ksec / 1e9
             ach = (units * bytes_per_sample + launches * opt_bytes) / ksec / 1e9
             per_sample = PMC_TRAFFIC_BYTES_PER_SAMPLE.get(args.roofline_kernel)
+            if fused_adam:
+                per_sample = PMC_FUSED_TRAFFIC_BYTES_PER_SAMPLE
             traffic = round(per_sample * units / launches + opt_bytes) if per_sample else None
             roof = {"bound": "hbm", "kernel": args.roofline_kernel + (" + Adam on the table (fused)" if fused_adam else ""),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,

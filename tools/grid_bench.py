@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--per-ray", type=int, default=50)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--fused-adam", action="store_true", help="apply with Adam inside the reduce kernel (single GPU step)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     _lib.load()
@@ -48,11 +49,16 @@ def main():
     ws = torch.empty(gb.backward_workspace_bytes(B, L, rows), dtype=torch.uint8, device=dev)
     cnt = torch.tensor([B, B, 0, 0], dtype=torch.int32, device=dev)
 
+    t_m, t_v = torch.zeros_like(table), torch.zeros_like(table)
+    hyper = torch.tensor([1e-6, 0.1, 31.6, 0.0], device=dev)       # tiny lr: the table stays where it is
+    adam = (table, t_m, t_v, hyper, 0.9, 0.999, 1e-15) if args.fused_adam else None
+
     def once():
         gb.grid_backward_binned_prepare(None, 0.0, offsets, rows, cnt, B, L, L, S, H, ws, merge_max_res=414, stage=1)
         eb.grid_encode_forward_slab(xyz, 1.0, table, offsets, enc, x01, cnt, B, B, L, L, S, H, binned_workspace=ws)
-        gb.grid_backward_binned_prepare(None, 0.0, offsets, rows, cnt, B, L, L, S, H, ws, stage=2)
-        gb.grid_backward_binned_apply(denc, x01, offsets, grad, cnt, B, B, L, L, S, H, ws)
+        gb.grid_backward_binned_prepare(None, 0.0, offsets, rows, cnt, B, L, L, S, H, ws, stage=2,
+                                        single_segment=args.fused_adam)
+        gb.grid_backward_binned_apply(denc, x01, offsets, grad, cnt, B, B, L, L, S, H, ws, adam=adam)
 
     for _ in range(3):
         once()
