@@ -157,6 +157,12 @@ def main():
                          "quoted at that point of the 5000-iteration schedule (learned occupancy grid), and the PSNR is "
                          "evaluated right after the timed steps")
     ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--background", default="random", choices=["black", "white", "random"],
+                    help="training background (main.py:46).  random (per-ray colours, what torch-ngp trains RGBA "
+                         "NeRF-synthetic data with) is the default here: against the reference's default, black, dark fog in "
+                         "empty space is invisible to the loss, and how much of it survives decides samples per ray")
+    ap.add_argument("--bound", type=float, default=1.0,
+                    help="scene bound (1 = the benchmark framing; 2 = the reference's default, two cascades)")
     ap.add_argument("--views", type=int, default=100)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--roofline-kernel", default="ngp_x_grid_backward_binned", choices=sorted(ROOFLINE_KERNELS))
@@ -198,7 +204,7 @@ def main():
     _lib.load()
     torch.manual_seed(0)
 
-    opt = Options(bound=1.0, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena,
+    opt = Options(bound=args.bound, background=args.background, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena,
                   fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
                   aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
@@ -207,7 +213,7 @@ def main():
     model = NeRFNetwork(opt)
     fused = not (args.autograd or args.torch_mlp)
     if fused:
-        trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed, capacity=args.arena or args.rays * 160)
+        trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed, capacity=args.arena or None)    # default: rays * 160 * ceil(bound)
     else:
         trainer = Trainer(opt, model, data, device=dev)
     # the reference's -O preset marks cells no training camera sees as never-to-sample (train_utils.py: mark_untrained)
@@ -315,7 +321,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.torch_mlp else "f32 (grid/SH/march/composite) + f16-MFMA/f32-acc MLP", "data": "synthetic",
-            "config": {"workload": "configs[1]: Lego-style 800x800 procedural scene, hashgrid L=16 F=2 T=2^19, "
+            "config": {"bound": args.bound, "background": args.background, "workload": "configs[1]: Lego-style 800x800 procedural scene, hashgrid L=16 F=2 T=2^19, "
                                    "density-grid march (cuda_ray path), 4096 rays/batch/GPU, "
                                    + ("fp32 nn.Linear MLPs" if args.torch_mlp else "fused tiny-MLP (configs[2])"),
                        "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
