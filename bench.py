@@ -146,6 +146,89 @@ def cpu_baseline(opt, n_rays, steps, seed=0):
                       f"oracle kernels + torch-CPU MLP/Adam, {dt:.1f} s"}
 
 
+def run_config(args, bound, background, rank, world, dev, probe_on=True):
+    """Train one configuration up to the timed region, time K steps, evaluate PSNR.  Returns a dict of raw results."""
+    opt = Options(bound=bound, background=background, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena,
+                  fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
+                  capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
+                  aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
+                  dp_rehearsal=args.dp_rehearsal, graph_collective=args.graph_collective)
+    data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
+    model = NeRFNetwork(opt)
+    fused = not (args.autograd or args.torch_mlp)
+    if fused:
+        trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed, capacity=args.arena or None)    # default: rays * 160 * ceil(bound)
+    else:
+        trainer = Trainer(opt, model, data, device=dev)
+    # the reference's -O preset marks cells no training camera sees as never-to-sample (train_utils.py: mark_untrained)
+    trainer.model.mark_untrained_grid(data)
+    untrained_cells = int((trainer.model.density_grid < 0).sum())
+
+    # set before the step is captured into graphs: the engine keeps the probed entry point out of them
+    arg_idx, bytes_per_sample = ROOFLINE_KERNELS[args.roofline_kernel]
+    symbols = (args.roofline_kernel,)
+    if args.roofline_kernel == "ngp_x_grid_backward_binned":
+        symbols = ("ngp_x_grid_backward_binned_apply", "ngp_x_grid_backward_binned_prepare")
+    # the north star also names the encoder's forward: timed the same way, reported as roofline_forward
+    fwd_symbol = "ngp_x_grid_encode_forward_slab"
+    probed = symbols + ((fwd_symbol,) if fused and fwd_symbol not in symbols else ())
+    _lib.set_probe(None if (args.no_probe or not probe_on) else probed, arg_idx, every=args.probe_every)
+    trainer.train(args.burnin)
+    trainer.train(args.warmup)
+
+    # ---- timed region -------------------------------------------------------------------------
+    parallel.barrier()
+    torch.cuda.synchronize()
+    _lib.probe_reset()
+    seen0 = int(trainer.samples_seen) if fused else 0
+    t0 = time.perf_counter()
+    samples = 0
+    host = 0.0
+    for _ in range(args.steps):
+        h0 = time.perf_counter()
+        trainer.train_step()
+        host += time.perf_counter() - h0
+        if not fused:
+            samples += trainer.last_num_points      # (host value of the per-op path; the fused step never syncs)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    probe = _lib.probe_results(symbols)
+    probe_fwd = _lib.probe_results((fwd_symbol,)) if fwd_symbol in probed else (0, 0, 0.0)
+    _lib.set_probe(None)
+    overflow = False
+    if fused:
+        samples = int(trainer.samples_seen) - seen0
+        overflow = int(trainer.arena.counter[1]) > trainer.cap
+        # live samples per launch (the launch argument is the arena capacity), scaled to the launches measured
+        probe = (probe[0], samples / max(args.steps, 1) * probe[0], probe[2])
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    in_sync = None
+    if world > 1 and fused:
+        # replicas must hold identical parameters and the same occupancy bitfield after the timed steps
+        sums = torch.stack([trainer.table.double().sum(), trainer.w_flat.double().sum(),
+                            model.density_bitfield.double().sum()])
+        lo, hi = sums.clone(), sums.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
+
+    psnr = None
+    if args.psnr_iters > trainer.global_step:
+        trainer.train(args.psnr_iters - trainer.global_step)
+    if args.psnr_iters > 0:
+        val = SyntheticDataset(opt, dev, "val", n_views=4, H=args.res, W=args.res)
+        psnr = trainer.evaluate(val)
+
+    return dict(dt=dt, host=host, samples=samples, probe=probe, probe_fwd=probe_fwd, probed=probed, fwd_symbol=fwd_symbol,
+                bytes_per_sample=bytes_per_sample, in_sync=in_sync, psnr=psnr, trainer=trainer, fused=fused,
+                untrained_cells=untrained_cells, overflow=bool(fused and overflow), model=model)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,7 +266,7 @@ def main():
     ap.add_argument("--no-fuse-adam", action="store_true",
                     help="separate Adam pass over the table (what data-parallel ranks run), on one GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--grad-wire", default="bf16", choices=["f32", "bf16"],
+    ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"],
                     help="data parallel: wire format of the table-gradient all-reduce")
     ap.add_argument("--graph-collective", action="store_true",
                     help="data parallel: capture the RCCL all-reduce inside the step graph (experimental, off by default)")
@@ -191,6 +274,8 @@ def main():
                     help="one GPU: run the data-parallel step (separate Adam, RCCL collectives on a one-rank group)")
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
     ap.add_argument("--autograd", action="store_true", help="per-op autograd path (Trainer) instead of the fused step")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the two secondary rows (reference defaults: black background; bound 2 + black)")
     args = ap.parse_args()
     if args.burnin < 0:
         args.burnin = max((args.psnr_iters or 5000) - args.warmup - args.steps, 300)
@@ -204,81 +289,33 @@ def main():
     _lib.load()
     torch.manual_seed(0)
 
-    opt = Options(bound=args.bound, background=args.background, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena,
-                  fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
-                  capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
-                  aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
-                  dp_rehearsal=args.dp_rehearsal, graph_collective=args.graph_collective)
-    data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
-    model = NeRFNetwork(opt)
-    fused = not (args.autograd or args.torch_mlp)
-    if fused:
-        trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed, capacity=args.arena or None)    # default: rays * 160 * ceil(bound)
-    else:
-        trainer = Trainer(opt, model, data, device=dev)
-    # the reference's -O preset marks cells no training camera sees as never-to-sample (train_utils.py: mark_untrained)
-    trainer.model.mark_untrained_grid(data)
-    untrained_cells = int((trainer.model.density_grid < 0).sum())
-
-    # set before the step is captured into graphs: the engine keeps the probed entry point out of them
-    arg_idx, bytes_per_sample = ROOFLINE_KERNELS[args.roofline_kernel]
-    symbols = (args.roofline_kernel,)
-    if args.roofline_kernel == "ngp_x_grid_backward_binned":
-        symbols = ("ngp_x_grid_backward_binned_apply", "ngp_x_grid_backward_binned_prepare")
-    # the north star also names the encoder's forward: timed the same way, reported as roofline_forward
-    fwd_symbol = "ngp_x_grid_encode_forward_slab"
-    probed = symbols + ((fwd_symbol,) if fused and fwd_symbol not in symbols else ())
-    _lib.set_probe(None if args.no_probe else probed, arg_idx, every=args.probe_every)
-    trainer.train(args.burnin)
-    trainer.train(args.warmup)
-
-    # ---- timed region -------------------------------------------------------------------------
-    parallel.barrier()
-    torch.cuda.synchronize()
-    _lib.probe_reset()
-    seen0 = int(trainer.samples_seen) if fused else 0
-    t0 = time.perf_counter()
-    samples = 0
-    host = 0.0
-    for _ in range(args.steps):
-        h0 = time.perf_counter()
-        trainer.train_step()
-        host += time.perf_counter() - h0
-        if not fused:
-            samples += trainer.last_num_points      # (host value of the per-op path; the fused step never syncs)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    dt = time.perf_counter() - t0
-    probe = _lib.probe_results(symbols)
-    probe_fwd = _lib.probe_results((fwd_symbol,)) if fwd_symbol in probed else (0, 0, 0.0)
-    _lib.set_probe(None)
-    if fused:
-        samples = int(trainer.samples_seen) - seen0
-        overflow = int(trainer.arena.counter[1]) > trainer.cap
-        # live samples per launch (the launch argument is the arena capacity), scaled to the launches measured
-        probe = (probe[0], samples / max(args.steps, 1) * probe[0], probe[2])
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-
-    in_sync = None
-    if world > 1 and fused:
-        # replicas must hold identical parameters and the same occupancy bitfield after the timed steps
-        sums = torch.stack([trainer.table.double().sum(), trainer.w_flat.double().sum(),
-                            model.density_bitfield.double().sum()])
-        lo, hi = sums.clone(), sums.clone()
-        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        in_sync = bool(torch.equal(lo, hi))
-
-    psnr = None
-    if args.psnr_iters > trainer.global_step:
-        trainer.train(args.psnr_iters - trainer.global_step)
-    if args.psnr_iters > 0:
-        val = SyntheticDataset(opt, dev, "val", n_views=4, H=args.res, W=args.res)
-        psnr = trainer.evaluate(val)
-
+    res = run_config(args, args.bound, args.background, rank, world, dev)
+    dt, host, samples, probe, probe_fwd = res["dt"], res["host"], res["samples"], res["probe"], res["probe_fwd"]
+    probed, fwd_symbol, bytes_per_sample, in_sync, psnr = (res["probed"], res["fwd_symbol"], res["bytes_per_sample"],
+                                                           res["in_sync"], res["psnr"])
+    trainer, fused, untrained_cells, overflow = res["trainer"], res["fused"], res["untrained_cells"], res["overflow"]
+    # what the JSON line needs from the primary run's trainer (it is freed before the secondary runs)
+    tinfo = {"fuse_adam": bool(fused and getattr(trainer, "fuse_adam", False)),
+             "table_numel": int(trainer.table.numel()) if fused else 0,
+             "graph": bool(fused and trainer.use_graph), "prefetch": bool(fused and trainer.prefetch),
+             "device_sampler": bool(fused and trainer.device_sampler), "cap": trainer.cap if fused else 0,
+             "step": trainer.global_step}
+    del res, trainer
+    # the reference's own defaults as secondary rows (main.py:31,46: --bound 2, black background): same schedule and
+    # timing protocol, no probes.  The headline stays the benchmark framing (bound 1, random background).
+    secondary = {}
+    if not args.no_secondary:
+        for name, (b2, bg2) in {"black_background": (args.bound, "black"), "bound2_black": (2.0, "black")}.items():
+            if (b2, bg2) == (args.bound, args.background):
+                continue
+            torch.cuda.empty_cache()
+            r2 = run_config(args, b2, bg2, rank, world, dev, probe_on=False)
+            secondary[name] = {"value": round(world * args.rays * args.steps / r2["dt"], 1), "unit": "rays/s",
+                               "ms_per_step": round(r2["dt"] / args.steps * 1e3, 4), "bound": b2, "background": bg2,
+                               "samples_per_step": round(r2["samples"] / max(args.steps, 1)),
+                               "psnr": None if r2["psnr"] is None else round(float(r2["psnr"]), 3),
+                               "arena_overflow": r2["overflow"], "untrained_cells": r2["untrained_cells"]}
+            del r2
     if rank == 0:
         launches, units, ksec = probe
         roof = None
@@ -286,8 +323,8 @@ def main():
             # one GPU: the same launch also runs Adam on the table (inside the reduce kernel): its algorithmic bytes are
             # the read + write of parameter, exp_avg and exp_avg_sq -- 24 B per table entry, the gradient never
             # reaches HBM (SURVEY 8d prices a separate optimiser pass at 28 B)
-            fused_adam = fused and getattr(trainer, "fuse_adam", False) and args.roofline_kernel == "ngp_x_grid_backward_binned"
-            opt_bytes = 24 * trainer.table.numel() if fused_adam else 0
+            fused_adam = tinfo["fuse_adam"] and args.roofline_kernel == "ngp_x_grid_backward_binned"
+            opt_bytes = 24 * tinfo["table_numel"] if fused_adam else 0
             grid_only = units * bytes_per_sample / ksec / 1e9
             ach = (units * bytes_per_sample + launches * opt_bytes) / ksec / 1e9
             per_sample = PMC_TRAFFIC_BYTES_PER_SAMPLE.get(args.roofline_kernel)
@@ -327,14 +364,15 @@ def main():
                        "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
                        "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
                        "parallelism": f"dp{world}", "grad_wire": args.grad_wire if (world > 1 or args.dp_rehearsal) else None, "replicas_in_sync": in_sync, "step": "fused" if fused else "autograd",
-                       "graph": bool(fused and trainer.use_graph), "prefetch": bool(fused and trainer.prefetch),
-                       "device_sampler": bool(fused and trainer.device_sampler),
+                       "graph": tinfo["graph"], "prefetch": tinfo["prefetch"],
+                       "device_sampler": tinfo["device_sampler"],
                        "host_enqueue_ms_per_step": round(host / max(args.steps, 1) * 1e3, 4),
-                       "untrained_cells": untrained_cells, "arena_capacity": trainer.cap if fused else 0, "arena_overflow": bool(fused and overflow)},
+                       "untrained_cells": untrained_cells, "arena_capacity": tinfo["cap"], "arena_overflow": bool(fused and overflow)},
             "roofline": roof, "roofline_forward": roof_fwd, "cpu_baseline": cpu,
+            "secondary": secondary or None,
         }
         if psnr is not None:
-            line["psnr"] = {"iters": trainer.global_step, "value": round(float(psnr), 3)}
+            line["psnr"] = {"iters": tinfo["step"], "value": round(float(psnr), 3)}
         print(json.dumps(line), flush=True)
     if parallel.is_dist():
         torch.distributed.destroy_process_group()

@@ -49,6 +49,11 @@ class FusedTrainer:
 
     def __init__(self, opt, model, dataset, device="cuda", seed=0, capacity=None, betas=(0.9, 0.999), eps=1e-15):
         assert opt.cuda_ray and not opt.rfield and opt.pose_opt == "none", "fused step: density-grid path only"
+        # terms of the reference's train_step (train_utils.py:544-564) this step does not compute: refuse them instead of
+        # silently training a different objective than the per-op Trainer would with the same Options
+        unsupported = [k for k in ("lambda_entropy", "lambda_orientation", "lambda_distort") if getattr(opt, k, 0) > 0]
+        assert not unsupported, f"fused step: {unsupported} not implemented here -- use nerf.trainer.Trainer"
+        assert not getattr(opt, "fp16", False) or opt.loss_scale > 0, "fused step: --fp16 maps to the static loss scale"
         self.opt, self.model, self.data, self.device = opt, model.to(device), dataset, torch.device(device)
         opt.fused_mlp = True
         assert model._fused(), "fused step needs the default field configuration"
@@ -609,7 +614,7 @@ class FusedTrainer:
         not fit the arena falls back to the reference-shaped inference loop."""
         from . import utils
         from .trainer import Trainer
-        if not fast or self.opt.background == "random":
+        if not fast:        # (the training background does not matter here: evaluation composites over a constant 0)
             return Trainer.evaluate(self, dataset, max_views, chunk)
         self.model.eval()
         meter = utils.PSNRMeter()

@@ -64,7 +64,8 @@ class Options:
     native_grid_refresh: bool = True  # fused engine: density-grid refresh as device kernels (no host syncs)
     graph_collective: bool = False  # data parallel: capture the gradient all-reduce inside the step graph (experimental)
     dp_rehearsal: bool = False    # run the data-parallel step on ONE rank (needs an initialised process group)
-    grad_wire: str = "bf16"       # data parallel: wire format of the table-gradient all-reduce (f32 | bf16)
+    grad_wire: str = "f32"        # data parallel: wire format of the gradient exchange (f32 | bf16; bf16 is an opt-in:
+                                  # the cross-rank sum is then formed in bfloat16, narrower than anything the reference does)
     aux_stream: bool = False      # fused engine: MLP-weight tail (dW reduction, Adam, f16 image) on a third stream
                                   # (measured slower: the fork/join costs more than the ~20 us it takes off the main stream)
     fuse_adam: bool = True        # fused engine, one rank: Adam on the table inside the gradient reduction kernel

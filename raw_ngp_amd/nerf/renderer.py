@@ -22,63 +22,77 @@ def custom_meshgrid(*args):
 
 # ----------------------------------------------------------------------------- helper functions
 
-@torch.autocast("cuda", enabled=False)
+def _fp32(fn):
+    """The reference runs these helpers with autocast switched off (`@torch.cuda.amp.autocast(enabled=False)`)."""
+    return torch.autocast("cuda", enabled=False)(fn)
+
+
+@_fp32
 def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.05):
-    """Slab test in torch (the one run_cuda actually uses, renderer.py:526-527): returns [N,1] tensors,
-    1e9 on a miss, `/(d + 1e-15)`."""
-    tmin = (aabb[:3] - rays_o) / (rays_d + 1e-15)
-    tmax = (aabb[3:] - rays_o) / (rays_d + 1e-15)
-    near = torch.where(tmin < tmax, tmin, tmax).amax(dim=-1, keepdim=True)
-    far = torch.where(tmin > tmax, tmin, tmax).amin(dim=-1, keepdim=True)
-    miss = far < near
-    big = torch.full_like(near, 1e9)
-    near = torch.where(miss, big, near)
-    far = torch.where(miss, big, far)
-    return torch.clamp(near, min=min_near), far
+    """Ray / axis-aligned-box slab test (semantics of reference renderer.py:139-158, the torch flavour `run_cuda`
+    uses): per axis the two plane parameters, entry = latest of the per-axis earlier ones, exit = earliest of the
+    later ones; a miss is reported as near = far = 1e9; directions are offset by 1e-15 before dividing.
+    Returns ([N,1], [N,1]) with near clamped to `min_near`."""
+    denom = rays_d + 1e-15                          # (a true division: a reciprocal-multiply differs in the last bit)
+    lo, hi = (aabb[:3] - rays_o) / denom, (aabb[3:] - rays_o) / denom
+    swap = ~(lo < hi)                               # comparison-based (not fmin/fmax): NaN handling as the reference
+    entry = torch.where(swap, hi, lo).amax(-1, keepdim=True)
+    swap = ~(lo > hi)
+    exit_ = torch.where(swap, hi, lo).amin(-1, keepdim=True)
+    hit = ~(exit_ < entry)
+    entry = torch.where(hit, entry, entry.new_tensor(1e9))
+    exit_ = torch.where(hit, exit_, exit_.new_tensor(1e9))
+    return entry.clamp(min=min_near), exit_
 
 
-@torch.autocast("cuda", enabled=False)
+def _linf_pick(x):
+    """|x|_inf per point and a one-hot mask of the coordinate that attains it (first one on ties, as Tensor.max)."""
+    mag, arg = x.abs().max(dim=-1, keepdim=True)
+    onehot = torch.arange(x.shape[-1], device=x.device).expand_as(x) == arg
+    return mag, onehot
+
+
+@_fp32
 def contract(x):
-    """MeRF-style L-inf contraction of [..., C] points: identity inside the unit cube."""
-    shape, C = x.shape[:-1], x.shape[-1]
-    x = x.view(-1, C)
-    mag, idx = x.abs().max(1, keepdim=True)
-    scale = 1 / mag.repeat(1, C)
-    scale.scatter_(1, idx, (2 - 1 / mag) / mag)
-    return torch.where(mag < 1, x, x * scale).view(*shape, C)
+    """L-inf scene contraction (reference renderer.py:77-87): the unit cube maps to itself; outside it the dominant
+    coordinate m becomes sign(m)(2 - 1/|m|) and the others are divided by |m|, so everything lands in [-2, 2]^C."""
+    flat = x.reshape(-1, x.shape[-1])
+    mag, dominant = _linf_pick(flat)
+    factor = torch.where(dominant, (2 - 1 / mag) / mag, 1 / mag)
+    return torch.where(mag < 1, flat, flat * factor).reshape(x.shape)
 
 
-@torch.autocast("cuda", enabled=False)
+@_fp32
 def uncontract(z):
-    shape, C = z.shape[:-1], z.shape[-1]
-    z = z.view(-1, C)
-    mag, idx = z.abs().max(1, keepdim=True)
-    scale = 1 / (2 - mag.repeat(1, C)).clamp(min=1e-8)
-    scale.scatter_(1, idx, 1 / (2 * mag - mag * mag).clamp(min=1e-8))
-    return torch.where(mag < 1, z, z * scale).view(*shape, C)
+    """Inverse of `contract` (reference renderer.py:89-99), with the reference's 1e-8 floors on the denominators."""
+    flat = z.reshape(-1, z.shape[-1])
+    mag, dominant = _linf_pick(flat)
+    factor = torch.where(dominant, 1 / (2 * mag - mag * mag).clamp(min=1e-8), 1 / (2 - mag).clamp(min=1e-8))
+    return torch.where(mag < 1, flat, flat * factor).reshape(z.shape)
 
 
-@torch.autocast("cuda", enabled=False)
+@_fp32
 def sample_pdf(bins, weights, T, perturb=False):
-    """Inverse-CDF resampling: bins [N,T0+1], weights [N,T0] -> [N,T]."""
-    N, T0 = weights.shape
-    weights = weights + 0.01
-    pdf = weights / weights.sum(-1, keepdim=True)
-    cdf = torch.cumsum(pdf, -1).clamp(max=1)
-    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
-    u = torch.linspace(0.5 / T, 1 - 0.5 / T, steps=T).to(weights.device).expand(N, T)
+    """Resample T positions from a piecewise-constant density by inverting its CDF (reference renderer.py:102-136):
+    bins [N, T0+1] are interval edges, weights [N, T0] their masses (+0.01 each before normalising); the T quantiles
+    are the centres of T equal slices of [0,1], each jittered inside its slice when `perturb`."""
+    n_rays, n_int = weights.shape
+    mass = weights + 0.01
+    cdf = (mass / mass.sum(-1, keepdim=True)).cumsum(-1).clamp(max=1)
+    cdf = torch.nn.functional.pad(cdf, (1, 0))                                   # cdf at the T0+1 edges, 0 first
+    # slice centres through linspace, like the reference: (arange + 0.5) / T rounds differently in the last bit
+    q = torch.linspace(0.5 / T, 1 - 0.5 / T, T, device=weights.device, dtype=cdf.dtype).expand(n_rays, T)
     if perturb:
-        u = u + (torch.rand_like(u) - 0.5) / T
-    u = u.contiguous()
-    inds = torch.searchsorted(cdf, u, right=True)
-    below, above = torch.clamp(inds - 1, 0, T0), torch.clamp(inds, 0, T0)
-    cdf0, cdf1 = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
-    b0, b1 = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
-    frac = torch.clamp(torch.nan_to_num((u - cdf0) / (cdf1 - cdf0)), 0, 1)
-    return b0 + frac * (b1 - b0)
+        q = q + (torch.rand_like(q) - 0.5) / T
+    hi = torch.searchsorted(cdf, q.contiguous(), right=True).clamp(0, n_int)     # first edge with cdf > q
+    lo = (hi - 1).clamp(0, n_int)
+    c_lo, c_hi = cdf.gather(-1, lo), cdf.gather(-1, hi)
+    e_lo, e_hi = bins.gather(-1, lo), bins.gather(-1, hi)
+    w = ((q - c_lo) / (c_hi - c_lo)).nan_to_num().clamp(0, 1)                   # 0/0 on empty intervals -> 0
+    return e_lo + w * (e_hi - e_lo)
 
 
-@torch.autocast("cuda", enabled=False)
+@_fp32
 def proposal_loss(all_bins, all_weights):
     """Inter-level histogram bound of mip-NeRF 360 between the final level and each proposal."""
 

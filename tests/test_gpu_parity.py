@@ -113,9 +113,11 @@ def test_grid_backward(be, orc, case, binned, monkeypatch):
                                atol=2e-6 * max(scale, 1.0) * 8)
 
 
-def test_grid_tv_and_wd(be, orc):
-    D, C, L, H = 3, 2, 6, 4
-    offsets, S, table, _ = grid_setup(orc, D, C, L, H, 9, 48, 16)
+@pytest.mark.parametrize("D,C,L,H,log2_T,desired", [(3, 2, 6, 4, 9, 48), (2, 2, 8, 4, 10, 256), (3, 4, 4, 8, 12, 64),
+                                                     (2, 1, 5, 16, 8, 128)],
+                         ids=["D3C2", "D2C2", "D3C4", "D2C1"])
+def test_grid_tv_and_wd(be, orc, D, C, L, H, log2_T, desired):
+    offsets, S, table, _ = grid_setup(orc, D, C, L, H, log2_T, desired, 16)
     rng = np.random.default_rng(3)
     B = 4000
     x = rng.uniform(0, 1, (B, D)).astype(np.float32)
@@ -461,25 +463,38 @@ def test_composite_train_empty_and_overflow(be):
 
 # ----------------------------------------------------------------------------- inference pair
 
-def test_inference_pair(be, orc):
+INFER_CASES = [
+    # H, cascades, bound, contract, dt_gamma, n_step, T_thresh
+    (128, 1, 1.0, False, 0.0, 4, 1e-2),          # the Function's defaults
+    (128, 2, 2.0, False, 1.0 / 128, 8, 1e-8),    # reference default bound (2 cascades), cone stepping, the CLI's T_thresh
+    (64, 2, 4.0, True, 0.0, 2, 1e-4),            # contraction (query bound 2 -> 2 cascades, real bound 4)
+    (64, 3, 4.0, False, 1.0 / 256, 1, 1e-2),     # three cascades, one sample per round
+]
+
+
+@pytest.mark.parametrize("case", INFER_CASES, ids=lambda c: f"H{c[0]}C{c[1]}b{c[2]}c{int(c[3])}g{c[4] > 0}n{c[5]}")
+def test_inference_pair(be, orc, case):
+    H, C, bound, contract, dt_gamma, n_step, T_thresh = case
     rng = np.random.default_rng(9)
-    N, H, max_steps = 2000, 128, 1024
-    bits, _ = brick_bitfield(orc, H, seed=3)
-    o, d = make_rays(rng, N)
-    aabb = np.array([-1, -1, -1, 1, 1, 1], dtype=np.float32)
+    N, max_steps = 2000, 1024
+    bits, _ = brick_bitfield(orc, H, cascades=C, seed=3, fill=0.08)
+    o, d = make_rays(rng, N, radius=2.5 * bound if not contract else 3.0, jitter=0.6 * bound if not contract else 0.5)
+    aabb = np.array([-bound] * 3 + [bound] * 3, dtype=np.float32)
     nears, fars = orc.near_far_from_aabb(o, d, aabb, N, 0.05)
     alive = np.arange(N, dtype=np.int32)[::2].copy()
-    n_alive, n_step = alive.size, 4
+    n_alive = alive.size
     rays_t = nears.copy()
+    rays_t[::3] += np.float32(0.37 * bound)          # rays in different states of progress, like later rounds of the loop
     noises = rng.uniform(0, 1, n_alive).astype(np.float32)
-    rx, rd, rt = orc.march_rays(n_alive, n_step, alive, rays_t, o, d, 1.0, False, 0.0, max_steps, 1, H, bits, nears, fars,
-                                noises)
+    rx, rd, rt = orc.march_rays(n_alive, n_step, alive, rays_t, o, d, bound, contract, dt_gamma, max_steps, C, H, bits, nears,
+                                fars, noises)
+    assert (rt[:, 1] > 0).sum() > n_alive // 4 and (rt[:, 1] == 0).sum() > 0     # live samples and zero tails both occur
     M = n_alive * n_step
     xyzs = torch.zeros(M, 3, device="cuda")
     dirs = torch.zeros(M, 3, device="cuda")
     ts = torch.zeros(M, 2, device="cuda")
-    be.raymarching_backend.march_rays(n_alive, n_step, dev(alive), dev(rays_t), dev(o), dev(d), 1.0, False, 0.0, max_steps,
-                                      1, H, dev(bits), dev(nears), dev(fars), xyzs, dirs, ts, dev(noises))
+    be.raymarching_backend.march_rays(n_alive, n_step, dev(alive), dev(rays_t), dev(o), dev(d), bound, contract, dt_gamma,
+                                      max_steps, C, H, dev(bits), dev(nears), dev(fars), xyzs, dirs, ts, dev(noises))
     assert np.array_equal(host(xyzs), rx) and np.array_equal(host(dirs), rd) and np.array_equal(host(ts), rt)
 
     sig = (40.0 * np.exp(-4 * (rx ** 2).sum(1))).astype(np.float32)
@@ -488,9 +503,10 @@ def test_inference_pair(be, orc):
     dep = rng.uniform(0, 1, N).astype(np.float32)
     img = rng.uniform(0, 1, (N, 3)).astype(np.float32)
     r_alive, r_t, r_ws, r_dep, r_img = alive.copy(), rays_t.copy(), ws.copy(), dep.copy(), img.copy()
-    orc.composite_rays(n_alive, n_step, 1e-2, r_alive, r_t, sig, col, rt, r_ws, r_dep, r_img)
+    orc.composite_rays(n_alive, n_step, T_thresh, r_alive, r_t, sig, col, rt, r_ws, r_dep, r_img)
+    assert (r_alive < 0).sum() > 0 and (r_alive >= 0).sum() > 0                  # some rays die in this round, some go on
     g_alive, g_t, g_ws, g_dep, g_img = dev(alive), dev(rays_t), dev(ws), dev(dep), dev(img)
-    be.raymarching_backend.composite_rays(n_alive, n_step, 1e-2, g_alive, g_t, dev(sig), dev(col), ts, g_ws, g_dep, g_img)
+    be.raymarching_backend.composite_rays(n_alive, n_step, T_thresh, g_alive, g_t, dev(sig), dev(col), ts, g_ws, g_dep, g_img)
     assert np.array_equal(host(g_alive), r_alive)
     np.testing.assert_allclose(host(g_t), r_t, rtol=0, atol=0)
     np.testing.assert_allclose(host(g_ws), r_ws, rtol=2e-4, atol=2e-6)

@@ -1,0 +1,146 @@
+"""Host-side renderer pieces that sit on the HIP kernels: `mark_untrained_grid` (reference renderer.py:716-809) against
+a numpy restatement on cameras that see only part of the volume, and the non-`cuda_ray` sampler `run()`
+(renderer.py:405-513) with the HIP encoders at the shape of BASELINE configs[0] (200 x 200 views, hashgrid L=8 F=2)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from raw_ngp_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _untrained_reference(orc, poses, intr, H, cascade, bound, aabb, min_near, cam_near=None):
+    """numpy restatement of renderer.py:716-809: a cell (of any cascade) stays trainable when its centre lies inside the
+    training AABB (+- half a cell) and inside at least one camera frustum (+- one cell); float32 like the reference."""
+    f32 = np.float32
+    g = np.arange(H, dtype=np.int32)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    coords = np.stack([X.reshape(-1), Y.reshape(-1), Z.reshape(-1)], 1)
+    idx = orc.morton3D(coords.astype(np.int32)).astype(np.int64)
+    world = (f32(2) * coords.astype(f32) / f32(H - 1) - f32(1))                    # [-1, 1]
+    fx, fy, cx, cy = [f32(v) for v in intr]
+    kx, ky = cx / fx, cy / fy
+    R, t = poses[:, :3, :3].astype(f32), poses[:, :3, 3].astype(f32)
+    untrained = np.zeros((cascade, H ** 3), dtype=bool)
+    for cas in range(cascade):
+        b = f32(min(2 ** cas, bound))
+        half = f32(b / H)
+        p = world * (b - half)
+        in_aabb = np.all(p >= aabb[:3] - half, 1) & np.all(p <= aabb[3:] + half, 1)
+        seen = np.zeros(p.shape[0], dtype=bool)
+        for v in range(poses.shape[0]):
+            cam = (p - t[v]) @ R[v]                   # world -> camera (R is cam2world, rows = world axes)
+            z = -cam[:, 2]                            # the camera looks down -z
+            near = f32(min_near) if cam_near is None else f32(cam_near[v])
+            seen |= (z > near) & (np.abs(cam[:, 0]) < kx * z + half * 2) & (np.abs(cam[:, 1]) < ky * z + half * 2)
+        untrained[cas, idx] = ~(in_aabb & seen)
+    return untrained
+
+
+@pytest.mark.parametrize("bound,n_cams,shrink", [(1.0, 3, False), (2.0, 5, True)], ids=["bound1", "bound2-cropped"])
+def test_mark_untrained_grid_matches_restatement(lib, orc, bound, n_cams, shrink):
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import hemisphere_poses
+    H = 32
+    opt = Options(bound=bound, grid_size=H)
+    model = NeRFNetwork(opt).cuda()
+    if shrink:          # a training AABB smaller than the bound: the out-of-AABB rule fires as well
+        model.update_aabb(torch.tensor([-1.5, -1.2, -0.9, 1.5, 1.3, 1.1]))
+    # a few close cameras with a narrow field of view, all on one side: they see roughly half of the volume
+    poses = hemisphere_poses(n_cams, 1.4 * bound, seed=5, min_elev=0.3, max_elev=0.6)
+    poses[:, :3, 3] *= np.array([1.0, 0.4, 1.0], dtype=np.float32)               # squeeze them towards +-x
+    W = 64
+    intr = np.array([1.9 * W, 1.9 * W, W / 2.0, W / 2.0])
+    data = types.SimpleNamespace(poses=torch.from_numpy(poses), intrinsics=intr)
+    model.density_grid.zero_()
+    model.mark_untrained_grid(data)
+    got = (model.density_grid < 0).cpu().numpy()
+    assert np.all(model.density_grid.cpu().numpy()[~got] == 0)                    # trainable cells are left alone
+    ref = _untrained_reference(orc, poses, intr, H, model.cascade, model.bound, model.aabb_train.cpu().numpy(),
+                                opt.min_near)
+    frac = ref.mean(axis=1)
+    assert np.all(frac > 0.2) and np.all(frac < 0.95), frac                       # a real split, in every cascade
+    # cells within float rounding of a frustum plane may flip (the restatement multiplies on the host): allow a handful
+    assert (got != ref).sum() <= 4, (got != ref).sum()
+
+    # per-camera intrinsics [V,4] and per-camera near planes take the other branches of the reference code
+    data2 = types.SimpleNamespace(poses=torch.from_numpy(poses), cam_near_far=torch.tensor([[0.9, 6.0]] * n_cams),
+                                  intrinsics=torch.from_numpy(np.tile(intr, (n_cams, 1))).float())
+    model.density_grid.zero_()
+    model.mark_untrained_grid(data2)
+    got2 = (model.density_grid < 0).cpu().numpy()
+    ref2 = _untrained_reference(orc, poses, intr, H, model.cascade, model.bound, model.aabb_train.cpu().numpy(),
+                                 opt.min_near, cam_near=[0.9] * n_cams)
+    assert ref2.sum() > ref.sum()                                                 # the later near plane hides more cells
+    assert (got2 != ref2).sum() <= 4
+
+
+def test_untrained_cells_are_never_sampled(lib):
+    """-1 cells survive the density-grid refresh (renderer.py:889: `valid = grid >= 0`) and never enter the bitfield."""
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd import raymarching
+    opt = Options(bound=1.0, num_rays=512, iters=100)
+    dev = torch.device("cuda")
+    data = SyntheticDataset(opt, dev, "train", n_views=2, H=64, W=64)
+    model = NeRFNetwork(opt)
+    trainer = FusedTrainer(opt, model, data, device=dev, capacity=512 * 256)
+    model.mark_untrained_grid(data)
+    marked = model.density_grid < 0
+    assert 0 < int(marked.sum()) < marked.numel()
+    for _ in range(20):                                   # two refreshes (steps 0 and 16) + training in between
+        trainer.train_step()
+    assert torch.equal(model.density_grid < 0, marked)
+    bits = model.density_bitfield.cpu().numpy()
+    occ = np.unpackbits(bits, bitorder="little").astype(bool).reshape(model.cascade, -1)
+    assert not (occ & marked.cpu().numpy()).any()
+    del raymarching
+
+
+def test_sampler_path_run_at_config0_shape(lib):
+    """`--cuda_ray` off: the proposal-sampling renderer `run()` with HIP hash-grid / SH encoders (proposal encoders
+    included), training and staged inference, at the configs[0] shape: 200 x 200 views, L = 8 levels x 2 features
+    (the shape the CPU fallback of BASELINE configs[0] names), num_steps [64, 32, 16] (the reduced
+    variant)."""
+    from raw_ngp_amd.nerf import network
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    from raw_ngp_amd.nerf.trainer import Trainer
+    from raw_ngp_amd.encoding import get_encoder
+    opt = Options(bound=1.0, cuda_ray=False, num_rays=256, num_steps=[64, 32, 16], iters=200, background="white")
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    data = SyntheticDataset(opt, dev, "train", n_views=4, H=200, W=200)
+    model = network.NeRFNetwork(opt)
+    # configs[0]: hashgrid L=8 F=2 (desired resolution 2048, T = 2^19) in front of a 16-input density MLP
+    model.grid_encoder, dim = get_encoder("hashgrid", input_dim=3, level_dim=2, num_levels=8, log2_hashmap_size=19,
+                                          desired_resolution=2048)
+    assert dim == 16
+    model.grid_mlp = network.MLP(dim, 16, 64, 3, opt, bias=False)
+    trainer = Trainer(opt, model, data, device=dev)
+    losses = []
+    for _ in range(60):
+        losses.append(float(trainer.train_step()))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-10:]) < 0.6 * np.mean(losses[:5]), (losses[:5], losses[-10:])
+    assert trainer.last_num_points == 256 * 16            # the final level's samples
+    g = model.grid_encoder.embeddings.grad
+    assert g is not None and float(g.abs().sum()) > 0
+    assert all(float(e.embeddings.grad.abs().sum()) > 0 for e in model.prop_encoders)   # proposal loss reached them
+    model.eval()
+    with torch.no_grad():
+        v = data.view(0)
+        out = model.render(v["rays_o"], v["rays_d"], bg_color=1, perturb=False)          # 40 000 rays, staged
+    assert out["image"].shape == (200 * 200, 3) and torch.isfinite(out["image"]).all()
+    assert float(out["weights_sum"].max()) <= 1.0 + 1e-4
