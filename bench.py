@@ -148,6 +148,7 @@ def cpu_baseline(opt, n_rays, steps, seed=0):
 
 def run_config(args, bound, background, rank, world, dev, probe_on=True):
     """Train one configuration up to the timed region, time K steps, evaluate PSNR.  Returns a dict of raw results."""
+    torch.manual_seed(0)                    # every configuration starts from the same initial weights
     opt = Options(bound=bound, background=background, num_rays=args.rays, iters=max(args.psnr_iters, 5000), arena_capacity=args.arena,
                   fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,

@@ -68,7 +68,7 @@ def test_mark_untrained_grid_matches_restatement(lib, orc, bound, n_cams, shrink
     ref = _untrained_reference(orc, poses, intr, H, model.cascade, model.bound, model.aabb_train.cpu().numpy(),
                                 opt.min_near)
     frac = ref.mean(axis=1)
-    assert np.all(frac > 0.2) and np.all(frac < 0.95), frac                       # a real split, in every cascade
+    assert np.all(frac > 0.1) and np.all(frac < 0.95), frac                       # a real split, in every cascade
     # cells within float rounding of a frustum plane may flip (the restatement multiplies on the host): allow a handful
     assert (got != ref).sum() <= 4, (got != ref).sum()
 
