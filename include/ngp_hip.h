@@ -286,6 +286,31 @@ int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, fl
  * two places in the operand image, so the next forward needs no prepare pass. */
 
 /* ------------------------------------------------------------------------------------
+ * The same fused field for the light-conditioned configuration (`--rfield`, nerf/network.py:55-56,111-143:
+ * view_mlp = MLP(15 + 16 + 16, 3, 64 + 16, 3): colour from [features, SH16(view dir), SH16(light dir)] through
+ * 47 -> 80 -> 80 -> 3), csrc/fused_mlp_rf.hip.  w4 [80,47], w5 [80,80], w6 [3,80]; w1..w3 as above.
+ *   ldirs    [M,3] light directions (normalised in-kernel, like the view directions)
+ *   level_w  optional device float[16]: per-level weights multiplied onto the encoder features before the density MLP
+ *            (the BARF window of network.py:99-109); the backward scales d(enc) by the same weights.  NULL = ones
+ *   ddirs    optional [M,3]: d loss / d (un-normalised view direction), through the SH basis' Jacobian
+ *            (shencoder.cu:126-350) and d / |d| (renderer.py:541): what raymarching.py:319-329 sums per ray
+ * Only the default activations (ReLU, trunc_exp density, clamped_exp colour) are implemented.
+ * ---------------------------------------------------------------------------------- */
+size_t ngp_x_mlp_rf_image_bytes(void);
+int ngp_x_mlp_rf_prepare(const float *w1, const float *w2, const float *w3, const float *w4, const float *w5,
+                         const float *w6, void *image, ngp_stream_t stream);
+/* rgb == NULL (then dirs / ldirs may be NULL): density only */
+int ngp_x_mlp_rf_forward(const float *enc, uint32_t stride, const float *dirs, const float *ldirs, const float *level_w,
+                         const int32_t *M_dev, uint32_t M, const void *image, float *sigma, float *rgb,
+                         ngp_stream_t stream);
+size_t ngp_x_mlp_rf_backward_workspace_bytes(uint32_t M);
+/* outputs: d(enc) (slab layout, rows >= M untouched), ddirs (optional), six weight gradients (OVERWRITTEN) */
+int ngp_x_mlp_rf_backward(const float *enc, uint32_t stride, const float *dirs, const float *ldirs, const float *level_w,
+                          const float *dsigma, const float *drgb, const int32_t *M_dev, uint32_t M, const void *image,
+                          float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2, float *dw3, float *dw4,
+                          float *dw5, float *dw6, void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Kernels of the fused training step (csrc/engine_kernels.hip; host side raw_ngp_amd/nerf/engine.py).
  * ---------------------------------------------------------------------------------- */
 
@@ -298,6 +323,13 @@ int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, const float *
                                    uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
                                    int align_corners, uint32_t interp, void *binned_workspace, uint32_t n_rows_total,
                                    ngp_stream_t stream);
+/* the same with the Jacobian d out / d x01 (gridencoder.cu:205-247) as a level-major slab dydx[L][stride][3][2]
+ * (dydx == NULL: as above).  Contracted with d(enc) per ray by ngp_x_ray_gradients. */
+int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound, const float *embeddings, const int32_t *offsets,
+                                       float *out, float *inputs01, const int32_t *B_dev, uint32_t B_cap, uint32_t stride,
+                                       uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                       int align_corners, uint32_t interp, void *binned_workspace, uint32_t n_rows_total,
+                                       float *dydx, ngp_stream_t stream);
 /* binned_workspace != NULL: a workspace of ngp_x_grid_backward_binned_prepare(stage 1) for the same samples; the
  * kernel also counts the records per 4096-row chunk (n_rows_total = rows of the whole table). */
 
@@ -330,6 +362,15 @@ int ngp_x_composite_mse_train(const float *gt_rgba, const float *bg_rgb, float b
                               const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
                               float T_thresh, float *weights_sum, float *depth, float *image, float *grad_sigmas,
                               float *grad_rgbs, float *loss_out, ngp_stream_t stream);
+/* The same launch with the HDR loss of nerf/train_utils.py:512-536 (`--image_mode HDR`, the RawNeRF loss) in place of the
+ * MSE:  clip = min(1, pred * exposure[n]);  loss = sum((clip - gt)^2 / (1e-3 + sg(clip))^2 * weight) * inv_norm, no
+ * gradient where pred * exposure >= 1.  exposure [N]; weight [N,3] = lossmult * loss_weight or NULL (ones);
+ * inv_norm = 1 / sum(lossmult) (= 1 / (3 N) without a Bayer mask). */
+int ngp_x_composite_hdr_train(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
+                              const float *weight, float inv_norm, const float *sigmas, const float *rgbs,
+                              const float *ts, const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                              float *weights_sum, float *depth, float *image, float *grad_sigmas, float *grad_rgbs,
+                              float *loss_out, ngp_stream_t stream);
 
 /* One torch.optim.Adam step (no amsgrad, no weight decay; main.py:245 uses eps 1e-15) over a flat fp32
  * tensor in a single pass; `step` counts from 1; zero_grad != 0 clears `grad` afterwards. */
@@ -374,6 +415,36 @@ int ngp_x_sample_rays(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W,
                       float fy, float cx, float cy, uint32_t N, uint64_t seed, const uint32_t *draw_dev, uint32_t draw,
                       float *rays_o, float *rays_d, float *gt_rgba, float *noises, float *bg_rgb, int32_t *index,
                       ngp_stream_t stream);
+/* ... and per-ray light directions rays_ldir [N,3] = view_ldirs[view] (colmap_provider.py:619-620; both NULL: as above) */
+int ngp_x_sample_rays_lit(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W, uint32_t C, const float *poses,
+                          float fx, float fy, float cx, float cy, uint32_t N, uint64_t seed, const uint32_t *draw_dev,
+                          uint32_t draw, float *rays_o, float *rays_d, float *gt_rgba, float *noises, float *bg_rgb,
+                          int32_t *index, const float *view_ldirs, float *rays_ldir, ngp_stream_t stream);
+
+/* ---- pose refinement around the fused step (csrc/pose_kernels.hip) -----------------------------------------------
+ * ngp_x_step_window   annealing = float16((step_counter[0] + step_offset) / iters) (train_utils.py:488) -> the BARF level
+ *                     window of network.py:99-109 for L levels (float16 alpha, float32 cosine, level 0 forced to 1) in
+ *                     level_w[L]; flags (optional, int32[2]) = {annealing < end_annealing, step}
+ * ngp_x_ray_gradients raymarching.py:319-329 + gridencoder.cu:352-378 in one pass: per ray the sums over its samples of
+ *                     d xyz and of ts[:,0] * d xyz + d dirs, with d xyz = sum_l d enc_l . dydx_l / (2 bound) formed on the
+ *                     fly from the level-major slabs (denc [L][stride][2], dydx [L][stride][3][2]); ddirs may be NULL
+ * ngp_x_pose_gradient d loss / d (camera-to-world 3 x 4) per camera [V][12] from the ray gradients and the batch's
+ *                     (view, pixel) list (the adjoint of get_rays, train_utils.py:150-160); fixed summation order
+ * ngp_x_pose_update   xi [V,6] se(3) corrections, base [V,12] the poses they refine: refined[V,16] =
+ *                     compose(exp(xi), base) (barf/camera.py:47-63,91-102).  grad_pose != NULL: first one
+ *                     torch.optim.Adam step on xi (lr = lr0 * gamma^step, bias corrections from step + 1, step = flags[1])
+ *                     when flags[0] != 0, with d loss / d xi by forward-mode differentiation of the exponential map;
+ *                     grad_xi (optional) receives that gradient */
+int ngp_x_step_window(const uint32_t *step_counter, uint32_t step_offset, double iters, float start_annealing,
+                      float end_annealing, uint32_t L, float *level_w, int32_t *flags, ngp_stream_t stream);
+int ngp_x_ray_gradients(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound, const float *ddirs,
+                        const float *ts, const int32_t *rays, uint32_t N, uint32_t M, float *grad_rays_o,
+                        float *grad_rays_d, ngp_stream_t stream);
+int ngp_x_pose_gradient(const int32_t *index, const float *grad_rays_o, const float *grad_rays_d, uint32_t N, uint32_t V,
+                        uint32_t W, float fx, float fy, float cx, float cy, float *grad_pose, ngp_stream_t stream);
+int ngp_x_pose_update(float *xi, const float *base, const float *grad_pose, uint32_t V, const int32_t *flags,
+                      float *exp_avg, float *exp_avg_sq, float lr0, float gamma, float beta1, float beta2, float eps,
+                      float *refined, float *grad_xi, ngp_stream_t stream);
 
 /* The slab test NeRFRenderer.run_cuda actually uses (the torch function, nerf/renderer.py:139-158, not the
  * CUDA kernel): divides by (d + 1e-15), marks a miss with near = far = 1e9. */

@@ -387,3 +387,68 @@ def density_grid_update(grid, tmp, decay):
     valid = (g >= 0) & (t >= 0)
     g[valid] = np.maximum(g[valid] * np.float32(decay), t[valid])
     return g, float(np.clip(g, 0, None).astype(np.float64).mean())
+
+
+# ------------------------------------------------------------------ pose-refinement / HDR side of the step (numpy)
+def hdr_loss(pred_rgb, gt_rgb, exposure, lossmult=None, loss_weight=None):
+    """The HDR ("RawNeRF") loss of nerf/train_utils.py:512-536 and its gradient with respect to the prediction:
+        clip = min(1, pred * exposure[:, None]);  scaling = 1 / (1e-3 + stop_gradient(clip))
+        loss = sum((clip - gt)^2 * scaling^2 * lossmult * loss_weight) / sum(lossmult)
+    pred_rgb, gt_rgb [N,3]; exposure [N]; lossmult / loss_weight: None (1.0), scalar or [N,3].  float32 throughout like
+    the torch code.  Returns (loss, d loss / d pred [N,3])."""
+    f32 = np.float32
+    pred = np.asarray(pred_rgb, f32)
+    gt = np.asarray(gt_rgb, f32)
+    ex = np.asarray(exposure, f32)[:, None]
+    mult = np.broadcast_to(np.asarray(1.0 if lossmult is None else lossmult, f32), gt.shape).astype(f32)
+    lw = np.broadcast_to(np.asarray(1.0 if loss_weight is None else loss_weight, f32), gt.shape).astype(f32)
+    scaled = pred * ex
+    clip = np.minimum(f32(1.0), scaled)
+    scaling = f32(1.0) / (f32(1e-3) + clip)
+    data = (clip - gt) ** 2 * scaling ** 2
+    norm = mult.sum(dtype=np.float64)
+    loss = float((data * mult * lw).sum(dtype=np.float64) / norm)
+    grad = np.where(scaled < 1.0, 2.0 * (clip - gt) * scaling ** 2 * ex, 0.0) * mult * lw / f32(norm)
+    return loss, grad.astype(f32)
+
+
+def barf_window(step, iters, start, end, L=16):
+    """Level weights of the BARF window at a training step, with the reference's types: annealing =
+    np.clip(step / iters, 0, 1).astype(np.float16) (train_utils.py:488), alpha evaluated with that numpy float16 scalar
+    and python floats (network.py:100-105: every operation rounds to half precision), then the float32 cosine ramp of
+    :106 and `weights[0:2] = 1` (:108).  Returns (weights per level [L] float32, annealing as np.float16)."""
+    annealing = np.clip(step / iters, 0, 1).astype(np.float16)
+    if end == 0:
+        # the guard `end = 1e-12` underflows to 0 in float16 (0/0 at step 0); in float64 -- NumPy 1.x promotes
+        # float16-scalar op python-float to float64 -- it opens every level from step 1 on, which is what it is for
+        alpha = np.float32((float(annealing) - start) / (1e-12 - start) * L)
+    else:
+        alpha = (annealing - np.float16(start)) / np.float16(end - start) * np.float16(L)
+        assert alpha.dtype == np.float16
+    k = np.arange(L, dtype=np.float32)
+    w = (1 - np.cos(np.clip(np.float32(alpha) - k, 0, 1).astype(np.float32) * np.float32(np.pi))) / 2
+    w = w.astype(np.float32)
+    w[0] = 1.0
+    return w, annealing
+
+
+def grid_input_backward(grad, dy_dx, B, D, C, L):
+    """gridencoder.cu:352-378: grad_inputs[b, d] = sum_{l, ch} grad[l, b, ch] * dy_dx[b, l, d, ch] (double accumulation)."""
+    g = np.asarray(grad, np.float64).reshape(L, B, C)
+    j = np.asarray(dy_dx, np.float64).reshape(B, L, D, C)
+    return np.einsum("lbc,bldc->bd", g, j)
+
+
+def pose_gradient(index, grad_rays_o, grad_rays_d, V, W, intrinsics):
+    """Adjoint of get_rays (train_utils.py:150-160) per camera: rays_o = P[:3,3], rays_d = P[:3,:3] @ dir_cam with
+    dir_cam = ((i + .5 - cx) / fx, -(j + .5 - cy) / fy, -1).  index [N,2] = (view, pixel).  Returns [V,3,4] float64."""
+    fx, fy, cx, cy = [float(v) for v in intrinsics]
+    out = np.zeros((V, 3, 4))
+    pix = index[:, 1].astype(np.int64)
+    jj, ii = pix // W, pix % W
+    dc = np.stack([(ii + 0.5 - cx) / fx, -((jj + 0.5 - cy) / fy), -np.ones(len(pix))], 1)
+    for n in range(index.shape[0]):
+        v = int(index[n, 0])
+        out[v, :, :3] += np.outer(grad_rays_d[n].astype(np.float64), dc[n])
+        out[v, :, 3] += grad_rays_o[n]
+    return out

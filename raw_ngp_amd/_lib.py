@@ -53,7 +53,19 @@ _SIGNATURES = {
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f, _f, _f, _p],
+    "ngp_x_mlp_rf_prepare": [_p, _p, _p, _p, _p, _p, _p],
+    "ngp_x_mlp_rf_forward": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _p],
+    "ngp_x_mlp_rf_backward": [_p, _u, _p, _p, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                              ctypes.c_size_t],
     "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
+    "ngp_x_grid_encode_forward_slab_jac": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p],
+    "ngp_x_composite_hdr_train": [_p, _p, _f, _p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
+    "ngp_x_sample_rays_lit": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p,
+                              _p, _p],
+    "ngp_x_step_window": [_p, _u, _d, _f, _f, _u, _p, _p],
+    "ngp_x_ray_gradients": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _u, _p, _p],
+    "ngp_x_pose_gradient": [_p, _p, _p, _u, _u, _u, _f, _f, _f, _f, _p],
+    "ngp_x_pose_update": [_p, _p, _p, _u, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p],
     "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
     "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
     "ngp_x_composite_mse_backward": [_p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p],
@@ -101,6 +113,10 @@ def load():
         lib.ngp_x_mlp_image_bytes.restype = ctypes.c_size_t
         lib.ngp_x_mlp_backward_workspace_bytes.argtypes = [_u]
         lib.ngp_x_mlp_backward_workspace_bytes.restype = ctypes.c_size_t
+        lib.ngp_x_mlp_rf_image_bytes.argtypes = []
+        lib.ngp_x_mlp_rf_image_bytes.restype = ctypes.c_size_t
+        lib.ngp_x_mlp_rf_backward_workspace_bytes.argtypes = [_u]
+        lib.ngp_x_mlp_rf_backward_workspace_bytes.restype = ctypes.c_size_t
         for name, args in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = list(args) + [_p]
@@ -111,7 +127,8 @@ def load():
 
 def declared_symbols():
     return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes",
-            "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes", "ngp_x_occupancy_index_bytes",
+            "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes", "ngp_x_mlp_rf_image_bytes",
+            "ngp_x_mlp_rf_backward_workspace_bytes", "ngp_x_occupancy_index_bytes",
             "ngp_x_density_grid_workspace_bytes"] + list(_SIGNATURES)
 
 
@@ -539,17 +556,60 @@ class _MlpBackend:
               image.data_ptr() if image is not None else None)
 
 
+class _MlpRfBackend:
+    """Fused field of the light-conditioned configuration (rfield: 47 -> 80 -> 80 -> 3 view MLP), optional level window."""
+
+    @staticmethod
+    def image_bytes():
+        return int(load().ngp_x_mlp_rf_image_bytes())
+
+    @staticmethod
+    def prepare(weights, image):
+        _call("ngp_x_mlp_rf_prepare", image, *[_ptr(w, "f", f"w{i + 1}") for i, w in enumerate(weights)],
+              image.data_ptr())
+
+    @staticmethod
+    def forward(enc, stride, dirs, ldirs, level_w, M_dev, M, image, sigma, rgb):
+        _call("ngp_x_mlp_rf_forward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs", True),
+              _ptr(ldirs, "f", "ldirs", True), _ptr(level_w, "f", "level_w", True), _ptr(M_dev, "i", "M_dev", True), M,
+              image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb", True))
+
+    @staticmethod
+    def backward_workspace_bytes(M):
+        return int(load().ngp_x_mlp_rf_backward_workspace_bytes(M))
+
+    @staticmethod
+    def backward(enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, image, loss_scale, denc, ddirs, dws,
+                 workspace=None):
+        nbytes = load().ngp_x_mlp_rf_backward_workspace_bytes(M)
+        ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+        if ws.numel() < nbytes or not ws.is_cuda:
+            raise RuntimeError("mlp_rf backward: workspace too small")
+        _call("ngp_x_mlp_rf_backward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"),
+              _ptr(ldirs, "f", "ldirs"), _ptr(level_w, "f", "level_w", True), _ptr(dsigma, "f", "dsigma"),
+              _ptr(drgb, "f", "drgb"), _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), float(loss_scale),
+              _ptr(denc, "f", "denc"), _ptr(ddirs, "f", "ddirs", True),
+              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], ws.data_ptr(), nbytes)
+
+
 class _EngineBackend:
     """Kernels of the fused training step (extensions)."""
 
     @staticmethod
     def grid_encode_forward_slab(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L, max_level, S,
-                                 H, gridtype=0, align_corners=False, interp=0, binned_workspace=None):
-        _call("ngp_x_grid_encode_forward_slab", xyzs, _ptr(xyzs, "f", "xyzs"), float(bound),
-              _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"), _ptr(out, "f", "out"),
-              _ptr(inputs01, "f", "inputs01", True), _ptr(B_dev, "i", "B_dev", True), B_cap, stride, L, max_level,
-              float(S), H, gridtype, int(bool(align_corners)), interp,
-              binned_workspace.data_ptr() if binned_workspace is not None else None, embeddings.shape[0])
+                                 H, gridtype=0, align_corners=False, interp=0, binned_workspace=None, dydx=None):
+        """dydx: optional [L, stride, 3, 2] slab receiving d out / d x01 (pose refinement: ray_gradients)."""
+        args = (_ptr(xyzs, "f", "xyzs"), float(bound),
+                _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"), _ptr(out, "f", "out"),
+                _ptr(inputs01, "f", "inputs01", True), _ptr(B_dev, "i", "B_dev", True), B_cap, stride, L, max_level,
+                float(S), H, gridtype, int(bool(align_corners)), interp,
+                binned_workspace.data_ptr() if binned_workspace is not None else None, embeddings.shape[0])
+        if dydx is None:
+            _call("ngp_x_grid_encode_forward_slab", xyzs, *args)
+        else:
+            if dydx.numel() < L * stride * 6:
+                raise RuntimeError("grid_encode_forward_slab: dydx must hold L * stride * 3 * 2 floats")
+            _call("ngp_x_grid_encode_forward_slab_jac", xyzs, *args, _ptr(dydx, "f", "dydx"))
 
     @staticmethod
     def composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum, depth, image):
@@ -584,6 +644,43 @@ class _EngineBackend:
               _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
               _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
               _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
+
+    @staticmethod
+    def composite_hdr_train(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, sigmas, rgbs, ts, rays, M, N, T_thresh,
+                            weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out):
+        """composite_mse_train with the HDR loss of train_utils.py:512-536 (exposure [N], weight [N,3] or None)."""
+        _call("ngp_x_composite_hdr_train", rays, _ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
+              float(bg_const), _ptr(exposure, "f", "exposure"), _ptr(weight, "f", "weight", True), float(inv_norm),
+              _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"),
+              _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
+              _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
+              _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
+
+    @staticmethod
+    def step_window(step_counter, step_offset, iters, start_annealing, end_annealing, L, level_w, flags=None):
+        _call("ngp_x_step_window", level_w, _ptr(step_counter, "u", "step_counter"), int(step_offset), float(iters),
+              float(start_annealing), float(end_annealing), int(L), _ptr(level_w, "f", "level_w"),
+              _ptr(flags, "i", "flags", True))
+
+    @staticmethod
+    def ray_gradients(denc, dydx, stride, L, bound, ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d):
+        _call("ngp_x_ray_gradients", rays, _ptr(denc, "f", "denc"), _ptr(dydx, "f", "dydx"), stride, L, float(bound),
+              _ptr(ddirs, "f", "ddirs", True), _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), N, M,
+              _ptr(grad_rays_o, "f", "grad_rays_o"), _ptr(grad_rays_d, "f", "grad_rays_d"))
+
+    @staticmethod
+    def pose_gradient(index, grad_rays_o, grad_rays_d, N, V, W, intrinsics, grad_pose):
+        fx, fy, cx, cy = [float(v) for v in intrinsics]
+        _call("ngp_x_pose_gradient", index, _ptr(index, "i", "index"), _ptr(grad_rays_o, "f", "grad_rays_o"),
+              _ptr(grad_rays_d, "f", "grad_rays_d"), N, V, W, fx, fy, cx, cy, _ptr(grad_pose, "f", "grad_pose"))
+
+    @staticmethod
+    def pose_update(xi, base, grad_pose, flags, exp_avg, exp_avg_sq, lr0, gamma, beta1, beta2, eps, refined, grad_xi=None):
+        """grad_pose None: only refined = compose(exp(xi), base); else one Adam step on xi first (when flags[0] != 0)."""
+        _call("ngp_x_pose_update", xi, _ptr(xi, "f", "xi"), _ptr(base, "f", "base"), _ptr(grad_pose, "f", "grad_pose", True),
+              xi.shape[0], _ptr(flags, "i", "flags", True), _ptr(exp_avg, "f", "exp_avg", True),
+              _ptr(exp_avg_sq, "f", "exp_avg_sq", True), float(lr0), float(gamma), float(beta1), float(beta2), float(eps),
+              _ptr(refined, "f", "refined"), _ptr(grad_xi, "f", "grad_xi", True))
 
     @staticmethod
     def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, zero_grad=False):
@@ -634,16 +731,22 @@ class _EngineBackend:
 
     @staticmethod
     def sample_rays(images, poses, intrinsics, N, seed, draw, rays_o, rays_d, gt_rgba, noises=None, bg_rgb=None,
-                    index=None):
-        """`draw`: int32 device tensor (read at run time) or a Python int."""
+                    index=None, view_ldirs=None, rays_ldir=None):
+        """`draw`: int32 device tensor (read at run time) or a Python int.  view_ldirs [V,3] + rays_ldir [N,3]: per-ray
+        light directions of the light-conditioned configuration."""
         V, H, W, C = images.shape
         fx, fy, cx, cy = [float(v) for v in intrinsics]
         on_dev = torch.is_tensor(draw)
-        _call("ngp_x_sample_rays", images, _ptr(images, "b", "images"), V, H, W, C, _ptr(poses, "f", "poses"), fx, fy,
-              cx, cy, N, int(seed) & (2 ** 64 - 1), _ptr(draw, "u", "draw") if on_dev else None,
-              0 if on_dev else int(draw) & 0xffffffff, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
-              _ptr(gt_rgba, "f", "gt_rgba"), _ptr(noises, "f", "noises", True), _ptr(bg_rgb, "f", "bg_rgb", True),
-              _ptr(index, "i", "index", True))
+        args = (_ptr(images, "b", "images"), V, H, W, C, _ptr(poses, "f", "poses"), fx, fy,
+                cx, cy, N, int(seed) & (2 ** 64 - 1), _ptr(draw, "u", "draw") if on_dev else None,
+                0 if on_dev else int(draw) & 0xffffffff, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
+                _ptr(gt_rgba, "f", "gt_rgba"), _ptr(noises, "f", "noises", True), _ptr(bg_rgb, "f", "bg_rgb", True),
+                _ptr(index, "i", "index", True))
+        if view_ldirs is None and rays_ldir is None:
+            _call("ngp_x_sample_rays", images, *args)
+        else:
+            _call("ngp_x_sample_rays_lit", images, *args, _ptr(view_ldirs, "f", "view_ldirs"),
+                  _ptr(rays_ldir, "f", "rays_ldir"))
 
     @staticmethod
     def density_grid_workspace_bytes(H):
@@ -683,6 +786,7 @@ class _EngineBackend:
 gridencoder_backend = _GridBackend()
 engine_backend = _EngineBackend()
 mlp_backend = _MlpBackend()
+mlp_rf_backend = _MlpRfBackend()
 shencoder_backend = _SHBackend()
 freqencoder_backend = _FreqBackend()
 raymarching_backend = _RayBackend()

@@ -22,11 +22,14 @@ namespace ngp {
 // COUNT: also size the bins of the binned table backward (grid_backward_binned.hip: what bin_count_kernel does) --
 // the rows of all 8 corners are in registers here and the kernel waits on its gathers anyway, so the LDS histogram
 // rides along for free and the backward needs no counting pass of its own.
-template <bool COUNT>
+// JAC: also write d out / d x01 (gridencoder.cu:205-247) as a level-major slab dydx[level][stride][3][2] -- what the ray
+// gradients of pose refinement contract with d enc (pose_kernels.hip: ray_gradients)
+template <bool COUNT, bool JAC = false>
 __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     const float *__restrict__ xyzs, float bound, const float *__restrict__ table, const int32_t *__restrict__ offsets,
     float *__restrict__ out, float *__restrict__ inputs01, const int32_t *__restrict__ B_dev, uint32_t B_cap,
-    uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w)
+    uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w,
+    float *__restrict__ dydx = nullptr)
 {
     extern __shared__ uint32_t hist[];
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
@@ -100,8 +103,41 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
             ax = fmaf(wts[corner], rows[corner].v[0], ax);
             ay = fmaf(wts[corner], rows[corner].v[1], ay);
         }
+        if constexpr (JAC) {   // corner bit d set = upper neighbour along d; same expression order as gridencoder.hip
+            const float scale = (float)(align_corners ? g.res - 1u : g.res);
+            float2 *jd = reinterpret_cast<float2 *>(dydx) + ((size_t)level * stride + b) * 3;
+#pragma unroll
+            for (uint32_t gd = 0; gd < 3; gd++) {
+                float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+                for (uint32_t combo = 0; combo < 4; combo++) {
+                    float wj = scale;
+                    uint32_t lo = 0;
+#pragma unroll
+                    for (uint32_t nd = 0; nd < 2; nd++) {
+                        const uint32_t d = nd >= gd ? nd + 1 : nd;
+                        if (combo & (1u << nd)) {
+                            wj *= cl.f[d];
+                            lo |= 1u << d;
+                        } else {
+                            wj *= 1.0f - cl.f[d];
+                        }
+                    }
+                    const uint32_t hi = lo | (1u << gd);
+                    g0 = fmaf(wj * (rows[hi].v[0] - rows[lo].v[0]), cl.df[gd], g0);
+                    g1 = fmaf(wj * (rows[hi].v[1] - rows[lo].v[1]), cl.df[gd], g1);
+                }
+                jd[gd] = make_float2(g0, g1);
+            }
+        }
     }
     if (have) *dst = make_float2(ax, ay);   // zeros outside [0,1]^3, like the reference
+    if constexpr (JAC) {
+        if (have && !live) {
+            float2 *jd = reinterpret_cast<float2 *>(dydx) + ((size_t)level * stride + b) * 3;
+            jd[0] = jd[1] = jd[2] = make_float2(0.f, 0.f);
+        }
+    }
     if (COUNT) {
         bool emit = live;
         if (mergeable(g, w)) {   // level-uniform; every lane of the wave gets here
@@ -210,6 +246,16 @@ __global__ __launch_bounds__(256) void composite_forward_wave_kernel(
 //         straight into the backward -- the training step needs no separate forward launch
 constexpr uint32_t kCompBwdBlock = 1024;   // 16 rays per workgroup: one loss atomic per workgroup (same-address
                                            // global atomics serialise: 4096 of them cost ~60 us)
+// The RawNeRF-style loss of the HDR mode (train_utils.py:512-536): the prediction is scaled by the ray's exposure and
+// clipped at 1, the squared residual is weighted by the squared gradient of the log tone curve 1 / (1e-3 + sg(clip)),
+//     loss = sum(resid^2 * scaling^2 * lossmult * loss_weight) / sum(lossmult)
+// exposure == NULL selects the MSE.  weight: optional [N,3] = lossmult * loss_weight (NULL = 1), inv_norm = 1 / sum(lossmult)
+struct HdrLoss {
+    const float *exposure = nullptr;
+    const float *weight = nullptr;
+    float inv_norm = 0.0f;
+};
+
 template <int MODE>
 __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
     const float *__restrict__ grad_weights, const float *__restrict__ grad_weights_sum,
@@ -217,7 +263,8 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
     const float *__restrict__ bg_rgb, float bg_const, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
     const float *__restrict__ ts, const int32_t *__restrict__ rays, const float *weights_sum, const float *depth,
     const float *image, uint32_t M, uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
-    float *__restrict__ grad_rgbs, float *__restrict__ loss_out, float *ws_out, float *depth_out, float *image_out)
+    float *__restrict__ grad_rgbs, float *__restrict__ loss_out, float *ws_out, float *depth_out, float *image_out,
+    HdrLoss hdr = HdrLoss{})
 {
     __shared__ float ray_err[kCompBwdBlock / 64];
     const uint32_t n = (blockIdx.x * kCompBwdBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
@@ -275,16 +322,38 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
         const float4 px = reinterpret_cast<const float4 *>(gt_rgba)[nn];
         const float b0 = bg_rgb ? bg_rgb[(size_t)nn * 3] : bg_const, b1 = bg_rgb ? bg_rgb[(size_t)nn * 3 + 1] : bg_const,
                     b2 = bg_rgb ? bg_rgb[(size_t)nn * 3 + 2] : bg_const;
-        const float e0 = (rF + (1.0f - wsF) * b0) - (px.x * px.w + b0 * (1.0f - px.w));
-        const float e1 = (gF + (1.0f - wsF) * b1) - (px.y * px.w + b1 * (1.0f - px.w));
-        const float e2 = (bF + (1.0f - wsF) * b2) - (px.z * px.w + b2 * (1.0f - px.w));
-        const float k = 2.0f / (3.0f * (float)N);
-        gr = k * e0;
-        gg = k * e1;
-        gb = k * e2;
+        float ray_loss;
+        if (hdr.exposure) {
+            const float ex = hdr.exposure[nn];
+            const float pred[3] = {rF + (1.0f - wsF) * b0, gF + (1.0f - wsF) * b1, bF + (1.0f - wsF) * b2};
+            const float gt[3] = {px.x * px.w + b0 * (1.0f - px.w), px.y * px.w + b1 * (1.0f - px.w),
+                                 px.z * px.w + b2 * (1.0f - px.w)};
+            float gch[3];
+            ray_loss = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float scaled = pred[c] * ex, clip = fminf(1.0f, scaled);
+                const float sg = 1.0f / (1e-3f + clip), resid = clip - gt[c];
+                const float wgt = (hdr.weight ? hdr.weight[(size_t)nn * 3 + c] : 1.0f) * hdr.inv_norm;
+                ray_loss += resid * resid * (sg * sg) * wgt;
+                gch[c] = scaled < 1.0f ? 2.0f * resid * (sg * sg) * wgt * ex : 0.0f;   // no gradient through the clip
+            }
+            gr = gch[0];
+            gg = gch[1];
+            gb = gch[2];
+        } else {
+            const float e0 = (rF + (1.0f - wsF) * b0) - (px.x * px.w + b0 * (1.0f - px.w));
+            const float e1 = (gF + (1.0f - wsF) * b1) - (px.y * px.w + b1 * (1.0f - px.w));
+            const float e2 = (bF + (1.0f - wsF) * b2) - (px.z * px.w + b2 * (1.0f - px.w));
+            const float k = 2.0f / (3.0f * (float)N);
+            gr = k * e0;
+            gg = k * e1;
+            gb = k * e2;
+            ray_loss = (e0 * e0 + e1 * e1 + e2 * e2) / (3.0f * (float)N);
+        }
         gws = -(gr * b0 + gg * b1 + gb * b2);
         gd = 0.0f;
-        if (lane == 0 && in_range) ray_err[threadIdx.x >> 6] = (e0 * e0 + e1 * e1 + e2 * e2) / (3.0f * (float)N);
+        if (lane == 0 && in_range) ray_err[threadIdx.x >> 6] = ray_loss;
         __syncthreads();
         if (threadIdx.x == 0) {
             float sum = 0.0f;
@@ -489,7 +558,8 @@ __global__ __launch_bounds__(256) void sample_rays_kernel(
     const uint8_t *__restrict__ images, uint32_t V, uint32_t H, uint32_t W, uint32_t C, const float *__restrict__ poses,
     float fx, float fy, float cx, float cy, uint32_t N, uint32_t seed_lo, uint32_t seed_hi,
     const uint32_t *__restrict__ draw_dev, uint32_t draw, float *__restrict__ rays_o, float *__restrict__ rays_d,
-    float *__restrict__ gt, float *__restrict__ noises, float *__restrict__ bg, int32_t *__restrict__ index)
+    float *__restrict__ gt, float *__restrict__ noises, float *__restrict__ bg, int32_t *__restrict__ index,
+    const float *__restrict__ view_ldirs = nullptr, float *__restrict__ rays_ldir = nullptr)
 {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
@@ -519,6 +589,10 @@ __global__ __launch_bounds__(256) void sample_rays_kernel(
     if (index) {
         index[2 * n] = (int32_t)view;
         index[2 * n + 1] = (int32_t)pix;
+    }
+    if (rays_ldir) {   // one light direction per view (colmap_provider.py:619-620: metadict['ldirs'][index])
+#pragma unroll
+        for (int k = 0; k < 3; k++) rays_ldir[(size_t)n * 3 + k] = view_ldirs[(size_t)view * 3 + k];
     }
 }
 
@@ -552,6 +626,18 @@ extern "C" int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, co
                                               uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                               void *binned_workspace, uint32_t n_rows_total, ngp_stream_t stream)
 {
+    return ngp_x_grid_encode_forward_slab_jac(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L,
+                                              max_level, S, H, gridtype, align_corners, interp, binned_workspace,
+                                              n_rows_total, nullptr, stream);
+}
+
+extern "C" int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound, const float *embeddings,
+                                                  const int32_t *offsets, float *out, float *inputs01,
+                                                  const int32_t *B_dev, uint32_t B_cap, uint32_t stride, uint32_t L,
+                                                  uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                                  int align_corners, uint32_t interp, void *binned_workspace,
+                                                  uint32_t n_rows_total, float *dydx, ngp_stream_t stream)
+{
     if (B_cap == 0 || max_level == 0) return NGP_OK;
     NGP_REQUIRE(xyzs && embeddings && offsets && out, "grid_encode_forward_slab: null tensor");
     NGP_REQUIRE(stride >= B_cap, "grid_encode_forward_slab: stride smaller than B_cap");
@@ -567,9 +653,18 @@ extern "C" int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, co
         const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
         NGP_REQUIRE(n_chunks_max <= kMaxChunks, "grid_encode_forward_slab: table too large for the binned backward");
         const WsLayout w = ws_layout(binned_workspace, n_chunks_max);
-        grid_forward_slab_kernel<true><<<dim3(nchunks * max_level), dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
+        if (dydx)
+            grid_forward_slab_kernel<true, true><<<dim3(nchunks * max_level), dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
+                xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
+                align_corners != 0, interp, w, dydx);
+        else
+            grid_forward_slab_kernel<true><<<dim3(nchunks * max_level), dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
+                xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
+                align_corners != 0, interp, w);
+    } else if (dydx) {
+        grid_forward_slab_kernel<false, true><<<dim3(nchunks * max_level), dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-            align_corners != 0, interp, w);
+            align_corners != 0, interp, WsLayout{}, dydx);
     } else {
         grid_forward_slab_kernel<false><<<dim3(nchunks * max_level), dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
@@ -641,6 +736,28 @@ extern "C" int ngp_x_composite_mse_train(const float *gt_rgba, const float *bg_r
         nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, nullptr, nullptr, nullptr, M,
         N, T_thresh, grad_sigmas, grad_rgbs, loss_out, weights_sum, depth, image);
     NGP_CHECK_LAUNCH("composite_mse_train");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_composite_hdr_train(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
+                                         const float *weight, float inv_norm, const float *sigmas, const float *rgbs,
+                                         const float *ts, const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                         float *weights_sum, float *depth, float *image, float *grad_sigmas,
+                                         float *grad_rgbs, float *loss_out, ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(gt_rgba && exposure && rays && weights_sum && depth && image && loss_out, "composite_hdr_train: null tensor");
+    NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && grad_sigmas && grad_rgbs), "composite_hdr_train: null sample tensor");
+    NGP_REQUIRE(((uintptr_t)gt_rgba & 15u) == 0, "composite_hdr_train: gt_rgba must be 16-byte aligned");
+    NGP_REQUIRE(inv_norm > 0.0f, "composite_hdr_train: inv_norm = 1 / sum(lossmult) must be positive");
+    HdrLoss hdr;
+    hdr.exposure = exposure;
+    hdr.weight = weight;
+    hdr.inv_norm = inv_norm;
+    composite_backward_wave_kernel<2><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
+        nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, nullptr, nullptr, nullptr, M,
+        N, T_thresh, grad_sigmas, grad_rgbs, loss_out, weights_sum, depth, image, hdr);
+    NGP_CHECK_LAUNCH("composite_hdr_train");
     return NGP_OK;
 }
 
@@ -748,13 +865,24 @@ extern "C" int ngp_x_sample_rays(const uint8_t *images, uint32_t V, uint32_t H, 
                                  const uint32_t *draw_dev, uint32_t draw, float *rays_o, float *rays_d, float *gt_rgba,
                                  float *noises, float *bg_rgb, int32_t *index, ngp_stream_t stream)
 {
+    return ngp_x_sample_rays_lit(images, V, H, W, C, poses, fx, fy, cx, cy, N, seed, draw_dev, draw, rays_o, rays_d, gt_rgba,
+                                 noises, bg_rgb, index, nullptr, nullptr, stream);
+}
+
+extern "C" int ngp_x_sample_rays_lit(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W, uint32_t C,
+                                     const float *poses, float fx, float fy, float cx, float cy, uint32_t N, uint64_t seed,
+                                     const uint32_t *draw_dev, uint32_t draw, float *rays_o, float *rays_d, float *gt_rgba,
+                                     float *noises, float *bg_rgb, int32_t *index, const float *view_ldirs,
+                                     float *rays_ldir, ngp_stream_t stream)
+{
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE((view_ldirs == nullptr) == (rays_ldir == nullptr), "sample_rays: view_ldirs and rays_ldir go together");
     NGP_REQUIRE(images && poses && rays_o && rays_d && gt_rgba, "sample_rays: null tensor");
     NGP_REQUIRE(V > 0 && H > 0 && W > 0 && (uint64_t)H * W < (1ull << 32), "sample_rays: bad image shape");
     NGP_REQUIRE(C == 3 || C == 4, "sample_rays: images must be RGB or RGBA (uint8)");
     sample_rays_kernel<<<dim3(ceil_div(N, 256u)), dim3(256), 0, as_stream(stream)>>>(
         images, V, H, W, C, poses, fx, fy, cx, cy, N, (uint32_t)seed, (uint32_t)(seed >> 32), draw_dev, draw, rays_o, rays_d,
-        gt_rgba, noises, bg_rgb, index);
+        gt_rgba, noises, bg_rgb, index, view_ldirs, rays_ldir);
     NGP_CHECK_LAUNCH("sample_rays");
     return NGP_OK;
 }

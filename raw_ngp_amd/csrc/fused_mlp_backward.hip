@@ -399,10 +399,13 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 }
 
 // ---- grid kernel ---------------------------------------------------------------------------------
+// WINDOW: the encoder features are multiplied by a per-level weight before the MLP (BARF, network.py:99-109); the same
+// weight then scales d enc
+template <bool WINDOW>
 __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
     const float *__restrict__ enc, uint32_t stride, const int32_t *__restrict__ M_dev, uint32_t M_host,
     const half8 *__restrict__ image, float inv_loss_scale, const half8 *__restrict__ d3buf,
-    float *__restrict__ denc, float *__restrict__ partial)
+    float *__restrict__ denc, float *__restrict__ partial, const float *__restrict__ level_w, uint32_t t3_base)
 {
     extern __shared__ half8 lds_w[];   // local 0..11 = F_W1, F_W2 ; 12..25 = T_W3, T_W2, T_W1
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
@@ -410,10 +413,12 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
     const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_host) : M_host;
     const uint32_t n_tiles = (M + 31u) >> 5;
     for (uint32_t i = threadIdx.x; i < 12u * 64u; i += 256) lds_w[i] = image[i];
-    for (uint32_t i = threadIdx.x; i < 14u * 64u; i += 256) lds_w[12u * 64u + i] = image[(size_t)T_W3 * 64 + i];
+    for (uint32_t i = threadIdx.x; i < 14u * 64u; i += 256) lds_w[12u * 64u + i] = image[(size_t)t3_base * 64 + i];
     __syncthreads();
     constexpr uint32_t LT_W3 = 12, LT_W2 = 14, LT_W1 = 22;
     const half8 I0 = identity_frag(0, lane), I1 = identity_frag(1, lane);
+    LaneWindow lw;
+    if constexpr (WINDOW) lw = load_window(level_w, h);
 
     f32x16 g[8];   // 0,1: dW1[rb]   2..5: dW2[rb][cb]   6,7: dW3[cb]
 #pragma unroll
@@ -446,7 +451,18 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
                 continue;
             }
         }
-        const TileInB<false> in = convert_raw<false>(cur, h);
+        TileInB<false> in;
+        if constexpr (WINDOW) {
+            RawTile scaled = cur;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {   // r.e[4s + 2q + e] = level 8s + 4q + 2h + e: the window's own order
+                scaled.e[i].x *= lw.w[i];
+                scaled.e[i].y *= lw.w[i];
+            }
+            in = convert_raw<false>(scaled, h);
+        } else {
+            in = convert_raw<false>(cur, h);
+        }
 
         f32x16 a[2];
         half8 h1[2][2], h2[2][2];
@@ -553,8 +569,13 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
 #pragma unroll
             for (uint32_t q = 0; q < 4; q++) {
                 const uint32_t level = 4 * q + 2 * h;
-                float2 lo = make_float2(dx0[4 * q] * inv_loss_scale, dx0[4 * q + 1] * inv_loss_scale);
-                float2 hi = make_float2(dx0[4 * q + 2] * inv_loss_scale, dx0[4 * q + 3] * inv_loss_scale);
+                float klo = inv_loss_scale, khi = inv_loss_scale;
+                if constexpr (WINDOW) {   // levels 4q + 2h + {0, 1} = window entries (s = q >> 1, q & 1, e)
+                    klo *= lw.w[4 * (q >> 1) + 2 * (q & 1)];
+                    khi *= lw.w[4 * (q >> 1) + 2 * (q & 1) + 1];
+                }
+                float2 lo = make_float2(dx0[4 * q] * klo, dx0[4 * q + 1] * klo);
+                float2 hi = make_float2(dx0[4 * q + 2] * khi, dx0[4 * q + 3] * khi);
                 reinterpret_cast<float2 *>(denc)[(size_t)level * stride + row] = lo;
                 reinterpret_cast<float2 *>(denc)[(size_t)(level + 1) * stride + row] = hi;
             }
@@ -662,6 +683,20 @@ __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restr
     }
 }
 
+int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
+                             const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
+                             float *partial, uint32_t blocks, hipStream_t st)
+{
+    if (level_w)
+        mlp_backward_grid_kernel<true><<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
+                                                                                  d3buf, denc, partial, level_w, t3_base);
+    else
+        mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
+                                                                                   d3buf, denc, partial, nullptr, t3_base);
+    NGP_CHECK_LAUNCH("mlp_backward_grid");
+    return NGP_OK;
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -699,8 +734,8 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
     const half8 *img = reinterpret_cast<const half8 *>(image);
     mlp_backward_view_kernel<<<dim3(blocks), dim3(256), 46 * 1024, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
                                                                         loss_scale, d3buf, part_view);
-    mlp_backward_grid_kernel<<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
-                                                                        d3buf, denc, part_grid);
+    mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
+                                                                               d3buf, denc, part_grid, nullptr, T_W3);
     if (reduce_now)
         mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, st>>>(part_view, part_grid, blocks, 1.0f / loss_scale,
                                                                               dw1, dw2, dw3, dw4, dw5, dw6, MlpAdam{});

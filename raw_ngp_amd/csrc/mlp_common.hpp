@@ -137,4 +137,27 @@ __host__ __device__ constexpr uint32_t frag_pos(uint32_t f, uint32_t r, uint32_t
     return ((f + s) * 64u + r + 32u * h) * 8u + t;
 }
 
+// BARF level window (network.py:99-109 of the reference: f * w before the density MLP): the weights of one lane's 8
+// encoder levels in load order (s, q, e): level = 8s + 4q + 2h + e
+struct LaneWindow {
+    float w[8];
+};
+__device__ __forceinline__ LaneWindow load_window(const float *__restrict__ level_w, uint32_t h)
+{
+    LaneWindow lw;
+#pragma unroll
+    for (uint32_t s = 0; s < 2; s++)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++)
+#pragma unroll
+            for (uint32_t e = 0; e < 2; e++) lw.w[4 * s + 2 * q + e] = level_w ? level_w[8 * s + 4 * q + 2 * h + e] : 1.0f;
+    return lw;
+}
+
+// the density MLP's backward kernel (fused_mlp_backward.hip) for callers in other translation units: level_w may be
+// NULL (no window); t3_base = first of the 14 transposed fragments (T_W3, T_W2, T_W1) in `image`
+int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
+                             const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
+                             float *partial, uint32_t blocks, hipStream_t st);
+
 }  // namespace ngp

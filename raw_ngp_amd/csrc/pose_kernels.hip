@@ -1,0 +1,369 @@
+// Kernels of the fused step for the pose-refinement / light-conditioned configuration (BASELINE
+// configs[3]).  What the reference does around its kernels with torch ops -- barf/camera.py (se(3) exponential, pose
+// composition), barf/camera_optimizers.py:14-52,94-106 (one correction per camera, Adam with an exponential decay),
+// nerf/network.py:99-109 (BARF level window from the annealing value), raymarching/raymarching.py:319-329 (ray gradients
+// as segment sums of the sample gradients), gridencoder/src/gridencoder.cu:352-378 (input gradient) -- as a handful of
+// launches with no host round trip, so that the whole step can be replayed from a hipGraph:
+//
+//   step_window     annealing = float16(step / iters) (train_utils.py:488) -> the 16 level weights, and whether this is
+//                   still a pose step (annealing < end_annealing, train_utils.py:901)
+//   ray_gradients   per ray: sum over its samples of d xyz (= sum_l d enc_l . dy_dx_l / (2 bound), the encoder's input
+//                   backward, never materialised) and of t * d xyz + d dirs
+//   pose_gradient   per camera: d loss / d (refined pose) from the ray gradients of the rays drawn from that camera
+//   pose_update     per camera: chain through compose(exp(xi), base) by forward-mode differentiation of the exponential
+//                   map, torch.optim.Adam on xi, the refined pose of the next step
+#include "grid_common.hpp"
+
+namespace ngp {
+
+// ------------------------------------------------------------------ annealing -> level window
+// The reference keeps the annealing value as numpy float16 and evaluates alpha = (annealing - start) / (end - start) * L in
+// that type (every operation rounds to half precision; the python floats are cast to float16 first), then the cosine
+// window in float32 torch ops (network.py:101-108).  level_w[0] is forced to 1 (weights[0:2] = 1).
+// flags[0] = 1 while annealing < end_annealing (the pose optimiser steps), flags[1] = the step index.
+__global__ void step_window_kernel(const uint32_t *__restrict__ step_counter, uint32_t step_offset, double iters,
+                                   float start, float end, uint32_t L, float *__restrict__ level_w,
+                                   int32_t *__restrict__ flags)
+{
+    const uint32_t k = threadIdx.x;
+    const uint32_t step = step_counter[0] + step_offset;
+    const _Float16 ann = (_Float16)fmin(fmax((double)step / iters, 0.0), 1.0);
+    // `if end == 0: end = 1e-12` (network.py:103-104); end - start is python float arithmetic, cast to float16 as a whole
+    const double span = (end == 0.0f ? 1e-12 : (double)end) - (double)start;
+    const _Float16 e16 = (_Float16)(double)end;                     // the pose-step test uses opt.end_annealing as given
+    float alpha = (float)(((ann - (_Float16)(double)start) / (_Float16)span) * (_Float16)(float)L);
+    // end == 0 ("no annealing"): the 1e-12 guard underflows to 0 in float16; what the guard is there for -- and what
+    // float64 arithmetic (NumPy 1.x scalar promotion) gives -- is a window that is fully open from the first step on
+    if (end == 0.0f) alpha = (float)(((double)(float)ann - (double)start) / span * (double)L);
+    if (k < L) {
+        const float x = fminf(fmaxf(alpha - (float)k, 0.0f), 1.0f);
+        level_w[k] = k == 0 ? 1.0f : (1.0f - cosf(x * 3.14159265358979323846f)) / 2.0f;
+    }
+    if (k == 0 && flags) {
+        flags[0] = ann < e16 ? 1 : 0;
+        flags[1] = (int32_t)step;
+    }
+}
+
+// ------------------------------------------------------------------ ray gradients
+// one wave per ray; lanes stride over the ray's samples.  denc / dydx are level-major slabs ([L][stride][2], [L][stride][3][2]);
+// ddirs may be NULL.  Sums are formed in a fixed order (lane partials, then a butterfly): reproducible.
+__global__ __launch_bounds__(256) void ray_gradients_kernel(const float *__restrict__ denc, const float *__restrict__ dydx,
+                                                            uint32_t stride, uint32_t L, float inv_2bound,
+                                                            const float *__restrict__ ddirs, const float *__restrict__ ts,
+                                                            const int32_t *__restrict__ rays, uint32_t N, uint32_t M,
+                                                            float *__restrict__ grad_rays_o, float *__restrict__ grad_rays_d)
+{
+    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[(size_t)n * 2], cnt = (uint32_t)rays[(size_t)n * 2 + 1];
+    float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0};
+    if (off + cnt <= M) {
+        for (uint32_t k = lane; k < cnt; k += kWave) {
+            const size_t i = (size_t)off + k;
+            float g[3] = {0, 0, 0};
+            for (uint32_t l = 0; l < L; l++) {
+                const float2 ge = reinterpret_cast<const float2 *>(denc)[(size_t)l * stride + i];
+                const float2 *j = reinterpret_cast<const float2 *>(dydx) + ((size_t)l * stride + i) * 3;
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const float2 jj = j[d];
+                    g[d] = fmaf(ge.x, jj.x, g[d]);
+                    g[d] = fmaf(ge.y, jj.y, g[d]);
+                }
+            }
+            const float t = ts[i * 2];      // the reference multiplies by ts[:, 0] (raymarching.py:297,328)
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float gx = g[d] * inv_2bound;
+                so[d] += gx;
+                sd[d] += gx * t + (ddirs ? ddirs[i * 3 + d] : 0.0f);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            so[c] += __shfl_xor(so[c], d, 64);
+            sd[c] += __shfl_xor(sd[c], d, 64);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            grad_rays_o[(size_t)n * 3 + c] = so[c];
+            grad_rays_d[(size_t)n * 3 + c] = sd[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ d loss / d pose per camera
+// rays_o = P[:, 3], rays_d[k] = sum_j dir_cam[j] P[k][j] with dir_cam = ((i + .5 - cx) / fx, -(j + .5 - cy) / fy, -1)
+// (train_utils.py:150-160).  One workgroup per camera scans the batch's (view, pixel) list: a fixed summation order.
+// grad_pose [V][12] row-major 3 x 4.
+__global__ __launch_bounds__(256) void pose_gradient_kernel(const int32_t *__restrict__ index, const float *__restrict__ g_o,
+                                                            const float *__restrict__ g_d, uint32_t N, uint32_t W, float fx,
+                                                            float fy, float cx, float cy, float *__restrict__ grad_pose)
+{
+    __shared__ float red[4][12];
+    const uint32_t v = blockIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc[i] = 0.0f;
+    for (uint32_t n = threadIdx.x; n < N; n += 256) {
+        if ((uint32_t)index[2 * n] != v) continue;
+        const uint32_t pix = (uint32_t)index[2 * n + 1];
+        const uint32_t j = pix / W, i = pix - j * W;
+        const float dc[3] = {((float)i + 0.5f - cx) / fx, -(((float)j + 0.5f - cy) / fy), -1.0f};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float gd = g_d[(size_t)n * 3 + k];
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[4 * k + c] = fmaf(gd, dc[c], acc[4 * k + c]);
+            acc[4 * k + 3] += g_o[(size_t)n * 3 + k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) acc[i] += __shfl_xor(acc[i], d, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) red[wid][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) grad_pose[(size_t)v * 12 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------ se(3) exponential with forward-mode derivatives
+// value + the 6 partial derivatives with respect to xi = (w, u)
+struct Dual6 {
+    float v, d[6];
+};
+__device__ __forceinline__ Dual6 dconst(float c)
+{
+    Dual6 r;
+    r.v = c;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r.d[i] = 0.0f;
+    return r;
+}
+__device__ __forceinline__ Dual6 operator+(const Dual6 &a, const Dual6 &b)
+{
+    Dual6 r;
+    r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+__device__ __forceinline__ Dual6 operator-(const Dual6 &a, const Dual6 &b)
+{
+    Dual6 r;
+    r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+__device__ __forceinline__ Dual6 operator*(const Dual6 &a, const Dual6 &b)
+{
+    Dual6 r;
+    r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    return r;
+}
+__device__ __forceinline__ Dual6 operator*(float s, const Dual6 &a)
+{
+    Dual6 r;
+    r.v = s * a.v;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r.d[i] = s * a.d[i];
+    return r;
+}
+__device__ __forceinline__ Dual6 dchain(const Dual6 &a, float f, float df)   // f(a) with f' = df
+{
+    Dual6 r;
+    r.v = f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r.d[i] = df * a.d[i];
+    return r;
+}
+
+// [exp(w^) | V(w) u] as nerf/pose.py: se3_to_SE3 (barf/camera.py:91-102), series below 1e-2 rad; out[12] row-major 3 x 4
+__device__ __forceinline__ void se3_exp(const float (&xi)[6], Dual6 (&out)[12])
+{
+    Dual6 w[3], u[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        w[i] = dconst(xi[i]);
+        w[i].d[i] = 1.0f;
+        u[i] = dconst(xi[3 + i]);
+        u[i].d[3 + i] = 1.0f;
+    }
+    const Dual6 t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    // theta = sqrt(clamp_min(|w|^2, 1e-24)): no gradient below the floor, like torch's clamp
+    const bool floored = t2.v < 1e-24f;
+    const float th = sqrtf(floored ? 1e-24f : t2.v);
+    const Dual6 theta = dchain(t2, th, floored ? 0.0f : 0.5f / th);
+    Dual6 a, b, c;
+    if (th < 1e-2f) {
+        const Dual6 q = theta * theta, q2 = q * q;
+        a = dconst(1.0f) - (1.0f / 6.0f) * q + (1.0f / 120.0f) * q2;
+        b = dconst(0.5f) - (1.0f / 24.0f) * q + (1.0f / 720.0f) * q2;
+        c = dconst(1.0f / 6.0f) - (1.0f / 120.0f) * q + (1.0f / 5040.0f) * q2;
+    } else {
+        const float s = sinf(th), co = cosf(th);
+        const Dual6 sn = dchain(theta, s, co), cs = dchain(theta, co, -s);
+        const Dual6 inv = dchain(theta, 1.0f / th, -1.0f / (th * th));
+        const Dual6 inv2 = inv * inv, inv3 = inv2 * inv;
+        a = sn * inv;
+        b = (dconst(1.0f) - cs) * inv2;
+        c = (theta - sn) * inv3;
+    }
+    // wx = skew(w), wx2 = wx @ wx
+    const Dual6 z = dconst(0.0f);
+    const Dual6 wx[9] = {z, z - w[2], w[1], w[2], z, z - w[0], z - w[1], w[0], z};
+    Dual6 wx2[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) wx2[3 * r + cc] = wx[3 * r] * wx[cc] + wx[3 * r + 1] * wx[3 + cc] + wx[3 * r + 2] * wx[6 + cc];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        Dual6 tr = z;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            const Dual6 eye = dconst(r == cc ? 1.0f : 0.0f);
+            out[4 * r + cc] = eye + a * wx[3 * r + cc] + b * wx2[3 * r + cc];
+            const Dual6 Vrc = eye + b * wx[3 * r + cc] + c * wx2[3 * r + cc];
+            tr = tr + Vrc * u[cc];
+        }
+        out[4 * r + 3] = tr;
+    }
+}
+
+// refined = compose([exp(xi), base]) (pose.py: compose; barf/camera.py:47-63): R = Rb Rx, t = Rb tx + tb
+struct PoseAdam {
+    float *exp_avg, *exp_avg_sq;   // [V][6]
+    float lr0, gamma, b1, b2, eps;
+};
+
+// One thread per camera.  grad_pose == NULL: only (re)compute the refined poses from xi.  Otherwise: gradient of xi through
+// the composition, torch.optim.Adam with lr = lr0 * gamma^step (ExponentialLR stepped once per pose step) when flags[0] != 0,
+// and the refined pose for the next step.
+__global__ void pose_update_kernel(float *__restrict__ xi, const float *__restrict__ base, const float *__restrict__ grad_pose,
+                                   uint32_t V, const int32_t *__restrict__ flags, PoseAdam opt, float *__restrict__ refined,
+                                   float *__restrict__ grad_xi)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float x[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = xi[(size_t)v * 6 + i];
+    const float *B = base + (size_t)v * 12;
+    if (grad_pose) {
+        Dual6 E[12];
+        se3_exp(x, E);
+        // d loss / d Rx = Rb^T G_R, d loss / d tx = Rb^T G_t
+        const float *G = grad_pose + (size_t)v * 12;
+        float g[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float up = 0.0f;   // (Rb^T G)[r][c]
+#pragma unroll
+                for (int k = 0; k < 3; k++) up = fmaf(B[4 * k + r], G[4 * k + c], up);
+#pragma unroll
+                for (int i = 0; i < 6; i++) g[i] = fmaf(up, E[4 * r + c].d[i], g[i]);
+            }
+        if (grad_xi) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) grad_xi[(size_t)v * 6 + i] = g[i];
+        }
+        if (flags[0] != 0) {
+            const double step = (double)flags[1], t = step + 1.0;
+            const float lr = (float)((double)opt.lr0 * pow((double)opt.gamma, step));
+            const float bc1 = (float)(1.0 - pow((double)opt.b1, t)), bc2s = (float)sqrt(1.0 - pow((double)opt.b2, t));
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const size_t k = (size_t)v * 6 + i;
+                const float m = opt.b1 * opt.exp_avg[k] + (1.0f - opt.b1) * g[i];
+                const float s = opt.b2 * opt.exp_avg_sq[k] + (1.0f - opt.b2) * g[i] * g[i];
+                opt.exp_avg[k] = m;
+                opt.exp_avg_sq[k] = s;
+                x[i] -= (lr / bc1) * (m / (sqrtf(s) / bc2s + opt.eps));
+                xi[k] = x[i];
+            }
+        }
+    }
+    Dual6 E[12];
+    se3_exp(x, E);
+    float *P = refined + (size_t)v * 16;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) P[4 * r + c] = B[4 * r] * E[c].v + B[4 * r + 1] * E[4 + c].v + B[4 * r + 2] * E[8 + c].v;
+        P[4 * r + 3] = B[4 * r] * E[3].v + B[4 * r + 1] * E[7].v + B[4 * r + 2] * E[11].v + B[4 * r + 3];
+    }
+    P[12] = P[13] = P[14] = 0.0f;
+    P[15] = 1.0f;
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" int ngp_x_step_window(const uint32_t *step_counter, uint32_t step_offset, double iters, float start_annealing,
+                                 float end_annealing, uint32_t L, float *level_w, int32_t *flags, ngp_stream_t stream)
+{
+    NGP_REQUIRE(step_counter && level_w, "step_window: null tensor");
+    NGP_REQUIRE(L >= 1 && L <= 64 && iters > 0.0, "step_window: bad L / iters");
+    step_window_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(step_counter, step_offset, iters, start_annealing,
+                                                                    end_annealing, L, level_w, flags);
+    NGP_CHECK_LAUNCH("step_window");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_ray_gradients(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
+                                   const float *ddirs, const float *ts, const int32_t *rays, uint32_t N, uint32_t M,
+                                   float *grad_rays_o, float *grad_rays_d, ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays && grad_rays_o && grad_rays_d, "ray_gradients: null tensor");
+    NGP_REQUIRE(M == 0 || (denc && dydx && ts), "ray_gradients: null sample tensor");
+    NGP_REQUIRE(stride >= M && bound > 0.0f && L >= 1, "ray_gradients: bad stride / bound / L");
+    ray_gradients_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
+        denc, dydx, stride, L, 1.0f / (2.0f * bound), ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d);
+    NGP_CHECK_LAUNCH("ray_gradients");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_pose_gradient(const int32_t *index, const float *grad_rays_o, const float *grad_rays_d, uint32_t N,
+                                   uint32_t V, uint32_t W, float fx, float fy, float cx, float cy, float *grad_pose,
+                                   ngp_stream_t stream)
+{
+    if (V == 0) return NGP_OK;
+    NGP_REQUIRE(index && grad_rays_o && grad_rays_d && grad_pose, "pose_gradient: null tensor");
+    NGP_REQUIRE(W > 0, "pose_gradient: image width must be positive");
+    pose_gradient_kernel<<<dim3(V), dim3(256), 0, as_stream(stream)>>>(index, grad_rays_o, grad_rays_d, N, W, fx, fy, cx, cy,
+                                                                       grad_pose);
+    NGP_CHECK_LAUNCH("pose_gradient");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_pose_update(float *xi, const float *base, const float *grad_pose, uint32_t V, const int32_t *flags,
+                                 float *exp_avg, float *exp_avg_sq, float lr0, float gamma, float beta1, float beta2,
+                                 float eps, float *refined, float *grad_xi, ngp_stream_t stream)
+{
+    if (V == 0) return NGP_OK;
+    NGP_REQUIRE(xi && base && refined, "pose_update: null tensor");
+    NGP_REQUIRE(!grad_pose || (flags && exp_avg && exp_avg_sq), "pose_update: an update needs flags and the Adam state");
+    const PoseAdam opt{exp_avg, exp_avg_sq, lr0, gamma, beta1, beta2, eps};
+    pose_update_kernel<<<dim3(ceil_div(V, 64u)), dim3(64), 0, as_stream(stream)>>>(xi, base, grad_pose, V, flags, opt, refined,
+                                                                                  grad_xi);
+    NGP_CHECK_LAUNCH("pose_update");
+    return NGP_OK;
+}

@@ -14,6 +14,7 @@ raw_ngp_amd/parallel.py and is applied here when a process group is initialised.
 """
 import time
 
+import numpy as np
 import torch
 
 from . import utils
@@ -59,7 +60,8 @@ class Trainer:
             model.update_extra_state()
         refine = self.pose_optimizer is not None
         if refine:
-            self.annealing = min(max(self.global_step / opt.iters, 0.0), 1.0)
+            # a numpy float16, like the reference (train_utils.py:488): the level windows see its rounding
+            self.annealing = np.clip(self.global_step / opt.iters, 0, 1).astype(np.float16)
             model.update_annealing(self.annealing)
             self.pose_optimizer.update_annealing(self.annealing)
             data = self.data.sample_rays(opt.num_rays, self.ray_gen, pose_fn=self.pose_optimizer)

@@ -118,7 +118,11 @@ def test_sampler_path_run_at_config0_shape(lib):
     from raw_ngp_amd.nerf.scene import SyntheticDataset
     from raw_ngp_amd.nerf.trainer import Trainer
     from raw_ngp_amd.encoding import get_encoder
-    opt = Options(bound=1.0, cuda_ray=False, num_rays=256, num_steps=[64, 32, 16], iters=200, background="white")
+    # bound 2 (the reference's default): every ray of these cameras crosses the box.  A ray that MISSES it gets
+    # near = far = 1e9 from near_far_from_aabb, spacing_fn(1e9) rounds to 1.0 and spacing_fn_inv(1.0) = 1 / (2 - 2) = inf:
+    # run() then samples at t = inf and the density heads receive NaN gradients -- in the reference just the same
+    # (renderer.py:419-447 has no guard); its datasets are framed so that it does not happen, and so is this one
+    opt = Options(bound=2.0, cuda_ray=False, num_rays=256, num_steps=[64, 32, 16], iters=200, background="white")
     dev = torch.device("cuda")
     torch.manual_seed(0)
     data = SyntheticDataset(opt, dev, "train", n_views=4, H=200, W=200)
