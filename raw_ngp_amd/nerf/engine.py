@@ -27,16 +27,20 @@ import torch
 from .. import parallel, raymarching
 from .._lib import engine_backend as eb
 from .._lib import gridencoder_backend as gb
-from .._lib import mlp_backend as mb
+from .._lib import mlp_backend as _mlp_plain
+from .._lib import mlp_rf_backend as _mlp_rf
 from .._lib import raymarching_backend as rb
 
 
 class _Slot:
     """One ray batch and everything derived from it before the field is evaluated."""
 
-    def __init__(self, N, max_steps, cap, dev, chain_cap=0):
+    def __init__(self, N, max_steps, cap, dev, chain_cap=0, lit=False, indexed=False):
         f32 = dict(dtype=torch.float32, device=dev)
-        self.arena = raymarching.MarchArena(N, max_steps, cap, dev, chain_cap=chain_cap)
+        self.arena = raymarching.MarchArena(N, max_steps, cap, dev, chain_cap=chain_cap, with_ldirs=lit)
+        self.rays_ldir = torch.zeros(N, 3, **f32) if lit else None            # rfield: one light direction per ray
+        self.index = torch.zeros(N, 2, dtype=torch.int32, device=dev) if indexed else None    # (view, pixel) of each ray
+        self.exposure = torch.ones(N, **f32) if indexed else None
         self.rays_o, self.rays_d = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32)
         self.gt, self.bg = torch.empty(N, 4, **f32), torch.empty(N, 3, **f32)
         self.noises = torch.empty(N, **f32)
@@ -48,7 +52,16 @@ class FusedTrainer:
     """Drop-in for Trainer.train_step / train on models that satisfy NeRFNetwork._fused()."""
 
     def __init__(self, opt, model, dataset, device="cuda", seed=0, capacity=None, betas=(0.9, 0.999), eps=1e-15):
-        assert opt.cuda_ray and not opt.rfield and opt.pose_opt == "none", "fused step: density-grid path only"
+        assert opt.cuda_ray, "fused step: density-grid path only"
+        # light-conditioned field (rfield: 47 -> 80 -> 80 -> 3 view MLP over [features, SH(view), SH(light)]), BARF pose
+        # refinement (level window + se(3) corrections) and the HDR loss: BASELINE configs[3]
+        self.rfield = bool(opt.rfield)
+        self.pose = opt.pose_opt != "none"
+        self.hdr = getattr(opt, "image_mode", "LDR") == "HDR"
+        assert opt.pose_opt in ("none", "barf"), "fused step: pose_opt 'baangp' is not implemented here -- use Trainer"
+        assert not self.pose or self.rfield, "fused step: pose refinement is fused for the rfield configuration only"
+        assert not self.hdr or getattr(opt, "loss_weight", "none") in ("none", "planck"), \
+            "fused step: HDR loss_weight gaussian / hanning need batch statistics -- use Trainer"
         # terms of the reference's train_step (train_utils.py:544-564) this step does not compute: refuse them instead of
         # silently training a different objective than the per-op Trainer would with the same Options
         unsupported = [k for k in ("lambda_entropy", "lambda_orientation", "lambda_distort") if getattr(opt, k, 0) > 0]
@@ -57,6 +70,7 @@ class FusedTrainer:
         self.opt, self.model, self.data, self.device = opt, model.to(device), dataset, torch.device(device)
         opt.fused_mlp = True
         assert model._fused(), "fused step needs the default field configuration"
+        self.mb = mb = _mlp_rf if self.rfield else _mlp_plain
         self.rank, self.world_size = parallel.rank(), parallel.world_size()
         # data-parallel step (separate Adam pass, gradient collectives); `dp_rehearsal` runs it on one rank as well
         self.dp = self.world_size > 1 or (bool(getattr(opt, "dp_rehearsal", False)) and parallel.is_dist())
@@ -92,14 +106,16 @@ class FusedTrainer:
         # per-ray and per-sample buffers
         # two ray-batch slots: while step i trains out of one, step i+1's rays are drawn and marched into the
         # other on a second stream (the march is a long, narrow kernel -- 64 waves -- that hides under backward)
-        self.prefetch = bool(getattr(opt, "prefetch_march", True)) and dev.type == "cuda"
+        # (pose refinement: the rays of step i + 1 are cast from the poses step i has just updated -- nothing to draw ahead)
+        self.prefetch = bool(getattr(opt, "prefetch_march", True)) and dev.type == "cuda" and not self.pose
         # march pass 1: "chain" (all candidate parameters classified in parallel), "index" (serial loop, occupancy
         # index in LDS) or "serial" (serial loop on the bitfield)
         self.march_mode = getattr(opt, "march_mode", "chain")
         chain_cap = opt.max_steps * int(math.ceil(model.real_bound)) + 2 if self.march_mode == "chain" else 0
         if chain_cap >= 65536:
             self.march_mode, chain_cap = "index", 0
-        self.slots = [_Slot(N, opt.max_steps, cap, dev, chain_cap) for _ in range(2 if self.prefetch else 1)]
+        self._slot_kw = dict(lit=self.rfield, indexed=self.pose or self.hdr)
+        self.slots = [_Slot(N, opt.max_steps, cap, dev, chain_cap, **self._slot_kw) for _ in range(2 if self.prefetch else 1)]
         self.arena = self.slots[0].arena
         self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
         self.aux = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
@@ -113,6 +129,17 @@ class FusedTrainer:
         imgs = getattr(dataset, "images", None)
         self.device_sampler = bool(getattr(opt, "device_sampler", True)) and torch.is_tensor(imgs) \
             and imgs.dtype == torch.uint8 and imgs.is_cuda and imgs.dim() == 4
+        assert self.device_sampler or not (self.pose or self.hdr), "fused pose / HDR step: needs the device-side ray sampler"
+        self.view_ldirs = None
+        if self.rfield:
+            ld = getattr(dataset, "ldirs", None)
+            assert ld is not None, "rfield: the dataset must carry one light direction per view (dataset.ldirs [V,3])"
+            self.view_ldirs = torch.as_tensor(ld, dtype=torch.float32, device=dev).contiguous()
+        self.view_exposure = None
+        if self.hdr:
+            ex = getattr(dataset, "exposures", None)
+            assert ex is not None, "HDR loss: the dataset must carry one exposure value per view (dataset.exposures [V])"
+            self.view_exposure = torch.as_tensor(ex, dtype=torch.float32, device=dev).contiguous()
         self.seed64 = (seed * 1000 + self.rank) & (2 ** 64 - 1)
         i32 = dict(dtype=torch.int32, device=dev)
         self.draw_ctr, self.step_ctr = torch.zeros(1, **i32), torch.zeros(1, **i32)
@@ -138,7 +165,9 @@ class FusedTrainer:
             self._wire_flat = torch.zeros(n_t + self.w_grad.numel(), dtype=torch.bfloat16, device=dev)
             self._wire = self._wire_flat[:n_t].view(self.table_grad.shape)
             self._wire_w = self._wire_flat[n_t:]
-        self._main_symbols = {"ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
+        self._main_symbols = {"ngp_x_mlp_rf_forward", "ngp_x_mlp_rf_backward", "ngp_x_mlp_rf_prepare",
+                              "ngp_x_grid_encode_forward_slab_jac", "ngp_x_composite_hdr_train",
+                              "ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
                               "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
                               "ngp_x_composite_mse_backward", "ngp_x_composite_mse_train", "ngp_x_adam_step_dev2", "ngp_x_adam_step_dev",
                               "ngp_x_step_begin", "ngp_x_mlp_prepare", "ngp_x_mlp_reduce_dw",
@@ -154,6 +183,36 @@ class FusedTrainer:
             self.dg_draw = torch.zeros(1, **i32)
             self.dg_ws = torch.empty(eb.density_grid_workspace_bytes(model.grid_size), dtype=torch.uint8, device=dev)
             self.dg_seed = ((seed * 1000) ^ 0x9E3779B97F4A7C15) & (2 ** 64 - 1)     # same on every rank
+        # BARF: per-level weights of the current step, {pose step?, step} flags; the se(3) corrections and their Adam state
+        self.level_w = torch.ones(self.L, **f32) if self.pose else None
+        self.flags = torch.zeros(2, **i32) if self.pose else None
+        self.pose_optimizer = None
+        if self.pose:
+            from .pose import CameraOptimizer, compose
+            V = len(dataset)
+            self.pose_optimizer = co = CameraOptimizer(V, dev, opt, seed=seed)
+            self.xi = co.se3_refine.weight.data                          # [V,6], updated in place by the device kernel
+            with torch.no_grad():                                         # what the corrections refine (pose.py: forward)
+                base = dataset.poses[:, :3, :].float()
+                if co.pose_noise is not None:
+                    base = compose([co.pose_noise, base])
+                if getattr(opt, "identity", False):
+                    base = torch.eye(4, device=dev)[None, :3, :4].expand(V, 3, 4)
+            self.pose_base = base.reshape(V, 12).contiguous()
+            self.poses_refined = torch.zeros(V, 4, 4, **f32)
+            self.pose_m, self.pose_v = torch.zeros(V, 6, **f32), torch.zeros(V, 6, **f32)
+            self.grad_pose = torch.zeros(V, 12, **f32)
+            self.g_rays_o, self.g_rays_d = torch.zeros(N, 3, **f32), torch.zeros(N, 3, **f32)
+            self.pose_lr0 = float(getattr(opt, "c_lr", 1e-3))
+            self.pose_gamma = 1e-2 ** (1.0 / opt.iters)                   # ExponentialLR of camera_optimizers.py:44-50
+            eb.pose_update(self.xi, self.pose_base, None, None, None, None, self.pose_lr0, self.pose_gamma, 0.9, 0.999, 1e-8,
+                           self.poses_refined)
+            self.dydx = torch.empty(self.L, cap, 3, 2, **f32)
+            self.ddirs = torch.empty(cap, 3, **f32)
+            # before the first step the reference's annealing value is 0.0 (train_utils.py:411): the first density-grid
+            # refresh sees that window (level 0 only)
+            eb.step_window(self.step_ctr, 0, float(opt.iters), opt.start_annealing, opt.end_annealing, self.L, self.level_w,
+                           self.flags)
         self.enc = torch.empty(self.L, cap, 2, **f32)
         self.denc = torch.empty(self.L, cap, 2, **f32)
         self.x01 = torch.empty(cap, 3, **f32)
@@ -178,6 +237,16 @@ class FusedTrainer:
     def lr(self):
         return self.lr0 * 0.1 ** min(self.global_step / self.opt.iters, 1)
 
+    def _mlp_prepare(self):
+        self.mb.prepare(self.weights, self.mlp_image)
+
+    def _mlp_forward(self, stride, dirs, ldirs, cnt, M, sigma, rgb):
+        """Field evaluation on self.enc (rgb None: density only).  rfield: light directions + the level window."""
+        if self.rfield:
+            self.mb.forward(self.enc, stride, dirs, ldirs, self.level_w, cnt, M, self.mlp_image, sigma, rgb)
+        else:
+            self.mb.forward(self.enc, stride, dirs, cnt, M, self.mlp_image, sigma, rgb)
+
     def march(self, slot, rays_o, rays_d, noises, aabb=None, plan=True):
         """rays -> sample arena of `slot` (near/far, count, scan, expand); runs on the current stream."""
         opt, m, ar, N = self.opt, self.model, slot.arena, self.N
@@ -187,10 +256,10 @@ class FusedTrainer:
             self._occ_version = version
         eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train if aabb is None else aabb, N, m.min_near, slot.nears,
                                  slot.fars)
-        rb.march_rays_train_arena(rays_o, rays_d, None, m.density_bitfield, m.real_bound, opt.contract, opt.dt_gamma,
-                                  opt.max_steps, N, m.cascade, m.grid_size, slot.nears, slot.fars, noises, ar.t_scratch,
-                                  self.cap, ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, self.occ_index,
-                                  ar.chain)
+        rb.march_rays_train_arena(rays_o, rays_d, slot.rays_ldir, m.density_bitfield, m.real_bound, opt.contract,
+                                  opt.dt_gamma, opt.max_steps, N, m.cascade, m.grid_size, slot.nears, slot.fars, noises,
+                                  ar.t_scratch, self.cap, ar.xyzs, ar.dirs, ar.ts, ar.ldirs, ar.rays, ar.counter, None,
+                                  self.occ_index, ar.chain)
         if not plan:
             return
         # reset the bookkeeping of the binned table backward for this batch (stage 1: plan); the encoder's forward
@@ -227,37 +296,65 @@ class FusedTrainer:
         def composite_train():      # forward + loss + backward of the compositor in one launch (the step path)
             if zero_loss:
                 self.loss.zero_()
+            if self.hdr:            # exposure-scaled, clipped loss of train_utils.py:512-536
+                weight = None
+                if opt.loss_weight == "planck":     # raw_utils.planck_taper_weighting(gt_rgb): pointwise in the target
+                    weight = self._planck_weight(gt_rgba, bg_rgb, bg_const)
+                eb.composite_hdr_train(gt_rgba, bg_rgb, bg_const, slot.exposure, weight, 1.0 / (3 * N), self.sigma, self.rgb,
+                                       ar.ts, ar.rays, cap, N, opt.T_thresh, self.ws, self.depth, self.image, self.dsigma,
+                                       self.drgb, self.loss)
+                return
             eb.composite_mse_train(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh,
                                    self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss)
+
+        def mlp_backward():
+            if self.rfield:         # one call: both view kernels, the density kernel, the weight-gradient reduction
+                self.mb.backward(self.enc, cap, ar.dirs, ar.ldirs, self.level_w, self.dsigma, self.drgb, cnt, cap,
+                                 self.mlp_image, opt.loss_scale, self.denc, self.ddirs if self.pose else None, self.dws,
+                                 self.ws_mlp)
+            else:
+                self.mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap, self.mlp_image, opt.loss_scale,
+                                 self.denc, None if split_weights else self.dws, self.ws_mlp)
 
         ops = [
             ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
                 ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt, cap, cap, self.L, self.L, self.S, self.H,
-                binned_workspace=slot.ws_grid)),
+                binned_workspace=slot.ws_grid, dydx=self.dydx if self.pose else None)),
             ("ngp_x_grid_backward_binned_prepare", lambda: gb.grid_backward_binned_prepare(
                 None, 0.0, offsets, self.rows, cnt, cap, self.L, self.L, self.S, self.H, slot.ws_grid,
                 single_segment=fused_adam or overwrite, stage=2)),
-            ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image)),
-            ("ngp_x_mlp_forward", lambda: mb.forward(self.enc, cap, ar.dirs, cnt, cap, self.mlp_image, self.sigma,
-                                                     self.rgb)),
+            ("ngp_x_mlp_prepare", self._mlp_prepare),
+            ("ngp_x_mlp_forward", lambda: self._mlp_forward(cap, ar.dirs, ar.ldirs, cnt, cap, self.sigma, self.rgb)),
             ("ngp_x_composite_rays_train_forward", lambda: eb.composite_rays_train_forward(
                 self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.weights_buf, self.ws, self.depth,
                 self.image)),
             ("ngp_x_composite_mse_backward", loss_and_composite_backward),
-            ("ngp_x_mlp_backward", lambda: mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap,
-                                                       self.mlp_image, opt.loss_scale, self.denc,
-                                                       None if split_weights else self.dws, self.ws_mlp)),
+            ("ngp_x_mlp_backward", mlp_backward),
             ("ngp_x_grid_backward_binned_apply", lambda: gb.grid_backward_binned_apply(
                 self.denc, self.x01, offsets, self._wire if overwrite and self.wire16 else self.table_grad, cnt, cap, cap,
                 self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite)),
         ]
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
+        assert fuse_composite or not self.hdr, "the HDR loss lives in the fused compositor step"
         if fuse_composite:
             ops = [o for o in ops if o[0] != "ngp_x_composite_rays_train_forward"]
             ops = [("ngp_x_composite_mse_train", composite_train) if o[0] == "ngp_x_composite_mse_backward" else o
                    for o in ops]
         return ops
+
+    def _planck_weight(self, gt_rgba, bg_rgb, bg_const):
+        """raw_utils.planck_taper_weighting of the target colour (raw/raw_utils.py:46-53: peak 0.5, taper 0.95, max 2)."""
+        a = gt_rgba[:, 3:]
+        bg = bg_rgb if bg_rgb is not None else bg_const
+        gt = gt_rgba[:, :3] * a + bg * (1 - a)
+        w = 2.0 * (0.5 + 0.5 * torch.cos((gt - 0.5) * (math.pi / (2 * 0.95))))
+        return torch.where((gt >= 0.5 - 0.95) & (gt <= 0.5 + 0.95), w, torch.zeros_like(w)).contiguous()
+
+    @torch.no_grad()
+    def refined_poses(self):
+        """[V,3,4] camera-to-world matrices the rays are currently cast from (pose refinement)."""
+        return self.poses_refined[:, :3, :].clone() if self.pose else self.data.poses[:, :3, :].clone()
 
     @staticmethod
     def _without(ops, name):
@@ -287,7 +384,7 @@ class FusedTrainer:
         n_uni, n_occ = (cells, 0) if full else (cells // 4, cells // 4)
         total = n_uni + n_occ
         offsets = m.grid_encoder.offsets
-        mb.prepare(self.weights, self.mlp_image)
+        self._mlp_prepare()
         for cas in range(m.cascade):
             bound = min(2 ** cas, m.bound)
             half = bound / H
@@ -298,7 +395,7 @@ class FusedTrainer:
                 k = min(cap, total - s)
                 eb.grid_encode_forward_slab(self.dg_xyzs[s:s + k], m.bound, self.table, offsets, self.enc, None, None, k,
                                             cap, self.L, self.L, self.S, self.H)
-                mb.forward(self.enc, cap, None, None, k, self.mlp_image, self.dg_sigma[s:s + k], None)
+                self._mlp_forward(cap, None, None, None, k, self.dg_sigma[s:s + k], None)
             eb.density_grid_scatter(self.dg_indices[:total], self.dg_sigma[:total], total, self.dg_tmp[cas])
         eb.density_grid_update(m.density_grid, self.dg_tmp, decay, self.dg_stats)
         eb.packbits_mean(m.density_grid, self.dg_stats, m.density_thresh, m.density_bitfield)
@@ -360,12 +457,18 @@ class FusedTrainer:
         opt = self.opt
         if batch is None and self.device_sampler:
             d = self.data
-            eb.sample_rays(d.images, d.poses, d.intrinsics, self.N, self.seed64, self.draw_ctr, slot.rays_o, slot.rays_d,
-                           slot.gt, slot.noises, slot.bg if opt.background == "random" else None)
+            # pose refinement: rays are cast from the refined cameras (the dataset's pose_fn hook, provider.py:298-300)
+            eb.sample_rays(d.images, self.poses_refined if self.pose else d.poses, d.intrinsics, self.N, self.seed64,
+                           self.draw_ctr, slot.rays_o, slot.rays_d, slot.gt, slot.noises,
+                           slot.bg if opt.background == "random" else None, slot.index, self.view_ldirs, slot.rays_ldir)
             eb.counter_add(self.draw_ctr, 1)
+            if self.hdr:        # the exposure of each ray's image (colmap_provider.py:605-606)
+                torch.index_select(self.view_exposure, 0, slot.index[:, 0].long(), out=slot.exposure)
         else:
             if batch is None:
                 batch = self.data.sample_rays(self.N, self.ray_gen)
+            if self.rfield:
+                slot.rays_ldir.copy_(batch["rays_ldir"])
             gt = batch["images"]
             slot.gt[:, :gt.shape[-1]].copy_(gt)
             if gt.shape[-1] == 3:
@@ -400,19 +503,47 @@ class FusedTrainer:
                                 fuse_composite=True)
         field = self._without(field, "ngp_x_grid_backward_binned_prepare")          # folded into step_begin
         field.insert(1, begin)                                                      # right after the encoder's forward
-        prepare = ("ngp_x_mlp_prepare", lambda: mb.prepare(self.weights, self.mlp_image))
+        if self.pose:
+            # the level window of THIS step and whether the cameras still move (annealing < end_annealing), from the step
+            # counter before step_begin advances it
+            field.insert(1, ("ngp_x_step_window", lambda: eb.step_window(
+                self.step_ctr, 0, float(opt.iters), opt.start_annealing, opt.end_annealing, self.L, self.level_w, self.flags)))
+        # pose refinement, after the field's own backward: ray gradients (encoder input backward + segment sums) ->
+        # per-camera pose gradients -> se(3) Adam step and the refined poses the next batch is cast from
+        pose_tail = []
+        if self.pose:
+            ar, d = slot.arena, self.data
+            pose_tail = [
+                ("ngp_x_ray_gradients", lambda: eb.ray_gradients(self.denc, self.dydx, self.cap, self.L, self.model.bound,
+                                                                 self.ddirs, ar.ts, ar.rays, self.N, self.cap,
+                                                                 self.g_rays_o, self.g_rays_d)),
+                ("ngp_x_pose_gradient", lambda: eb.pose_gradient(slot.index, self.g_rays_o, self.g_rays_d, self.N, len(d),
+                                                                 d.W, d.intrinsics, self.grad_pose)),
+                ("ngp_x_pose_update", lambda: eb.pose_update(self.xi, self.pose_base, self.grad_pose, self.flags, self.pose_m,
+                                                             self.pose_v, self.pose_lr0, self.pose_gamma, 0.9, 0.999, 1e-8,
+                                                             self.poses_refined)),
+            ]
         if split:
-            # weight gradients out of the partial sums and, element by element, Adam on the flat MLP weights and the new
-            # value's two entries in the f16 operand image (so the next step needs no prepare pass)
-            tail = [("ngp_x_mlp_reduce_dw", lambda: mb.reduce_dw(
-                        self.cap, opt.loss_scale, self.dws, self.ws_mlp,
-                        adam=(self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps),
-                        image=self.mlp_image))]
+            if self.rfield:
+                # (the light-conditioned kernels reduce their weight gradients themselves: Adam and next step's operand
+                # image are two more small launches)
+                tail = [("ngp_x_adam_step_dev", lambda: eb.adam_step_dev(self.w_flat, self.w_grad, self.w_m, self.w_v,
+                                                                         self.hyper, *self.betas, self.eps)),
+                        ("ngp_x_mlp_prepare", self._mlp_prepare)]
+            else:
+                # weight gradients out of the partial sums and, element by element, Adam on the flat MLP weights and the
+                # new value's two entries in the f16 operand image (so the next step needs no prepare pass)
+                tail = [("ngp_x_mlp_reduce_dw", lambda: self.mb.reduce_dw(
+                            self.cap, opt.loss_scale, self.dws, self.ws_mlp,
+                            adam=(self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps),
+                            image=self.mlp_image))]
             for name, op in field:
                 if name == "ngp_x_grid_backward_binned_apply":      # right after the MLP backward, beside the apply
                     ops += [(n, o, "aux") for n, o in tail]
                 ops.append((name, op, "main"))
+            ops += [(n, o, "main") for n, o in pose_tail]
             return ops
+        assert not self.rfield, "fused rfield step: single-GPU fused-Adam variant only (data parallel: use Trainer)"
         ops += [(n, o, "main") for n, o in field]
         if self.dp:
             if self.wire16:
@@ -508,7 +639,7 @@ class FusedTrainer:
                     torch.manual_seed(1234567 + step)
                 model.update_extra_state()
         if not self._image_ready:                       # later steps prepare it right after their Adam step
-            mb.prepare(self.weights, self.mlp_image)
+            self._mlp_prepare()
             self._image_ready = True
         slot = self.slots[step % len(self.slots)]
         if batch is not None:
@@ -562,7 +693,7 @@ class FusedTrainer:
                       + (f" (ARENA OVERFLOW: {needed} > {self.cap})" if needed > self.cap else ""), flush=True)
 
     @torch.no_grad()
-    def render_rays(self, rays_o, rays_d, bg_const=0.0):
+    def render_rays(self, rays_o, rays_d, bg_const=0.0, ldir=None):
         """Images for evaluation out of the TRAINING kernels, forward only: per block of N rays one chain-parallel march
         (no jitter), slab encoder, fused MLP, wave compositor -- instead of the reference's alive-ray loop
         (renderer.py:573-616: up to max_steps rounds of march_rays / field / composite_rays with a host sync each).
@@ -570,10 +701,13 @@ class FusedTrainer:
         opt, m, N, cap = self.opt, self.model, self.N, self.cap
         if self._eval_slot is None:
             chain_cap = self.slots[0].arena.chain[0].shape[0] if self.slots[0].arena.chain is not None else 0
-            self._eval_slot = _Slot(N, opt.max_steps, cap, self.device, chain_cap)
+            self._eval_slot = _Slot(N, opt.max_steps, cap, self.device, chain_cap, lit=self.rfield)
             self._eval_slot.noises.zero_()
         slot, ar = self._eval_slot, self._eval_slot.arena
-        mb.prepare(self.weights, self.mlp_image)
+        if self.rfield:             # one light per rendered view (colmap_provider.py:619: rays_ldir of the image)
+            assert ldir is not None, "render_rays: the light-conditioned field needs the view's light direction"
+            slot.rays_ldir.copy_(torch.as_tensor(ldir, dtype=torch.float32, device=self.device).view(-1, 3).expand(N, 3))
+        self._mlp_prepare()
         total = rays_o.shape[0]
         out = torch.empty(total, 3, device=self.device)
         # image rays are coherent: a block of N neighbouring pixels can need more samples than the arena holds (training
@@ -599,7 +733,7 @@ class FusedTrainer:
                 continue
             eb.grid_encode_forward_slab(ar.xyzs, m.bound, self.table, m.grid_encoder.offsets, self.enc, None, ar.counter,
                                         cap, cap, self.L, self.L, self.S, self.H)
-            mb.forward(self.enc, cap, ar.dirs, ar.counter, cap, self.mlp_image, self.sigma, self.rgb)
+            self._mlp_forward(cap, ar.dirs, ar.ldirs, ar.counter, cap, self.sigma, self.rgb)
             eb.composite_rays_train_forward(self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.weights_buf,
                                             self.ws, self.depth, self.image)
             out[s:s + n] = self.image[:n] + (1.0 - self.ws[:n, None]) * bg_const
@@ -621,9 +755,11 @@ class FusedTrainer:
         n = len(dataset) if max_views is None else min(max_views, len(dataset))
         for v in range(n):
             data = dataset.view(v)
-            pred, overflow = self.render_rays(data["rays_o"].contiguous(), data["rays_d"].contiguous(), 0.0)
+            pred, overflow = self.render_rays(data["rays_o"].contiguous(), data["rays_d"].contiguous(), 0.0,
+                                              ldir=data.get("rays_ldir"))
             if overflow:
-                preds = [self.model.render(data["rays_o"][s:s + chunk], data["rays_d"][s:s + chunk], bg_color=0,
+                preds = [self.model.render(data["rays_o"][s:s + chunk], data["rays_d"][s:s + chunk],
+                                           rays_ldir=data.get("rays_ldir"), bg_color=0,
                                            perturb=False)["image"] for s in range(0, pred.shape[0], chunk)]
                 pred = torch.cat(preds, 0)
             img = data["images"]

@@ -128,11 +128,16 @@ class NeRFNetwork(NeRFRenderer):
         return f
 
     # -- fused MFMA path (extension; Options.fused_mlp) ------------------------------------------
-    def _fused(self):
+    def _fused(self, plain_only=False):
+        """The field configuration the MFMA kernels implement (ReLU, trunc_exp density, clamped_exp colour).
+        plain_only: additionally the 31-input view MLP without level windows -- what the autograd op `fused_field`
+        covers; the light-conditioned / BARF variants exist for the fused training step only (nerf/engine.py)."""
         o = self.opt
-        return (getattr(o, "fused_mlp", False) and not o.rfield and o.pose_opt == "none"
-                and o.internal_activation == "relu" and o.density_activation == "clamped_exp"
-                and o.color_activation == "clamped_exp" and self.grid_encoder.embeddings.is_cuda)
+        ok = (getattr(o, "fused_mlp", False) and o.internal_activation == "relu" and o.density_activation == "clamped_exp"
+              and o.color_activation == "clamped_exp" and self.grid_encoder.embeddings.is_cuda)
+        if plain_only:
+            ok = ok and not o.rfield and o.pose_opt == "none"
+        return ok
 
     def _mlp_weights(self):
         return [l.weight for l in self.grid_mlp.net] + [l.weight for l in self.view_mlp.net]
@@ -149,7 +154,7 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward(self, x, d, ld=None, **kwargs):
         """x [N,3] in [-bound, bound], d [N,3] unit view dirs, ld [N,3] light dirs (rfield)."""
-        if self._fused() and not d.requires_grad:
+        if self._fused(plain_only=True) and not d.requires_grad:
             from .fused_field import fused_field
             enc = self.grid_encoder(x.reshape(-1, 3), bound=self.bound, slab=True)
             sigma, color = fused_field(enc, d.reshape(-1, 3), self._mlp_weights(),
@@ -170,7 +175,7 @@ class NeRFNetwork(NeRFRenderer):
         return {"sigma": sigma, "color": color}
 
     def density(self, x, proposal=-1):
-        if self._fused() and not torch.is_grad_enabled() and not (0 <= proposal < len(getattr(self, "prop_encoders", ()))):
+        if self._fused(plain_only=True) and not torch.is_grad_enabled() and not (0 <= proposal < len(getattr(self, "prop_encoders", ()))):
             from .fused_field import fused_density
             enc = self.grid_encoder(x.reshape(-1, 3), bound=self.bound, slab=True)
             return {"sigma": fused_density(enc, self._mlp_weights()).view(x.shape[:-1])}

@@ -35,18 +35,30 @@ def main():
     ap.add_argument("--log-every", type=int, default=500)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--arena", type=int, default=0, help="sample-arena rows (0 = the reference's two-call march)")
+    ap.add_argument("--per-op", action="store_true",
+                    help="the per-op autograd path (Trainer: torch MLPs, the reference's call sequence) instead of the fused step")
+    ap.add_argument("--hdr", action="store_true", help="HDR loss with per-view exposures (train_utils.py:512-536)")
+    ap.add_argument("--timed-steps", type=int, default=200)
     args = ap.parse_args()
     dev = torch.device("cuda")
     torch.manual_seed(args.seed)
     opt = Options(bound=1.0, num_rays=args.rays, iters=args.iters, rfield=not args.no_rfield, pose_opt=args.pose_opt,
-                  noise=args.noise, c_lr=args.c_lr, arena_capacity=args.arena)
+                  noise=args.noise, c_lr=args.c_lr, arena_capacity=args.arena, image_mode="HDR" if args.hdr else "LDR")
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     if opt.rfield:
         data.ldirs = torch.from_numpy(P.synthetic_light_dirs(args.views)).to(dev)
+    if args.hdr:
+        import numpy as np
+        data.exposures = torch.from_numpy(np.random.default_rng(5).choice([0.5, 1.0, 2.0], args.views).astype("float32")).to(dev)
     model = NeRFNetwork(opt)
-    trainer = Trainer(opt, model, data, dev, seed=args.seed)
+    if args.per_op:
+        assert not args.hdr, "the HDR loss is implemented in the fused step"
+        trainer = Trainer(opt, model, data, dev, seed=args.seed)
+    else:
+        from raw_ngp_amd.nerf.engine import FusedTrainer
+        trainer = FusedTrainer(opt, model, data, device=dev, seed=args.seed)
     co = trainer.pose_optimizer
-    report = {"config": vars(args)}
+    report = {"config": vars(args), "step": "per-op" if args.per_op else "fused"}
     if co is not None:
         report["pose_error_start"] = P.pose_error(co.get_refined_poses(data.poses), data.poses)
     t0, last = time.time(), 0
@@ -62,10 +74,10 @@ def main():
     # steady-state step rate
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(50):
+    for _ in range(args.timed_steps):
         trainer.train_step()
     torch.cuda.synchronize()
-    ms = (time.time() - t0) / 50 * 1e3
+    ms = (time.time() - t0) / args.timed_steps * 1e3
     report.update(ms_per_step=round(ms, 3), rays_per_s=round(args.rays / ms * 1e3),
                   samples_per_step=int(trainer.last_num_points))
     if co is not None:
