@@ -103,6 +103,8 @@ def _fused_setup(pose_opt, iters, views=24, noise=0.03, rays=2048, image_mode="L
     data.ldirs = torch.from_numpy(P.synthetic_light_dirs(views)).to(dev)
     if image_mode == "HDR":
         data.exposures = torch.from_numpy(np.random.default_rng(5).choice([0.5, 1.0, 2.0], views).astype(np.float32)).to(dev)
+        rgb = data.images[..., :3].float() * data.exposures.view(-1, 1, 1, 1)       # radiance x exposure, clipped at white
+        data.images[..., :3] = rgb.clamp(max=255).to(torch.uint8)
     return P, data, FusedTrainer(opt, NeRFNetwork(opt), data, device=dev, seed=seed, capacity=rays * 200)
 
 

@@ -50,6 +50,9 @@ def main():
     if args.hdr:
         import numpy as np
         data.exposures = torch.from_numpy(np.random.default_rng(5).choice([0.5, 1.0, 2.0], args.views).astype("float32")).to(dev)
+        # what a camera with that exposure records of the same radiance: colour x exposure, clipped at white
+        rgb = data.images[..., :3].float() * data.exposures.view(-1, 1, 1, 1)
+        data.images[..., :3] = rgb.clamp(max=255).to(torch.uint8)
     model = NeRFNetwork(opt)
     if args.per_op:
         assert not args.hdr, "the HDR loss is implemented in the fused step"
