@@ -23,10 +23,18 @@ struct WsLayout {
     uint32_t *cursor;       // [n_chunks_max]
     uint32_t *offset;       // [n_chunks_max + 1] record offsets (multiples of 4)
     uint32_t *seg_base;     // [n_chunks_max + 1] first reduce work item of each chunk
-    uint32_t *records;      // 3 words per record
+    float2 *vals;           // record payloads (w * g.x, w * g.y), rec_cap of them
+    uint16_t *keys;         // record keys (row inside the chunk), rec_cap of them, behind the payloads
 };
 
-__host__ __device__ inline WsLayout ws_layout(void *ws, uint32_t n_chunks_max)
+// records a call can emit at most: 8 per (sample, level) + the 4-record alignment slack of every chunk
+__host__ __device__ inline size_t ws_rec_cap(uint32_t B, uint32_t L, uint32_t n_chunks_max)
+{
+    return (size_t)B * L * 8 + 4 * (size_t)n_chunks_max + 8;
+}
+
+// rec_cap = 0: header only (callers that never touch the records: counting, scanning)
+__host__ __device__ inline WsLayout ws_layout(void *ws, uint32_t n_chunks_max, size_t rec_cap = 0)
 {
     WsLayout w;
     uint32_t *p = reinterpret_cast<uint32_t *>(ws);
@@ -41,14 +49,15 @@ __host__ __device__ inline WsLayout ws_layout(void *ws, uint32_t n_chunks_max)
     w.seg_base = p;
     p += n_chunks_max + 1;
     p += (4 - ((uintptr_t)(p - reinterpret_cast<uint32_t *>(ws)) & 3)) & 3;
-    w.records = p;
+    w.vals = reinterpret_cast<float2 *>(p);
+    w.keys = reinterpret_cast<uint16_t *>(w.vals + rec_cap);
     return w;
 }
 
 static inline size_t ws_bytes(uint32_t B, uint32_t L, uint32_t n_chunks_max)
 {
     const size_t head = (size_t)(kMaxLevels + 4 + 4 * (size_t)n_chunks_max + 2 + 4) * 4;
-    return head + ((size_t)B * L * 8 + 4 * (size_t)n_chunks_max + 8) * 12 + 64;
+    return head + ws_rec_cap(B, L, n_chunks_max) * 12 + 64;   // (10 bytes per record are used: float2 + uint16)
 }
 
 template <int CTRL>

@@ -152,10 +152,11 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w, 
 }
 
 // ------------------------------------------------------------------ fill
-// LDS: hist[nbins] | lbase[nbins] | gbase[nbins] | stage[8 * kFillTile] x 12 B  (row-in-chunk | chunk << 12, v.x, v.y)
-struct StageRec {
-    uint32_t key, vx, vy;
-};
+// One workgroup = 512 samples of one level.  Records (row-in-chunk, w * g.x, w * g.y) are sorted by chunk inside the
+// workgroup (LDS) and leave it as two contiguous streams per chunk: float2 payloads and uint16 keys (10 bytes a record).
+// LDS: hist[nbins] | lbase[nbins] | delta[nbins] | stage_key[8 * kFillTile] u32 | stage_val[8 * kFillTile] float2
+// Phases (4 barriers): zero hist | locate, weights, run merge, hist atomics | wave 0: scan -> lbase, cursor atomics in
+// flight | stage (wave 0 first turns the returned cursors into delta = global slot - staging slot) | stream out
 __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
                                                          const int32_t *__restrict__ offsets,
                                                          const int32_t *__restrict__ B_dev, uint32_t B_cap, uint32_t gstride,
@@ -164,9 +165,10 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
                                                          WsLayout w)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *hist = lds, *lbase = lds + nbins_cap, *gbase = lds + 2 * nbins_cap;
-    StageRec *stage = reinterpret_cast<StageRec *>(lds + 3 * nbins_cap);
-    __shared__ uint32_t wave_tot[kFillBlock / 64];
+    uint32_t *hist = lds, *lbase = lds + nbins_cap, *delta = lds + 2 * nbins_cap;
+    uint32_t *stage_key = lds + 3 * nbins_cap;
+    float2 *stage_val = reinterpret_cast<float2 *>(stage_key + 8 * kFillTile);   // 8-byte aligned: nbins_cap % 4 == 0
+    __shared__ uint32_t s_total;
 
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
@@ -219,50 +221,73 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
         // (evaluated by every lane before the &&: a DPP scan under a divergent EXEC mask reads disabled lanes)
         const float active_in_run = run_sum(active ? 1.0f : 0.0f, flags);
         emit = tail && active_in_run > 0.0f;
+        // (a wave without a single active sample has nothing to add up: wave-uniform, so the scans below stay legal)
+        if (__ballot(active) != 0ull) {
 #pragma unroll
-        for (uint32_t corner = 0; corner < 8; corner++) {
-            vx[corner] = run_sum(vx[corner], flags);
-            vy[corner] = run_sum(vy[corner], flags);
+            for (uint32_t corner = 0; corner < 8; corner++) {
+                vx[corner] = run_sum(vx[corner], flags);
+                vy[corner] = run_sum(vy[corner], flags);
+            }
         }
     }
     if (emit) {   // only a run's last lane needs the rows (hashes)
         const AxisTerms<3> terms = axis_terms<3>(g, cl);
 #pragma unroll
-        for (uint32_t corner = 0; corner < 8; corner++) rows[corner] = row_from_terms<3>(g, terms, corner);
-    }
-    if (emit) {
-#pragma unroll
-        for (uint32_t corner = 0; corner < 8; corner++) pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
+        for (uint32_t corner = 0; corner < 8; corner++) {
+            rows[corner] = row_from_terms<3>(g, terms, corner);
+            pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
+        }
     }
     __syncthreads();
 
-    // exclusive scan of hist -> staging offsets; reserve the global ranges
-    {
-        const uint32_t per = (nbins + kFillBlock - 1) / kFillBlock;   // consecutive bins per lane
-        const uint32_t lo = threadIdx.x * per, hi = min(nbins, lo + per);
-        uint32_t sum = 0;
-        for (uint32_t i = lo; i < hi; i++) sum += hist[i];
-        const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-        uint32_t inc = sum;
+    // wave 0: exclusive scan of hist -> staging offsets (lbase); reserve the global ranges with one atomic per non-empty
+    // bin -- issued here, consumed after the next barrier, so their round trip overlaps the other waves' staging
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool fast = nbins <= 128u;               // two bins per lane of wave 0 (every level of the field's table)
+    uint32_t g0 = 0, g1 = 0, n0 = 0, n1 = 0, run0 = 0;
+    if (threadIdx.x < 64u) {
+        if (fast) {
+            const uint32_t i0 = 2u * lane, i1 = i0 + 1u;
+            n0 = i0 < nbins ? hist[i0] : 0u;
+            n1 = i1 < nbins ? hist[i1] : 0u;
+            uint32_t inc = n0 + n1;
 #pragma unroll
-        for (uint32_t d = 1; d < 64u; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += up;
-        }
-        if (lane == 63u) wave_tot[wid] = inc;
-        __syncthreads();
-        uint32_t run = inc - sum;
-        for (uint32_t k = 0; k < wid; k++) run += wave_tot[k];
-        for (uint32_t i = lo; i < hi; i++) {
-            const uint32_t n = hist[i];
-            lbase[i] = run;
-            gbase[i] = n ? w.offset[first + i] + atomicAdd(&w.cursor[first + i], n) : 0u;
-            run += n;
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += up;
+            }
+            run0 = inc - (n0 + n1);
+            if (i0 < nbins) lbase[i0] = run0;
+            if (i1 < nbins) lbase[i1] = run0 + n0;
+            if (lane == 63u) s_total = inc;
+            if (n0) g0 = w.offset[first + i0] + atomicAdd(&w.cursor[first + i0], n0);
+            if (n1) g1 = w.offset[first + i1] + atomicAdd(&w.cursor[first + i1], n1);
+        } else {   // many bins per lane: consecutive runs of bins, serial inside the lane
+            const uint32_t per = (nbins + 63u) / 64u, lo = lane * per, hi = min(nbins, lo + per);
+            uint32_t sum = 0;
+            for (uint32_t i = lo; i < hi; i++) sum += hist[i];
+            uint32_t inc = sum;
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += up;
+            }
+            uint32_t run = inc - sum;
+            for (uint32_t i = lo; i < hi; i++) {
+                const uint32_t n = hist[i];
+                lbase[i] = run;
+                delta[i] = n ? w.offset[first + i] + atomicAdd(&w.cursor[first + i], n) - run : 0u;
+                run += n;
+            }
+            if (lane == 63u) s_total = inc;
         }
     }
     __syncthreads();
-    uint32_t total = 0;
-    for (uint32_t k = 0; k < kFillBlock / 64; k++) total += wave_tot[k];
+    if (threadIdx.x < 64u && fast) {
+        const uint32_t i0 = 2u * lane, i1 = i0 + 1u;
+        if (i0 < nbins) delta[i0] = g0 - run0;
+        if (i1 < nbins) delta[i1] = g1 - (run0 + n0);
+    }
 
     // stage the records sorted by chunk
     float gmax = nan ? __uint_as_float(0x7f800000u) : 0.0f;   // NaN -> inf
@@ -271,11 +296,9 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
         for (uint32_t corner = 0; corner < 8; corner++) {
             gmax = fmaxf(gmax, fmaxf(fabsf(vx[corner]), fabsf(vy[corner])));
             const uint32_t bin = rows[corner] >> kChunkShift;
-            StageRec r;
-            r.key = (rows[corner] & (kChunkRows - 1u)) | (bin << kChunkShift);
-            r.vx = __float_as_uint(vx[corner]);
-            r.vy = __float_as_uint(vy[corner]);
-            stage[lbase[bin] + pos[corner]] = r;
+            const uint32_t slot = lbase[bin] + pos[corner];
+            stage_key[slot] = (rows[corner] & (kChunkRows - 1u)) | (bin << kChunkShift);
+            stage_val[slot] = make_float2(vx[corner], vy[corner]);
         }
     }
     // largest |gradient| of the call -> fixed-point scale of the reduce kernel; one word for the whole grid,
@@ -285,15 +308,13 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     if ((threadIdx.x & 63u) == 0 && __float_as_uint(gmax) > __builtin_nontemporal_load(&w.chunk_base[kMaxLevels + 1]))
         atomicMax(&w.chunk_base[kMaxLevels + 1], __float_as_uint(gmax));
     __syncthreads();
-    // consecutive lanes -> consecutive WORDS of the record stream of one chunk (until the chunk changes): every store
-    // instruction covers 256 contiguous bytes instead of 64 words 12 bytes apart
-    const uint32_t *stage_u = reinterpret_cast<const uint32_t *>(stage);
-    for (uint32_t q = threadIdx.x; q < total * 3u; q += kFillBlock) {
-        const uint32_t j = __umulhi(q, 0xAAAAAAABu) >> 1, comp = q - j * 3u;   // q / 3
-        const uint32_t key = stage_u[j * 3u];
-        const uint32_t bin = key >> kChunkShift;
-        const uint32_t val = comp == 0u ? (key & (kChunkRows - 1u)) : stage_u[q];
-        w.records[(size_t)(gbase[bin] + (j - lbase[bin])) * 3 + comp] = val;
+    // consecutive lanes -> consecutive records of one chunk (until the chunk changes): contiguous 8-byte and 2-byte stores
+    const uint32_t total = s_total;
+    for (uint32_t j = threadIdx.x; j < total; j += kFillBlock) {
+        const uint32_t key = stage_key[j];
+        const uint32_t dst = j + delta[key >> kChunkShift];
+        w.vals[dst] = stage_val[j];
+        w.keys[dst] = (uint16_t)(key & (kChunkRows - 1u));
     }
 }
 
@@ -386,36 +407,41 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
 
     // fixed-point scale: max |g| < 2^e  ->  |g * 2^k| < 2^(62 - headroom) with k = 62 - headroom - e
     int e;
-    frexpf(__uint_as_float(w.chunk_base[kMaxLevels + 1]), &e);
+    const float gmax = __uint_as_float(w.chunk_base[kMaxLevels + 1]);
+    // a non-finite gradient anywhere in the batch (the fill turns NaN into inf): no fixed-point scale exists and an Adam
+    // step on it would poison the table for good -- skip the update, like the reference's GradScaler skips the step
+    if (ADAM && !(gmax < __uint_as_float(0x7f800000u))) return;
+    frexpf(gmax, &e);
     const int k = 62 - kHeadroomBits - e;
 
-    const uint4 *rec4 = reinterpret_cast<const uint4 *>(w.records);   // 4 records = 3 x 16 bytes
-    auto apply = [&](uint32_t row, uint32_t gx, uint32_t gy) {
-        const long long qx = __double2ll_rn(scalbn((double)__uint_as_float(gx), k));
-        const long long qy = __double2ll_rn(scalbn((double)__uint_as_float(gy), k));
+    // 4 records per lane and load group: keys 8 bytes, payloads 2 x 16 bytes; two groups in flight
+    auto apply = [&](uint32_t row, float gx, float gy) {
+        const long long qx = __double2ll_rn(scalbn((double)gx, k));
+        const long long qy = __double2ll_rn(scalbn((double)gy, k));
         atomicAdd(&acc[row * 2], (unsigned long long)qx);
         atomicAdd(&acc[row * 2 + 1], (unsigned long long)qy);
     };
+    const uint2 *key4 = reinterpret_cast<const uint2 *>(w.keys);       // 4 keys per uint2
+    const float4 *val2 = reinterpret_cast<const float4 *>(w.vals);     // 2 payloads per float4
     for (uint32_t i0 = beg + threadIdx.x * 4; i0 < end; i0 += kReduceBlock * 8) {
-        // two groups of 4 records per lane in flight
         const uint32_t i1 = i0 + kReduceBlock * 4;
-        const size_t q0 = (size_t)(i0 >> 2) * 3;
-        const uint4 a0 = rec4[q0], a1 = rec4[q0 + 1], a2 = rec4[q0 + 2];
-        uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0;
+        const uint2 ka = key4[i0 >> 2];
+        const float4 a0 = val2[i0 >> 1], a1 = val2[(i0 >> 1) + 1];
+        uint2 kb = make_uint2(0, 0);
+        float4 b0 = make_float4(0, 0, 0, 0), b1 = b0;
         if (i1 < end) {
-            const size_t q1 = (size_t)(i1 >> 2) * 3;
-            b0 = rec4[q1];
-            b1 = rec4[q1 + 1];
-            b2 = rec4[q1 + 2];
+            kb = key4[i1 >> 2];
+            b0 = val2[i1 >> 1];
+            b1 = val2[(i1 >> 1) + 1];
         }
-        apply(a0.x, a0.y, a0.z);
-        if (i0 + 1 < end) apply(a0.w, a1.x, a1.y);
-        if (i0 + 2 < end) apply(a1.z, a1.w, a2.x);
-        if (i0 + 3 < end) apply(a2.y, a2.z, a2.w);
-        if (i1 < end) apply(b0.x, b0.y, b0.z);
-        if (i1 + 1 < end) apply(b0.w, b1.x, b1.y);
-        if (i1 + 2 < end) apply(b1.z, b1.w, b2.x);
-        if (i1 + 3 < end) apply(b2.y, b2.z, b2.w);
+        apply(ka.x & 0xffffu, a0.x, a0.y);
+        if (i0 + 1 < end) apply(ka.x >> 16, a0.z, a0.w);
+        if (i0 + 2 < end) apply(ka.y & 0xffffu, a1.x, a1.y);
+        if (i0 + 3 < end) apply(ka.y >> 16, a1.z, a1.w);
+        if (i1 < end) apply(kb.x & 0xffffu, b0.x, b0.y);
+        if (i1 + 1 < end) apply(kb.x >> 16, b0.z, b0.w);
+        if (i1 + 2 < end) apply(kb.y & 0xffffu, b1.x, b1.y);
+        if (i1 + 3 < end) apply(kb.y >> 16, b1.z, b1.w);
     }
     __syncthreads();
 
@@ -498,12 +524,12 @@ int binned_setup(BinnedCall &c, const char *who, const int32_t *offsets, uint32_
     NGP_REQUIRE(workspace_bytes >= ws_bytes(B, L, c.n_chunks_max), "%s: workspace too small", who);
     NGP_REQUIRE((uint64_t)B * L * 8 + 4ull * c.n_chunks_max < (1ull << 32), "%s: B * L too large", who);
     NGP_REQUIRE(c.n_chunks_max <= kMaxChunks, "%s: table too large (> %u chunks)", who, kMaxChunks);
-    c.w = ws_layout(workspace, c.n_chunks_max);
+    c.w = ws_layout(workspace, c.n_chunks_max, ws_rec_cap(B, L, c.n_chunks_max));
     // LDS histograms are per level: the caller may tell us the largest level (rows); 0 = unknown
     NGP_REQUIRE(max_level_rows <= n_rows_total, "%s: max_level_rows > n_rows_total", who);
     const uint32_t level_chunks = max_level_rows ? ceil_div(max_level_rows, kChunkRows) : c.n_chunks_max;
     c.nbins_cap = (level_chunks + 3u) & ~3u;
-    c.fill_lds = (size_t)c.nbins_cap * 12 + (size_t)kFillTile * 8 * sizeof(StageRec);
+    c.fill_lds = (size_t)c.nbins_cap * 12 + (size_t)kFillTile * 8 * 12;
     return NGP_OK;
 }
 }  // namespace
@@ -563,7 +589,7 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
     static const bool lds_ok = [] {   // the fill kernel wants more than the default 64 KiB of dynamic LDS
         return hipFuncSetAttribute(reinterpret_cast<const void *>(bin_fill_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kMaxChunks * 12 + kFillTile * 8 * sizeof(StageRec)) == hipSuccess;
+                                   kMaxChunks * 12 + kFillTile * 8 * 12) == hipSuccess;
     }();
     NGP_REQUIRE(lds_ok, "grid_backward_binned_apply: cannot raise the dynamic LDS limit");
     hipStream_t st = as_stream(stream);
