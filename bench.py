@@ -153,7 +153,7 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
                   fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
                   aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
-                  dp_rehearsal=args.dp_rehearsal, graph_collective=args.graph_collective)
+                  dp_rehearsal=args.dp_rehearsal, graph_collective=args.graph_collective, group_steps=args.group_steps)
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
     fused = not (args.autograd or args.torch_mlp)
@@ -185,11 +185,15 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     t0 = time.perf_counter()
     samples = 0
     host = 0.0
-    for _ in range(args.steps):
+    if fused:       # the engine's own loop: consecutive steps are replayed from one graph where nothing forbids it
         h0 = time.perf_counter()
-        trainer.train_step()
-        host += time.perf_counter() - h0
-        if not fused:
+        trainer.train(args.steps)
+        host = time.perf_counter() - h0
+    else:
+        for _ in range(args.steps):
+            h0 = time.perf_counter()
+            trainer.train_step()
+            host += time.perf_counter() - h0
             samples += trainer.last_num_points      # (host value of the per-op path; the fused step never syncs)
     torch.cuda.synchronize()
     parallel.barrier()
@@ -258,7 +262,9 @@ def main():
                          "region if needed; 0 = skip)")
     ap.add_argument("--arena", type=int, default=0, help="sample arena capacity (0 = reference two-pass march)")
     ap.add_argument("--torch-mlp", action="store_true", help="fp32 nn.Linear MLPs instead of the fused f16 MFMA field")
-    ap.add_argument("--probe-every", type=int, default=4,
+    ap.add_argument("--group-steps", type=int, default=8,
+                    help="fused step: consecutive steps per captured graph (1 = one graph launch per step)")
+    ap.add_argument("--probe-every", type=int, default=8,
                     help="time every N-th launch of the roofline entry point with HIP events (each timed launch drains the queue)")
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event roofline probe (roofline: null)")
     ap.add_argument("--no-graph", action="store_true", help="fused step: launch kernels one by one (no hipGraph replay)")
@@ -365,7 +371,7 @@ def main():
                        "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
                        "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
                        "parallelism": f"dp{world}", "grad_wire": args.grad_wire if (world > 1 or args.dp_rehearsal) else None, "replicas_in_sync": in_sync, "step": "fused" if fused else "autograd",
-                       "graph": tinfo["graph"], "prefetch": tinfo["prefetch"],
+                       "graph": tinfo["graph"], "group_steps": args.group_steps, "prefetch": tinfo["prefetch"],
                        "device_sampler": tinfo["device_sampler"],
                        "host_enqueue_ms_per_step": round(host / max(args.steps, 1) * 1e3, 4),
                        "untrained_cells": untrained_cells, "arena_capacity": tinfo["cap"], "arena_overflow": bool(fused and overflow)},

@@ -191,6 +191,14 @@ def probe_next_timed():
     return _probe["calls"].get(_probe["names"][0], 0) % _probe["every"] == 0
 
 
+def probe_untimed_run():
+    """Number of upcoming calls of the probed symbols that will NOT be timed (a large number when nothing is probed)."""
+    if not _probe["names"]:
+        return 1 << 30
+    k = _probe["calls"].get(_probe["names"][0], 0) % _probe["every"]
+    return 0 if k == 0 else _probe["every"] - k
+
+
 def probe_skip(names=None):
     """Account for calls that happened inside a captured graph (where nothing can be timed)."""
     for n in (names or _probe["names"]):

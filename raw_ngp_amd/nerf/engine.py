@@ -684,9 +684,67 @@ class FusedTrainer:
     def last_num_points(self):
         return int(self.arena.counter[0])          # host read: only for logging
 
+    # ------------------------------------------------------------------ several steps per graph
+    def _multi_step(self, limit):
+        """Run up to `limit` (and at most self.group_steps) consecutive regular steps from ONE captured graph; returns how
+        many it ran (0: the caller takes a single train_step).  Between two graph launches the GPU idles for ~ 20 us (the
+        replay floor of a dependent launch); a step is ~ 0.4 ms, so one launch per step costs 5 %.  A group never contains
+        a density-grid refresh (those steps go through train_step), nor a step whose kernels bench.py times with events."""
+        from .. import _lib
+        opt = self.opt
+        every = opt.update_extra_interval
+        s = self.global_step
+        if not (self.use_graph and self.prefetch and self.device_sampler and self.march_mode != "index" and not self.dp
+                and s >= 2 and s % every != 0 and self._image_ready):
+            return 0
+        G = min(limit, every - s % every, int(getattr(opt, "group_steps", 8)), _lib.probe_untimed_run())
+        slot = self.slots[s % 2]
+        if G < 2 or slot.step != s:
+            return 0
+        G = 1 << (G.bit_length() - 1)              # 2, 4, 8: a handful of graph variants, all captured early in a run
+                                                   # (a capture takes milliseconds: none may fall into a timed region)
+        last_ahead = (s + G) % every != 0          # does the group's last step draw the rays of the step after it?
+        key = ("multi", s % 2, G, last_ahead)
+        if key not in self.graphs:
+            if self.graph_pool is None:
+                self.graph_pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
+                main = torch.cuda.current_stream(self.device)
+                for k in range(G):
+                    cur = self.slots[(s + k) % 2]
+                    nxt = self.slots[(s + k + 1) % 2] if (k + 1 < G or last_ahead) else None
+                    if nxt is not None:         # fork: the next step's rays, on the side stream
+                        self.side.wait_stream(main)
+                        with torch.cuda.stream(self.side):
+                            self._load_slot(nxt)
+                    self._run_ops(self._step_ops(cur), fork=bool(getattr(opt, "aux_stream", False)))
+                    if nxt is not None:
+                        main.wait_stream(self.side)     # join
+            self._graphs_alive.append(g)
+            self.graphs[key] = [g.replay]
+        for part in self.graphs[key]:           # (capturing does not execute anything)
+            part()
+        probed = [n for n in _lib.probed_symbols() if n in self._main_symbols]
+        for k in range(G):
+            nxt_step = s + k + 1
+            if k + 1 < G or last_ahead:
+                self.slots[nxt_step % 2].step = nxt_step
+            if probed:
+                _lib.probe_skip(probed)
+        self.global_step += G
+        self.last_loss = self.loss
+        self.last_graph_key = key
+        return G
+
     def train(self, steps, log_every=0):
-        for _ in range(steps):
-            self.train_step()
+        done = 0
+        while done < steps:
+            n = 0 if log_every else self._multi_step(steps - done)
+            if n == 0:
+                self.train_step()
+                n = 1
+            done += n
             if log_every and self.rank == 0 and self.global_step % log_every == 0:
                 needed = int(self.arena.counter[1])
                 print(f"[step {self.global_step}] loss {float(self.loss):.5f} samples {self.last_num_points}"

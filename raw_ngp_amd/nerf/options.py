@@ -74,4 +74,5 @@ class Options:
     march_mode: str = "chain"     # fused engine, march pass 1: chain | index | serial (see engine.py)
     device_sampler: bool = True   # fused engine: draw ray batches with one kernel (Philox) instead of torch ops
     capture_graph: bool = True    # fused engine: replay whole steps from captured hipGraphs
+    group_steps: int = 8          # fused engine: consecutive regular steps replayed from ONE graph (1 = a graph per step)
     prefetch_march: bool = True   # fused engine: march step i+1's rays on a second stream during step i's backward
