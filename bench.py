@@ -153,7 +153,8 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
                   fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
                   aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
-                  dp_rehearsal=args.dp_rehearsal, graph_collective=args.graph_collective, group_steps=args.group_steps)
+                  dp_rehearsal=args.dp_rehearsal, graph_collective=args.graph_collective, group_steps=args.group_steps,
+                  dp_mode=args.dp_mode)
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
     fused = not (args.autograd or args.torch_mlp)
@@ -181,6 +182,8 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     parallel.barrier()
     torch.cuda.synchronize()
     _lib.probe_reset()
+    if fused and trainer.dp and trainer.shard is not None:
+        trainer.collective_events = []          # HIP events around the step's collectives, read after the timed region
     seen0 = int(trainer.samples_seen) if fused else 0
     t0 = time.perf_counter()
     samples = 0
@@ -198,6 +201,10 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
+    collective_ms = None
+    if fused and getattr(trainer, "collective_events", None):
+        collective_ms = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / max(args.steps, 1)
+        trainer.collective_events = None
     probe = _lib.probe_results(symbols)
     probe_fwd = _lib.probe_results((fwd_symbol,)) if fwd_symbol in probed else (0, 0, 0.0)
     _lib.set_probe(None)
@@ -231,6 +238,7 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
 
     return dict(dt=dt, host=host, samples=samples, probe=probe, probe_fwd=probe_fwd, probed=probed, fwd_symbol=fwd_symbol,
                 bytes_per_sample=bytes_per_sample, in_sync=in_sync, psnr=psnr, trainer=trainer, fused=fused,
+                collective_ms=collective_ms,
                 untrained_cells=untrained_cells, overflow=bool(fused and overflow), model=model)
 
 
@@ -275,6 +283,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"],
                     help="data parallel: wire format of the table-gradient all-reduce")
+    ap.add_argument("--dp-mode", default="shard", choices=["shard", "allreduce"],
+                    help="data parallel: reduce_scatter -> Adam on 1/R of the table -> all_gather (shard), or gradient "
+                         "all-reduce + full Adam on every rank (allreduce)")
     ap.add_argument("--graph-collective", action="store_true",
                     help="data parallel: capture the RCCL all-reduce inside the step graph (experimental, off by default)")
     ap.add_argument("--dp-rehearsal", action="store_true",
@@ -295,12 +306,19 @@ def main():
     torch.cuda.set_device(dev)
     _lib.load()
     torch.manual_seed(0)
+    # how many ranks the collectives really span (an all-reduce of ones), for the record
+    ranks_seen = 1
+    if parallel.is_dist():
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
     res = run_config(args, args.bound, args.background, rank, world, dev)
     dt, host, samples, probe, probe_fwd = res["dt"], res["host"], res["samples"], res["probe"], res["probe_fwd"]
     probed, fwd_symbol, bytes_per_sample, in_sync, psnr = (res["probed"], res["fwd_symbol"], res["bytes_per_sample"],
                                                            res["in_sync"], res["psnr"])
     trainer, fused, untrained_cells, overflow = res["trainer"], res["fused"], res["untrained_cells"], res["overflow"]
+    collective_ms = res["collective_ms"]
     # what the JSON line needs from the primary run's trainer (it is freed before the secondary runs)
     tinfo = {"fuse_adam": bool(fused and getattr(trainer, "fuse_adam", False)),
              "table_numel": int(trainer.table.numel()) if fused else 0,
@@ -370,7 +388,12 @@ def main():
                                    + ("fp32 nn.Linear MLPs" if args.torch_mlp else "fused tiny-MLP (configs[2])"),
                        "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
                        "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
-                       "parallelism": f"dp{world}", "grad_wire": args.grad_wire if (world > 1 or args.dp_rehearsal) else None, "replicas_in_sync": in_sync, "step": "fused" if fused else "autograd",
+                       "parallelism": f"dp{world}", "grad_wire": args.grad_wire if (world > 1 or args.dp_rehearsal) else None,
+                       "dp_mode": args.dp_mode if (world > 1 or args.dp_rehearsal) else None, "ranks_seen": ranks_seen,
+                       "collective_ms_per_step": None if collective_ms is None else round(collective_ms, 4),
+                       "multi_gpu_measured": "RCCL over >1 rank has not been measured by the builder (no multi-GPU box in reach): "
+                                             "this line is the first measurement" if world > 1 else None,
+                       "replicas_in_sync": in_sync, "step": "fused" if fused else "autograd",
                        "graph": tinfo["graph"], "group_steps": args.group_steps, "prefetch": tinfo["prefetch"],
                        "device_sampler": tinfo["device_sampler"],
                        "host_enqueue_ms_per_step": round(host / max(args.steps, 1) * 1e3, 4),

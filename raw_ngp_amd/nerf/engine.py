@@ -165,6 +165,27 @@ class FusedTrainer:
             self._wire_flat = torch.zeros(n_t + self.w_grad.numel(), dtype=torch.bfloat16, device=dev)
             self._wire = self._wire_flat[:n_t].view(self.table_grad.shape)
             self._wire_w = self._wire_flat[n_t:]
+        # data parallel, "shard" mode: reduce_scatter the table gradient, Adam on this rank's 1/R of the (flat, padded) table
+        # with moments that exist for that shard only, all_gather the updated rows (parallel.ShardedStep)
+        self.shard = None
+        self.collective_events = None           # bench.py: [(start, stop)] HIP events around the collectives of a step
+        if self.dp and getattr(opt, "dp_mode", "shard") == "shard" and opt.lambda_tv == 0 and opt.lambda_wd == 0:
+            n = self.table.numel()
+            n_pad = parallel.padded_numel(n)
+            flat = torch.zeros(n_pad, **f32)
+            flat[:n].copy_(self.table.reshape(-1))
+            self.table = flat[:n].view(self.rows, 2)
+            enc.embeddings.data = self.table                # the module's parameter lives in the padded buffer
+            gdt = torch.bfloat16 if self.wire16 else torch.float32
+            gflat = torch.zeros(n_pad, dtype=gdt, device=dev)
+            if self.wire16:
+                self._wire = gflat[:n].view(self.rows, 2)
+                self._wire_flat = self._wire_w = None       # (the MLP gradients travel on their own, in f32)
+            else:
+                self.table_grad = gflat[:n].view(self.rows, 2)
+            self.shard = parallel.ShardedStep(flat, gflat)
+            self.t_m = torch.zeros(self.shard.n_shard, **f32)
+            self.t_v = torch.zeros(self.shard.n_shard, **f32)
         self._main_symbols = {"ngp_x_mlp_rf_forward", "ngp_x_mlp_rf_backward", "ngp_x_mlp_rf_prepare",
                               "ngp_x_grid_encode_forward_slab_jac", "ngp_x_composite_hdr_train",
                               "ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
@@ -434,6 +455,34 @@ class FusedTrainer:
             dist.all_reduce(self.table_grad)
             self.table_grad.div_(self.world_size)
 
+    def _timed(self, fn):
+        """Run fn() between two HIP events on the current stream when bench.py asked for collective timings."""
+        if self.collective_events is None:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.collective_events.append((a, b))
+
+    def _sharded_exchange_and_step(self):
+        """Data parallel, "shard" mode (eager, outside the step's graphs): reduce_scatter of the table gradient and
+        all-reduce of the 53 KiB of MLP gradients, Adam on this rank's shard of the table and on the (replicated) MLP
+        weights in one launch, all_gather of the updated table rows."""
+        sh, dist = self.shard, torch.distributed
+
+        def reduce():
+            sh.reduce_scatter()
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(self.w_grad, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self.w_grad)
+                self.w_grad.div_(self.world_size)
+        self._timed(reduce)
+        eb.adam_step_dev2((sh.param_shard, sh.grad_shard, self.t_m, self.t_v, False),
+                          (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
+        self._timed(sh.all_gather)
+
     def optimizer_step(self, device_hyper=False):
         """Adam on the table and the MLP weights.  device_hyper: learning rate and bias corrections come from
         self.hyper (written by schedule_step earlier in the step) instead of host scalars."""
@@ -447,6 +496,7 @@ class FusedTrainer:
             eb.adam_step_dev2((self.table, self._wire if self.wire16 else self.table_grad, self.t_m, self.t_v, False),
                               (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
             return
+        assert self.shard is None, "data parallel 'shard' mode: only the step path (train_step) owns the optimiser"
         step, lr = self.global_step + 1, self.lr()
         eb.adam_step(self.table, self.table_grad, self.t_m, self.t_v, lr, *self.betas, self.eps, step, zero_grad=True)
         eb.adam_step(self.w_flat, self.w_grad, self.w_m, self.w_v, lr, *self.betas, self.eps, step, zero_grad=False)
@@ -545,6 +595,9 @@ class FusedTrainer:
             return ops
         assert not self.rfield, "fused rfield step: single-GPU fused-Adam variant only (data parallel: use Trainer)"
         ops += [(n, o, "main") for n, o in field]
+        if self.shard is not None:
+            ops.append(("all_reduce", self._sharded_exchange_and_step, "main"))
+            return ops
         if self.dp:
             if self.wire16:
                 ops.append(("wire_pack", lambda: self._wire_w.copy_(self.w_grad), "main"))

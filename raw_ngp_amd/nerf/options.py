@@ -68,6 +68,8 @@ class Options:
     dp_rehearsal: bool = False    # run the data-parallel step on ONE rank (needs an initialised process group)
     grad_wire: str = "f32"        # data parallel: wire format of the gradient exchange (f32 | bf16; bf16 is an opt-in:
                                   # the cross-rank sum is then formed in bfloat16, narrower than anything the reference does)
+    dp_mode: str = "shard"        # data parallel: "shard" = reduce_scatter -> Adam on 1/R of the table -> all_gather
+                                  # (SURVEY 8e), "allreduce" = gradient all-reduce + full Adam on every rank
     aux_stream: bool = False      # fused engine: MLP-weight tail (dW reduction, Adam, f16 image) on a third stream
                                   # (measured slower: the fork/join costs more than the ~20 us it takes off the main stream)
     fuse_adam: bool = True        # fused engine, one rank: Adam on the table inside the gradient reduction kernel

@@ -61,3 +61,49 @@ def test_single_process_is_a_noop():
     parallel.broadcast_module(m)
     parallel.GradReducer(m).all_reduce()
     parallel.barrier()
+
+
+def _shard_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from raw_ngp_amd import parallel
+    parallel.init_from_env("cpu")
+    n = 100_003                                                     # not divisible by anything convenient
+    N = parallel.padded_numel(n)
+    assert N % (4 * world) == 0 and 0 <= N - n < 4 * world
+    g0 = torch.Generator().manual_seed(5)
+    param = torch.zeros(N)
+    param[:n] = torch.randn(n, generator=g0)                        # replicas start identical
+    grad = torch.zeros(N)
+    grad[:n] = torch.randn(n, generator=torch.Generator().manual_seed(50 + rank))    # every rank: its own gradient
+    step = parallel.ShardedStep(param, grad)
+    m, v = torch.zeros(step.n_shard), torch.zeros(step.n_shard)     # moments exist for this rank's shard only
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-15
+    for t in (1, 2, 3):
+        step.reduce_scatter()
+        g = step.grad_shard
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        step.param_shard.sub_((lr / (1 - b1 ** t)) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps))
+        step.all_gather()
+    torch.save({"param": param.clone(), "grad": grad.clone()}, os.path.join(out_dir, f"shard{rank}.pt"))
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_equals_adam_on_the_mean_gradient(tmp_path):
+    """reduce_scatter -> Adam on 1/R of the rows -> all_gather leaves every replica with what a single process gets from
+    torch.optim.Adam on the mean of the ranks' gradients."""
+    world = 2
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"shard{r}.pt"), weights_only=True) for r in range(world)]
+    assert torch.equal(outs[0]["param"], outs[1]["param"])          # bit-identical replicas
+    n = 100_003
+    p = torch.zeros(outs[0]["param"].numel())
+    p[:n] = torch.randn(n, generator=torch.Generator().manual_seed(5))
+    p = torch.nn.Parameter(p)
+    opt = torch.optim.Adam([p], lr=1e-2, eps=1e-15)
+    for _ in range(3):
+        p.grad = (outs[0]["grad"] + outs[1]["grad"]) / 2
+        opt.step()
+    np.testing.assert_allclose(outs[0]["param"].numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-7)
