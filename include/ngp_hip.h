@@ -421,6 +421,22 @@ int ngp_x_sample_rays_lit(const uint8_t *images, uint32_t V, uint32_t H, uint32_
                           uint32_t draw, float *rays_o, float *rays_d, float *gt_rgba, float *noises, float *bg_rgb,
                           int32_t *index, const float *view_ldirs, float *rays_ldir, ngp_stream_t stream);
 
+/* ... and adaptive batch sizes (`--adaptive_num_rays`, train_utils.py:563-564) decided on the device: the batch gets
+ * live[0] = clamp(round(num_points / prev_samples[0] * prev_live[0]), 1, N) rays (prev_samples / prev_live NULL: N), written
+ * by the kernel; ray slots >= live[0] are parked outside the volume (no samples; index -1). */
+int ngp_x_sample_rays_adaptive(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W, uint32_t C, const float *poses,
+                               float fx, float fy, float cx, float cy, uint32_t N, uint64_t seed, const uint32_t *draw_dev,
+                               uint32_t draw, float *rays_o, float *rays_d, float *gt_rgba, float *noises, float *bg_rgb,
+                               int32_t *index, const float *view_ldirs, float *rays_ldir, const int32_t *prev_samples,
+                               const int32_t *prev_live, int32_t *live, uint32_t num_points, ngp_stream_t stream);
+/* ngp_x_composite_mse_train (exposure == NULL) / ngp_x_composite_hdr_train with the loss taken over the first n_live[0]
+ * of the N ray slots only (mean over those rays; n_live == NULL: all N). */
+int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
+                               const float *weight, float inv_norm, const int32_t *n_live, const float *sigmas,
+                               const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
+                               float T_thresh, float *weights_sum, float *depth, float *image, float *grad_sigmas,
+                               float *grad_rgbs, float *loss_out, ngp_stream_t stream);
+
 /* ---- pose refinement around the fused step (csrc/pose_kernels.hip) -----------------------------------------------
  * ngp_x_step_window   annealing = float16((step_counter[0] + step_offset) / iters) (train_utils.py:488) -> the BARF level
  *                     window of network.py:99-109 for L levels (float16 alpha, float32 cosine, level 0 forced to 1) in

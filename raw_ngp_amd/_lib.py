@@ -62,6 +62,9 @@ _SIGNATURES = {
     "ngp_x_composite_hdr_train": [_p, _p, _f, _p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
     "ngp_x_sample_rays_lit": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p,
                               _p, _p],
+    "ngp_x_sample_rays_adaptive": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p,
+                                   _p, _p, _p, _p, _p, _p, _u],
+    "ngp_x_composite_train_live": [_p, _p, _f, _p, _p, _f, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
     "ngp_x_step_window": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_ray_gradients": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_pose_gradient": [_p, _p, _p, _u, _u, _u, _f, _f, _f, _f, _p],
@@ -665,6 +668,17 @@ class _EngineBackend:
               _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
 
     @staticmethod
+    def composite_train_live(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, n_live, sigmas, rgbs, ts, rays, M, N,
+                             T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out):
+        """composite_mse_train (exposure None) / composite_hdr_train over the first n_live[0] ray slots."""
+        _call("ngp_x_composite_train_live", rays, _ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
+              float(bg_const), _ptr(exposure, "f", "exposure", True), _ptr(weight, "f", "weight", True), float(inv_norm),
+              _ptr(n_live, "i", "n_live", True), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"),
+              _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
+              _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
+              _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
+
+    @staticmethod
     def step_window(step_counter, step_offset, iters, start_annealing, end_annealing, L, level_w, flags=None):
         _call("ngp_x_step_window", level_w, _ptr(step_counter, "u", "step_counter"), int(step_offset), float(iters),
               float(start_annealing), float(end_annealing), int(L), _ptr(level_w, "f", "level_w"),
@@ -739,7 +753,7 @@ class _EngineBackend:
 
     @staticmethod
     def sample_rays(images, poses, intrinsics, N, seed, draw, rays_o, rays_d, gt_rgba, noises=None, bg_rgb=None,
-                    index=None, view_ldirs=None, rays_ldir=None):
+                    index=None, view_ldirs=None, rays_ldir=None, adaptive=None):
         """`draw`: int32 device tensor (read at run time) or a Python int.  view_ldirs [V,3] + rays_ldir [N,3]: per-ray
         light directions of the light-conditioned configuration."""
         V, H, W, C = images.shape
@@ -750,7 +764,12 @@ class _EngineBackend:
                 0 if on_dev else int(draw) & 0xffffffff, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
                 _ptr(gt_rgba, "f", "gt_rgba"), _ptr(noises, "f", "noises", True), _ptr(bg_rgb, "f", "bg_rgb", True),
                 _ptr(index, "i", "index", True))
-        if view_ldirs is None and rays_ldir is None:
+        if adaptive is not None:        # (prev_samples, prev_live, live, num_points): see ngp_x_sample_rays_adaptive
+            prev_samples, prev_live, live, num_points = adaptive
+            _call("ngp_x_sample_rays_adaptive", images, *args, _ptr(view_ldirs, "f", "view_ldirs", True),
+                  _ptr(rays_ldir, "f", "rays_ldir", True), _ptr(prev_samples, "i", "prev_samples", True),
+                  _ptr(prev_live, "i", "prev_live", True), _ptr(live, "i", "live"), int(num_points))
+        elif view_ldirs is None and rays_ldir is None:
             _call("ngp_x_sample_rays", images, *args)
         else:
             _call("ngp_x_sample_rays_lit", images, *args, _ptr(view_ldirs, "f", "view_ldirs"),

@@ -254,6 +254,9 @@ struct HdrLoss {
     const float *exposure = nullptr;
     const float *weight = nullptr;
     float inv_norm = 0.0f;
+    // adaptive ray batches (train_utils.py:563-564): only the first n_live[0] of the N ray slots carry rays; the loss is
+    // the mean over those (NULL: all N)
+    const int32_t *n_live = nullptr;
 };
 
 template <int MODE>
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
     if (MODE >= 1) {   // the whole workgroup passes the barrier before any wave leaves
         if (lane == 0) ray_err[threadIdx.x >> 6] = 0.0f;
     }
-    const bool in_range = n < N;
+    const uint32_t n_rays = hdr.n_live ? min((uint32_t)max(hdr.n_live[0], 1), N) : N;
+    const bool in_range = n < n_rays;
     const uint32_t nn = in_range ? n : 0u;
     const uint32_t off = (uint32_t)rays[(size_t)nn * 2], cnt = (uint32_t)rays[(size_t)nn * 2 + 1];
     const bool live = in_range && cnt != 0 && off + cnt <= M;
@@ -334,7 +338,8 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
             for (int c = 0; c < 3; c++) {
                 const float scaled = pred[c] * ex, clip = fminf(1.0f, scaled);
                 const float sg = 1.0f / (1e-3f + clip), resid = clip - gt[c];
-                const float wgt = (hdr.weight ? hdr.weight[(size_t)nn * 3 + c] : 1.0f) * hdr.inv_norm;
+                const float wgt = (hdr.weight ? hdr.weight[(size_t)nn * 3 + c] : 1.0f) *
+                                  (hdr.n_live ? 1.0f / (3.0f * (float)n_rays) : hdr.inv_norm);
                 ray_loss += resid * resid * (sg * sg) * wgt;
                 gch[c] = scaled < 1.0f ? 2.0f * resid * (sg * sg) * wgt * ex : 0.0f;   // no gradient through the clip
             }
@@ -345,11 +350,11 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
             const float e0 = (rF + (1.0f - wsF) * b0) - (px.x * px.w + b0 * (1.0f - px.w));
             const float e1 = (gF + (1.0f - wsF) * b1) - (px.y * px.w + b1 * (1.0f - px.w));
             const float e2 = (bF + (1.0f - wsF) * b2) - (px.z * px.w + b2 * (1.0f - px.w));
-            const float k = 2.0f / (3.0f * (float)N);
+            const float k = 2.0f / (3.0f * (float)n_rays);
             gr = k * e0;
             gg = k * e1;
             gb = k * e2;
-            ray_loss = (e0 * e0 + e1 * e1 + e2 * e2) / (3.0f * (float)N);
+            ray_loss = (e0 * e0 + e1 * e1 + e2 * e2) / (3.0f * (float)n_rays);
         }
         gws = -(gr * b0 + gg * b1 + gb * b2);
         gd = 0.0f;
@@ -554,15 +559,51 @@ __global__ __launch_bounds__(1024) void step_begin_kernel(uint32_t *step_counter
 // The random_image_batch collate + get_rays + target gather of the harness (nerf/provider.py, nerf/train_utils.py:96-172)
 // as one kernel: every ray draws its own (view, pixel), builds its origin / direction from that view's pose and
 // reads its target colour.  Pixel centre +0.5, camera looks down -z, y flipped, directions not normalised.
+// Adaptive ray batches (`--adaptive_num_rays`, train_utils.py:563-564: num_rays <- round(num_points / samples * num_rays)
+// after every step) without a host read: the batch drawn for step i + 1 looks at the sample count step i's march left on
+// the device and at step i's ray count.  Only the first live[0] of the N ray slots get rays; the others are parked outside
+// the volume (no samples, excluded from the loss).  prev_samples == NULL: no adaptation (all N rays live).
+struct AdaptiveRays {
+    const int32_t *prev_samples = nullptr;   // samples of the previous batch (arena counter)
+    const int32_t *prev_live = nullptr;      // rays of the previous batch
+    int32_t *live = nullptr;                 // out: rays of this batch
+    uint32_t num_points = 0;                 // target samples per batch
+};
+
 __global__ __launch_bounds__(256) void sample_rays_kernel(
     const uint8_t *__restrict__ images, uint32_t V, uint32_t H, uint32_t W, uint32_t C, const float *__restrict__ poses,
     float fx, float fy, float cx, float cy, uint32_t N, uint32_t seed_lo, uint32_t seed_hi,
     const uint32_t *__restrict__ draw_dev, uint32_t draw, float *__restrict__ rays_o, float *__restrict__ rays_d,
     float *__restrict__ gt, float *__restrict__ noises, float *__restrict__ bg, int32_t *__restrict__ index,
-    const float *__restrict__ view_ldirs = nullptr, float *__restrict__ rays_ldir = nullptr)
+    const float *__restrict__ view_ldirs = nullptr, float *__restrict__ rays_ldir = nullptr,
+    AdaptiveRays ad = AdaptiveRays{})
 {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
+    if (ad.live) {
+        uint32_t n_live = N;
+        if (ad.prev_samples) {   // python: int(round(num_points / num_points_seen * num_rays)), kept inside [1, N]
+            const double ratio = (double)ad.num_points / (double)max(ad.prev_samples[0], 1);
+            n_live = (uint32_t)fmin(fmax(rint(ratio * (double)max(ad.prev_live[0], 1)), 1.0), (double)N);
+        }
+        if (n == 0) ad.live[0] = (int32_t)n_live;
+        if (n >= n_live) {       // a parked slot: the ray starts far outside the volume and points away from it
+            rays_o[(size_t)n * 3] = rays_o[(size_t)n * 3 + 1] = 0.0f;
+            rays_o[(size_t)n * 3 + 2] = 1e6f;
+            rays_d[(size_t)n * 3] = rays_d[(size_t)n * 3 + 1] = 0.0f;
+            rays_d[(size_t)n * 3 + 2] = 1.0f;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) gt[(size_t)n * 4 + k] = 0.0f;
+            if (noises) noises[n] = 0.0f;
+            if (bg) bg[(size_t)n * 3] = bg[(size_t)n * 3 + 1] = bg[(size_t)n * 3 + 2] = 0.0f;
+            if (index) index[2 * n] = index[2 * n + 1] = -1;
+            if (rays_ldir) {
+                rays_ldir[(size_t)n * 3] = rays_ldir[(size_t)n * 3 + 1] = 0.0f;
+                rays_ldir[(size_t)n * 3 + 2] = 1.0f;
+            }
+            return;
+        }
+    }
     if (draw_dev) draw = draw_dev[0];
     uint32_t r[4] = {n, draw, 0u, 0u};
     philox4x32_10(r, seed_lo, seed_hi);
@@ -745,19 +786,32 @@ extern "C" int ngp_x_composite_hdr_train(const float *gt_rgba, const float *bg_r
                                          float *weights_sum, float *depth, float *image, float *grad_sigmas,
                                          float *grad_rgbs, float *loss_out, ngp_stream_t stream)
 {
+    NGP_REQUIRE(exposure, "composite_hdr_train: null tensor");
+    return ngp_x_composite_train_live(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, nullptr, sigmas, rgbs, ts, rays, M,
+                                      N, T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out, stream);
+}
+
+extern "C" int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
+                                          const float *weight, float inv_norm, const int32_t *n_live, const float *sigmas,
+                                          const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
+                                          float T_thresh, float *weights_sum, float *depth, float *image,
+                                          float *grad_sigmas, float *grad_rgbs, float *loss_out, ngp_stream_t stream)
+{
     if (N == 0) return NGP_OK;
-    NGP_REQUIRE(gt_rgba && exposure && rays && weights_sum && depth && image && loss_out, "composite_hdr_train: null tensor");
-    NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && grad_sigmas && grad_rgbs), "composite_hdr_train: null sample tensor");
-    NGP_REQUIRE(((uintptr_t)gt_rgba & 15u) == 0, "composite_hdr_train: gt_rgba must be 16-byte aligned");
-    NGP_REQUIRE(inv_norm > 0.0f, "composite_hdr_train: inv_norm = 1 / sum(lossmult) must be positive");
+    NGP_REQUIRE(gt_rgba && rays && weights_sum && depth && image && loss_out, "composite_train_live: null tensor");
+    NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && grad_sigmas && grad_rgbs), "composite_train_live: null sample tensor");
+    NGP_REQUIRE(((uintptr_t)gt_rgba & 15u) == 0, "composite_train_live: gt_rgba must be 16-byte aligned");
+    NGP_REQUIRE(!exposure || n_live || inv_norm > 0.0f, "composite_train_live: inv_norm = 1 / sum(lossmult) must be positive");
+    NGP_REQUIRE(!(weight && n_live), "composite_train_live: a Bayer / loss weight and adaptive batches are not combined");
     HdrLoss hdr;
     hdr.exposure = exposure;
     hdr.weight = weight;
     hdr.inv_norm = inv_norm;
+    hdr.n_live = n_live;
     composite_backward_wave_kernel<2><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
         nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, nullptr, nullptr, nullptr, M,
         N, T_thresh, grad_sigmas, grad_rgbs, loss_out, weights_sum, depth, image, hdr);
-    NGP_CHECK_LAUNCH("composite_hdr_train");
+    NGP_CHECK_LAUNCH("composite_train_live");
     return NGP_OK;
 }
 
@@ -875,14 +929,34 @@ extern "C" int ngp_x_sample_rays_lit(const uint8_t *images, uint32_t V, uint32_t
                                      float *noises, float *bg_rgb, int32_t *index, const float *view_ldirs,
                                      float *rays_ldir, ngp_stream_t stream)
 {
+    return ngp_x_sample_rays_adaptive(images, V, H, W, C, poses, fx, fy, cx, cy, N, seed, draw_dev, draw, rays_o, rays_d,
+                                      gt_rgba, noises, bg_rgb, index, view_ldirs, rays_ldir, nullptr, nullptr, nullptr, 0,
+                                      stream);
+}
+
+extern "C" int ngp_x_sample_rays_adaptive(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W, uint32_t C,
+                                          const float *poses, float fx, float fy, float cx, float cy, uint32_t N,
+                                          uint64_t seed, const uint32_t *draw_dev, uint32_t draw, float *rays_o,
+                                          float *rays_d, float *gt_rgba, float *noises, float *bg_rgb, int32_t *index,
+                                          const float *view_ldirs, float *rays_ldir, const int32_t *prev_samples,
+                                          const int32_t *prev_live, int32_t *live, uint32_t num_points,
+                                          ngp_stream_t stream)
+{
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE((prev_samples == nullptr) == (prev_live == nullptr), "sample_rays: prev_samples and prev_live go together");
+    NGP_REQUIRE(!prev_samples || (live && num_points > 0), "sample_rays: adaptive batches need `live` and num_points");
+    AdaptiveRays ad;
+    ad.prev_samples = prev_samples;
+    ad.prev_live = prev_live;
+    ad.live = live;
+    ad.num_points = num_points;
     NGP_REQUIRE((view_ldirs == nullptr) == (rays_ldir == nullptr), "sample_rays: view_ldirs and rays_ldir go together");
     NGP_REQUIRE(images && poses && rays_o && rays_d && gt_rgba, "sample_rays: null tensor");
     NGP_REQUIRE(V > 0 && H > 0 && W > 0 && (uint64_t)H * W < (1ull << 32), "sample_rays: bad image shape");
     NGP_REQUIRE(C == 3 || C == 4, "sample_rays: images must be RGB or RGBA (uint8)");
     sample_rays_kernel<<<dim3(ceil_div(N, 256u)), dim3(256), 0, as_stream(stream)>>>(
         images, V, H, W, C, poses, fx, fy, cx, cy, N, (uint32_t)seed, (uint32_t)(seed >> 32), draw_dev, draw, rays_o, rays_d,
-        gt_rgba, noises, bg_rgb, index, view_ldirs, rays_ldir);
+        gt_rgba, noises, bg_rgb, index, view_ldirs, rays_ldir, ad);
     NGP_CHECK_LAUNCH("sample_rays");
     return NGP_OK;
 }

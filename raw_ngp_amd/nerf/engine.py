@@ -41,6 +41,7 @@ class _Slot:
         self.rays_ldir = torch.zeros(N, 3, **f32) if lit else None            # rfield: one light direction per ray
         self.index = torch.zeros(N, 2, dtype=torch.int32, device=dev) if indexed else None    # (view, pixel) of each ray
         self.exposure = torch.ones(N, **f32) if indexed else None
+        self.live = torch.full((1,), N, dtype=torch.int32, device=dev)        # rays the batch really carries (adaptive)
         self.rays_o, self.rays_d = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32)
         self.gt, self.bg = torch.empty(N, 4, **f32), torch.empty(N, 3, **f32)
         self.noises = torch.empty(N, **f32)
@@ -60,6 +61,8 @@ class FusedTrainer:
         self.hdr = getattr(opt, "image_mode", "LDR") == "HDR"
         assert opt.pose_opt in ("none", "barf"), "fused step: pose_opt 'baangp' is not implemented here -- use Trainer"
         assert not self.pose or self.rfield, "fused step: pose refinement is fused for the rfield configuration only"
+        assert not (getattr(opt, "adaptive_num_rays", False) and getattr(opt, "loss_weight", "none") != "none"), \
+            "fused step: adaptive ray batches and a loss weight are not combined"
         assert not self.hdr or getattr(opt, "loss_weight", "none") in ("none", "planck"), \
             "fused step: HDR loss_weight gaussian / hanning need batch statistics -- use Trainer"
         # terms of the reference's train_step (train_utils.py:544-564) this step does not compute: refuse them instead of
@@ -74,9 +77,13 @@ class FusedTrainer:
         self.rank, self.world_size = parallel.rank(), parallel.world_size()
         # data-parallel step (separate Adam pass, gradient collectives); `dp_rehearsal` runs it on one rank as well
         self.dp = self.world_size > 1 or (bool(getattr(opt, "dp_rehearsal", False)) and parallel.is_dist())
-        self.N = N = opt.num_rays
+        # adaptive ray batches (train_utils.py:563-564, part of the reference's -O preset): the ray SLOTS are fixed
+        # (max_ray_batch of them), how many carry rays is decided on the device from the previous batch's sample count
+        self.adaptive = bool(getattr(opt, "adaptive_num_rays", False))
+        self.N = N = max(opt.max_ray_batch, opt.num_rays) if self.adaptive else opt.num_rays
         # sample arena: ~145 samples/ray are needed while the occupancy grid is still full at bound 1; rays longer with the bound
-        self.cap = cap = int(capacity or max(opt.arena_capacity, N * 160 * int(math.ceil(model.real_bound))))
+        self.cap = cap = int(capacity or max(opt.arena_capacity, opt.num_rays * 160 * int(math.ceil(model.real_bound)),
+                                             2 * opt.num_points if self.adaptive else 0))
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         enc = model.grid_encoder
@@ -117,6 +124,12 @@ class FusedTrainer:
         self._slot_kw = dict(lit=self.rfield, indexed=self.pose or self.hdr)
         self.slots = [_Slot(N, opt.max_steps, cap, dev, chain_cap, **self._slot_kw) for _ in range(2 if self.prefetch else 1)]
         self.arena = self.slots[0].arena
+        if self.adaptive:
+            assert bool(getattr(opt, "device_sampler", True)), "adaptive ray batches are drawn by the device sampler"
+            for sl in self.slots:       # "the previous batch": num_rays rays that produced exactly num_points samples
+                sl.live.fill_(opt.num_rays)
+                sl.arena.counter[0] = opt.num_points
+            self.rays_seen = torch.zeros(1, dtype=torch.int64, device=dev)
         self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
         self.aux = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         # compressed occupancy bitfield the march keeps in LDS (rebuilt after every density-grid refresh)
@@ -258,6 +271,13 @@ class FusedTrainer:
     def lr(self):
         return self.lr0 * 0.1 ** min(self.global_step / self.opt.iters, 1)
 
+    def _adaptive_args(self, slot):
+        """(previous batch's sample count, its ray count, this batch's ray count, target) for the device sampler."""
+        if not self.adaptive:
+            return None
+        prev = self.slots[(self.slots.index(slot) + 1) % len(self.slots)] if slot in self.slots else slot
+        return prev.arena.counter, prev.live, slot.live, self.opt.num_points
+
     def _mlp_prepare(self):
         self.mb.prepare(self.weights, self.mlp_image)
 
@@ -317,6 +337,12 @@ class FusedTrainer:
         def composite_train():      # forward + loss + backward of the compositor in one launch (the step path)
             if zero_loss:
                 self.loss.zero_()
+            if self.adaptive:       # loss over the rays the batch really carries
+                eb.composite_train_live(gt_rgba, bg_rgb, bg_const, slot.exposure if self.hdr else None, None, 1.0 / (3 * N),
+                                        slot.live, self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.ws,
+                                        self.depth, self.image, self.dsigma, self.drgb, self.loss)
+                self.rays_seen.add_(slot.live)
+                return
             if self.hdr:            # exposure-scaled, clipped loss of train_utils.py:512-536
                 weight = None
                 if opt.loss_weight == "planck":     # raw_utils.planck_taper_weighting(gt_rgb): pointwise in the target
@@ -510,7 +536,8 @@ class FusedTrainer:
             # pose refinement: rays are cast from the refined cameras (the dataset's pose_fn hook, provider.py:298-300)
             eb.sample_rays(d.images, self.poses_refined if self.pose else d.poses, d.intrinsics, self.N, self.seed64,
                            self.draw_ctr, slot.rays_o, slot.rays_d, slot.gt, slot.noises,
-                           slot.bg if opt.background == "random" else None, slot.index, self.view_ldirs, slot.rays_ldir)
+                           slot.bg if opt.background == "random" else None, slot.index, self.view_ldirs, slot.rays_ldir,
+                           adaptive=self._adaptive_args(slot))
             eb.counter_add(self.draw_ctr, 1)
             if self.hdr:        # the exposure of each ray's image (colmap_provider.py:605-606)
                 torch.index_select(self.view_exposure, 0, slot.index[:, 0].long(), out=slot.exposure)

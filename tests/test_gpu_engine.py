@@ -570,3 +570,35 @@ def test_fast_evaluation_renders_what_the_inference_loop_renders(lib):
     before = eng.global_step
     eng.train(5)
     assert eng.global_step == before + 5 and torch.isfinite(eng.loss).all()
+
+
+def test_adaptive_ray_batches_follow_the_reference_rule(lib):
+    """`--adaptive_num_rays` on the device (train_utils.py:563-564): every batch gets round(num_points / samples * rays) rays
+    of the previous batch's counts, nothing is read back by the step; samples per step settle at num_points."""
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=1024, iters=400, adaptive_num_rays=True, num_points=2 ** 15, max_ray_batch=8192)
+    data = SyntheticDataset(opt, dev, "train", n_views=6, H=96, W=96)
+    ft = FusedTrainer(opt, NeRFNetwork(opt), data, device=dev)
+    assert ft.N == 8192
+    hist = []
+    for it in range(300):
+        ft.train_step()
+        slot = ft.slots[it % len(ft.slots)]
+        hist.append((int(slot.live), int(slot.arena.counter[0])))         # (rays, samples) of the batch just trained on
+    assert hist[0][0] == 1024                                             # the first batch: opt.num_rays
+    for (r0, s0), (r1, _) in zip(hist[:-1], hist[1:]):                    # the rule, batch after batch
+        assert r1 == min(max(int(round(opt.num_points / max(s0, 1) * r0)), 1), ft.N), (r0, s0, r1)
+    late = np.array([s for _, s in hist[-60:]], dtype=np.float64)
+    assert abs(late.mean() / opt.num_points - 1) < 0.1, late.mean()       # samples per step ~ num_points
+    assert len({r for r, _ in hist[-60:]}) > 1 and all(r != 1024 for r, _ in hist[-60:])   # the batch size moved and keeps adjusting
+    assert int(ft.rays_seen) == sum(r for r, _ in hist)
+    assert np.isfinite(float(ft.loss)) and torch.isfinite(ft.table).all()
+    # parked ray slots carry nothing: no samples, no image
+    n_live = hist[-1][0]
+    last = ft.slots[299 % len(ft.slots)]
+    assert int(last.arena.rays[n_live:, 1].sum()) == 0
