@@ -159,6 +159,59 @@ def main():
             wres[f"{mode}_{ann}"] = seen[0].numpy()
     np.savez(os.path.join(args.out, "level_windows.npz"), feat=feat.numpy(), **wres)
 
+    # ---------------------------------------------------------------- the field as the reference evaluates it
+    # NeRFNetwork.forward (network.py:111-143) with its own MLP class, trunc_exp and clamped-exp colour, for the plain
+    # (31 -> 64 -> 64 -> 3) and the light-conditioned (47 -> 80 -> 80 -> 3) view MLP: inputs, outputs and the gradients
+    # of <dsigma, sigma> + <drgb, color>.  The two CUDA-backed encoders are replaced by stand-ins that return given
+    # tensors: the hash features are an input of the fixture, the SH features come from the closed-form degree-4
+    # polynomials (tests pin those against the kernels separately).  Consumed by the fused MFMA kernels' GPU tests.
+    def sh16(d):
+        x, y, z = d[:, 0], d[:, 1], d[:, 2]
+        xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+        return torch.stack([
+            torch.full_like(x, 0.28209479177387814),
+            -0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x,
+            1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * z2 - 0.31539156525251999,
+            -1.0925484305920792 * xz, 0.54627421529603959 * x2 - 0.54627421529603959 * y2,
+            0.59004358992664352 * y * (-3.0 * x2 + y2), 2.8906114426405538 * xy * z,
+            0.45704579946446572 * y * (1.0 - 5.0 * z2), 0.3731763325901154 * z * (5.0 * z2 - 3.0),
+            0.45704579946446572 * x * (1.0 - 5.0 * z2), 1.4453057213202769 * z * (x2 - y2),
+            0.59004358992664352 * x * (-x2 + 3.0 * y2)], -1)
+
+    class GivenFeatures(torch.nn.Module):
+        def __init__(self, feat):
+            super().__init__()
+            self.feat = feat
+
+        def forward(self, x, bound=1):
+            return self.feat
+
+    class ShOfUnit(torch.nn.Module):
+        def forward(self, d):
+            return sh16(d)
+
+    for tag, rfield in (("plain", False), ("rfield", True)):
+        fopt = types.SimpleNamespace(**{**base, "rfield": rfield, "pose_opt": "none"})
+        torch.manual_seed(3 if rfield else 2)
+        net = NW.NeRFNetwork(fopt)
+        Mf = 96
+        g = torch.Generator().manual_seed(17)
+        feat = (torch.randn(Mf, 32, generator=g) * 0.5).requires_grad_(True)
+        dirs = torch.nn.functional.normalize(torch.randn(Mf, 3, generator=g), dim=-1)
+        ldirs = torch.nn.functional.normalize(torch.randn(Mf, 3, generator=g), dim=-1)
+        net.grid_encoder = GivenFeatures(feat)
+        net.view_encoder = ShOfUnit()
+        out = net(torch.zeros(Mf, 3), dirs, ldirs if rfield else None)
+        dsig = torch.randn(Mf, generator=g) * 1e-3
+        drgb = torch.randn(Mf, 3, generator=g) * 1e-3
+        params = [l.weight for l in net.grid_mlp.net] + [l.weight for l in net.view_mlp.net]
+        grads = torch.autograd.grad((out["sigma"] * dsig).sum() + (out["color"] * drgb).sum(), [feat] + params)
+        np.savez(os.path.join(args.out, f"field_{tag}.npz"), feat=feat.detach().numpy(), dirs=dirs.numpy(),
+                 ldirs=ldirs.numpy(), sigma=out["sigma"].detach().numpy(), color=out["color"].detach().numpy(),
+                 dsigma=dsig.numpy(), drgb=drgb.numpy(), dfeat=grads[0].numpy(),
+                 **{f"w{i + 1}": p.detach().numpy() for i, p in enumerate(params)},
+                 **{f"gw{i + 1}": g_.numpy() for i, g_ in enumerate(grads[1:])})
+
     # ---------------------------------------------------------------- run() with an analytic field
     class Analytic(R.NeRFRenderer):
         def density(self, x, proposal=-1, **kw):
@@ -184,6 +237,38 @@ def main():
         outp = ren.run(torch.from_numpy(ro), torch.from_numpy(rd), bg_color=None, perturb=False)
     np.savez(os.path.join(args.out, "run_analytic.npz"), rays_o=ro, rays_d=rd, num_steps=np.array([64, 32, 16]),
              image=outp["image"].numpy(), depth=outp["depth"].numpy(), weights_sum=outp["weights_sum"].numpy())
+    # ---------------------------------------------------------------- per-sample weights of run()'s compositor
+    # renderer.py:471-495 (alphas, exclusive cumsum transmittance, weights, weights_sum, depth, image) on seeded densities
+    # and colours, one sampling level, training mode (results['weights']).  The HIP compositors are compared with it at
+    # T_thresh = 0 with ts = (interval midpoint, interval length).
+    class Seeded(R.NeRFRenderer):
+        def forward(self, x, d, **kw):
+            return {"sigma": self._sigma, "color": self._color}
+
+    Tc, Nc = 48, 40
+    copt = types.SimpleNamespace(**{**vars(ropt), "num_steps": [Tc]})
+    cren = Seeded(copt)
+    cren.train()
+    crng = np.random.default_rng(23)
+    cren._sigma = torch.from_numpy(crng.lognormal(0.0, 2.0, (Nc, Tc)).astype(np.float32))
+    cren._sigma[5] = 0.0                                                     # an empty ray
+    cren._sigma[6, 3:] = 1e4                                                 # a wall: transmittance underflows behind it
+    cren._color = torch.from_numpy(crng.uniform(0, 1, (Nc, Tc, 3)).astype(np.float32))
+    co = crng.normal(size=(Nc, 3)).astype(np.float32)
+    co = 2.2 * co / np.linalg.norm(co, axis=1, keepdims=True)
+    cd = (crng.uniform(-0.5, 0.5, (Nc, 3)) - co).astype(np.float32)
+    cd /= np.linalg.norm(cd, axis=1, keepdims=True)
+    with torch.no_grad():
+        cout = cren.run(torch.from_numpy(co), torch.from_numpy(cd), bg_color=0, perturb=False)
+        # the sample positions run() used: its own spacing functions on the uniform bins (renderer.py:441-452)
+        nears, fars = R.near_far_from_aabb(torch.from_numpy(co), torch.from_numpy(cd), cren.aabb_train, cren.min_near)
+        bins = torch.linspace(0, 1, Tc + 1).unsqueeze(0).expand(Nc, -1)
+        real = cren.spacing_fn_inv(cren.spacing_fn(nears) * (1 - bins) + cren.spacing_fn(fars) * bins)
+    np.savez(os.path.join(args.out, "run_weights.npz"), sigma=cren._sigma.numpy(), color=cren._color.numpy(),
+             t_mid=((real[:, 1:] + real[:, :-1]) / 2).numpy(), delta=(real[:, 1:] - real[:, :-1]).numpy(),
+             weights=cout["weights"].numpy(), weights_sum=cout["weights_sum"].numpy(), depth=cout["depth"].numpy(),
+             image=cout["image"].numpy())
+
     # ---------------------------------------------------------------- pose refinement (barf/camera.py)
     import barf.camera as CAM
     prng = np.random.default_rng(11)
