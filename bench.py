@@ -43,19 +43,18 @@ from raw_ngp_amd.nerf.trainer import Trainer  # noqa: E402
 METRIC = "training rays/sec + PSNR@5k-iters, NeRF-synthetic Lego 800², 1/2/4/8 MI355X"
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
-# dominant-kernel candidates: C symbol -> (index of the sample-count argument, algorithmic bytes/sample)
-# HBM-side bytes per sample of the binned table backward from the PMC passes in profiles/r01_pmc_grid_traffic.csv
-# (FETCH_SIZE + WRITE_SIZE of count + fill + reduce on 204 800 samples, 16-byte streaming fetches doubled as the
-# MI355X guide prescribes): 469 MB / 204 800.  rocprofv3's counter mode cannot run this script (it crashes in the
-# profiler's dispatch hook), so the figure is carried over from tools/grid_bench.py, which drives the same kernels.
+# HBM-side traffic of the hash-grid kernels, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE ON THIS SCRIPT's own
+# steady state (tools/pmc_bench.sh, profiles/r02_pmc_bench_traffic.csv: last 30 steps before iteration 5000, 136.6 k live
+# samples per step; 16-byte streaming fetches doubled as the MI355X guide prescribes).  Counters cannot be read while this
+# script times itself, so the per-sample figures are carried as constants and scaled by the samples of the run:
+#   binned backward, Adam fused (one GPU):  fill 19.0 + 44.0 MB, reduce 2 x 92.7 + 143.1 MB = 391.5 MB per launch, of which
+#     292.7 MB are the optimiser state (24 B x 12.2 M table entries, independent of the samples) -> 723 B/sample + 292.7 MB
+#   binned backward, gradient written (data parallel): the round-1 passes on tools/grid_bench.py's synthetic samples
+#     (profiles/r01_pmc_grid_traffic.csv), 2 290 B/sample with 12-byte records; not re-measured this round
+#   slab forward: 41.7 + 22.1 MB = 63.8 MB per launch -> 467 B/sample (gathers of 8 / 16 bytes, counted as reported)
 PMC_TRAFFIC_BYTES_PER_SAMPLE = {"ngp_x_grid_backward_binned": 2290.0}
-# with Adam fused into the reduce kernel (one GPU) the gradient's accumulate traffic disappears and the optimiser state
-# appears: bin_reduce_kernel<1> measures FETCH 2 x 156.1 MB (streaming loads, doubled as above) + WRITE 143.1 MB = 455 MB
-# on 204 800 samples, of which 24 B x 12.2 M table entries = 293 MB do not depend on the sample count:
-# (count 10.3 + fill 200.3 + records read back 162.6) MB / 204 800 = 1 822 B/sample, plus 293 MB per launch
-PMC_FUSED_TRAFFIC_BYTES_PER_SAMPLE = 1822.0
-# slab forward, same passes: FETCH 63.7 MB (8-byte gathers, counted as reported) + WRITE 28.0 MB on 204 800 samples
-PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 448.0
+PMC_FUSED_TRAFFIC_BYTES_PER_SAMPLE = 723.0
+PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 467.0
 FWD_BYTES_PER_SAMPLE = 12 + 16 * (64 + 8)      # 1164 B/sample, SURVEY.md section 8d
 
 # entry point(s) timed with HIP events -> (index of the samples-per-launch argument, algorithmic bytes per sample)
@@ -359,8 +358,10 @@ def main():
             roof = {"bound": "hbm", "kernel": args.roofline_kernel + (" + Adam on the table (fused)" if fused_adam else ""),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_grid_traffic.csv, scaled by samples"
-                                    + (", plus the optimiser's 24 B per table entry" if fused_adam else "") + ")",
+                    "traffic_source": ("FETCH_SIZE + WRITE_SIZE measured on this script's steady state (profiles/r02_pmc_bench_"
+                                       "traffic.csv), per-sample part scaled to this run's samples, plus the optimiser's 24 B per "
+                                       "table entry" if fused_adam else
+                                       "PMC on tools/grid_bench.py (profiles/r01_pmc_grid_traffic.csv), scaled by samples"),
                     "launches": launches, "timed_every": args.probe_every, "avg_us": round(ksec / launches * 1e6, 2),
                     "bytes_per_sample": bytes_per_sample, "samples_per_launch": round(units / launches),
                     "optimizer_bytes_per_launch": opt_bytes, "achieved_grid_only": round(grid_only, 1),

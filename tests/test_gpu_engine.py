@@ -602,3 +602,67 @@ def test_adaptive_ray_batches_follow_the_reference_rule(lib):
     n_live = hist[-1][0]
     last = ft.slots[299 % len(ft.slots)]
     assert int(last.arena.rays[n_live:, 1].sum()) == 0
+
+
+def test_grid_kernels_at_their_boundaries_stay_inside_their_buffers(lib, orc):
+    """The arena exactly full (B == capacity), samples on the faces, edges and corners of [0,1]^3 (first and last cell of
+    every level, including the last row of the last level's table) and a few outside: forward (+ Jacobian, + counting),
+    binned fill + reduce.  Every output lives in one allocation with guard words between the tensors; the guards must come
+    back untouched and the results must match the oracle."""
+    rng = np.random.default_rng(14)
+    e, gb = lib.engine_backend, lib.gridencoder_backend
+    L, H, bound = 16, 16, 1.0
+    offsets, scale = orc.grid_offsets(desired_resolution=2048 * bound)
+    S, rows = float(np.log2(scale)), int(offsets[-1])
+    cap = B = 4096 + 512                                         # not a multiple of the 512-sample fill tile's double
+    x01 = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    corners = np.array([[a, b, c] for a in (0.0, 1.0) for b in (0.0, 1.0) for c in (0.0, 1.0)], np.float32)
+    x01[:8] = corners
+    x01[8:16] = np.nextafter(corners, 0.5).astype(np.float32)     # one ulp inside
+    x01[16:24] = corners * np.float32(1 - 2.0 ** -12)             # inside the last cell of the finest level
+    x01[24] = [1.0, 0.5, 0.25]
+    x01[25] = [np.nextafter(np.float32(1), np.float32(2)), 0.5, 0.5]   # just outside -> zeros
+    x01[26] = [-1e-7, 0.5, 0.5]
+    x01[-1] = [1.0, 1.0, 1.0]                                     # the last slot of the arena
+    xyz = (x01 * np.float32(2 * bound) - np.float32(bound)).astype(np.float32)
+    x01 = ((xyz + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)      # what the kernel will compute
+    table = rng.uniform(-1, 1, (rows, 2)).astype(np.float32)
+    denc = rng.normal(size=(L, cap, 2)).astype(np.float32)
+    ws_bytes = gb.backward_workspace_bytes(cap, L, rows)
+    G = 1024                                                      # guard floats
+    sizes = dict(enc=L * cap * 2, x01=cap * 3, jac=L * cap * 6, grad=rows * 2)
+    flat = torch.full((sum(sizes.values()) + G * (len(sizes) + 1),), 123.0, device="cuda")
+    views, at = {}, G
+    for k, n in sizes.items():
+        views[k] = flat[at:at + n]
+        at += n + G
+    guard = torch.ones_like(flat, dtype=torch.bool)
+    at = G
+    for n in sizes.values():
+        guard[at:at + n] = False
+        at += n + G
+    ws_flat = torch.full((ws_bytes + 8192,), 0x5A, dtype=torch.uint8, device="cuda")
+    ws = ws_flat[4096:4096 + ws_bytes]                            # (4096-byte offset keeps the 16-byte alignment)
+    enc, xo, jac = views["enc"].view(L, cap, 2), views["x01"].view(cap, 3), views["jac"].view(L, cap, 3, 2)
+    grad = views["grad"].view(rows, 2)
+    grad.zero_()
+    cnt = torch.tensor([B, B, 0, 0], dtype=torch.int32, device="cuda")
+    d_off = dev(offsets)
+    gb.grid_backward_binned_prepare(None, 0.0, d_off, rows, cnt, cap, L, L, S, H, ws, merge_max_res=414, stage=1)
+    e.grid_encode_forward_slab(dev(xyz), bound, dev(table), d_off, enc, xo, cnt, cap, cap, L, L, S, H, binned_workspace=ws,
+                               dydx=jac)
+    gb.grid_backward_binned_prepare(None, 0.0, d_off, rows, cnt, cap, L, L, S, H, ws, stage=2)
+    gb.grid_backward_binned_apply(dev(denc), xo, d_off, grad, cnt, cap, cap, L, L, S, H, ws)
+    torch.cuda.synchronize()
+    assert torch.all(flat[guard] == 123.0), "a kernel wrote outside its output tensor"
+    assert torch.all(ws_flat[:4096] == 0x5A) and torch.all(ws_flat[4096 + ws_bytes:] == 0x5A), "workspace overrun"
+    ref, ref_j = orc.grid_encode_forward(x01, table, offsets, B, 3, 2, L, L, S, H, True)
+    np.testing.assert_allclose(host(enc), ref, rtol=1e-6, atol=1e-6)
+    assert np.all(host(enc)[:, 25] == 0) and np.all(host(enc)[:, 26] == 0)
+    np.testing.assert_allclose(host(jac), ref_j.reshape(B, L, 3, 2).transpose(1, 0, 2, 3), rtol=1e-5,
+                               atol=1e-5 * np.abs(ref_j).max())
+    ref_g, _ = orc.grid_encode_backward(denc, x01, table, offsets, B, 3, 2, L, L, S, H)
+    np.testing.assert_allclose(host(grad), ref_g, rtol=1e-4, atol=2e-5 * np.abs(ref_g).max())
+    last = int(offsets[-1]) - 1
+    assert np.abs(ref_g[int(offsets[-2]):]).sum() > 0             # the last level received gradient
+    assert host(grad)[last].tolist() == pytest.approx(ref_g[last].tolist(), rel=1e-4, abs=1e-6)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Standalone driver of the hash-grid forward (slab) and the binned table backward on ray-ordered samples, for
-rocprofv3 --pmc passes and quick timing (the full bench cannot run under --pmc: the profiler's dispatch hook
-crashes on one of the compositor launches).  Samples: 4096 rays x ~50 steps of dt = 2*sqrt(3)/1024 through a shell
+rocprofv3 --pmc passes and quick timing on a fixed synthetic sample set (bench.py itself runs under --pmc only with
+--no-graph: the profiler's queue-intercept callback faults on the batched AQL submissions of hipGraph launches --
+profiles/r02_pmc_graph_crash_stack.txt; tools/pmc_bench.sh measures the bench's own steady state that way).  Samples: 4096 rays x ~50 steps of dt = 2*sqrt(3)/1024 through a shell
 around a sphere, like a trained occupancy grid produces."""
 import argparse
 import os
