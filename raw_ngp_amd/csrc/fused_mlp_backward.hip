@@ -21,6 +21,9 @@
 namespace ngp {
 
 constexpr uint32_t kAccFloats = 8 * 16 * 64;   // 8 accumulator tiles per kernel = 8192 floats per workgroup
+// dynamic LDS: the weight fragments during the tile loop (46 / 26 KiB), then the staging area of the partial-sum flush
+constexpr size_t kViewLds = flush_lds_bytes(8) > 46 * 1024 ? flush_lds_bytes(8) : 46 * 1024;
+constexpr size_t kGridLds = flush_lds_bytes(8) > 32 * 1024 ? flush_lds_bytes(8) : 32 * 1024;
 
 // ---- helpers -----------------------------------------------------------------------------------
 template <bool WANT_SH>
@@ -179,27 +182,36 @@ __device__ __forceinline__ f32x16 transpose_tile(half8 f0, half8 f1, half8 I0, h
 }
 
 #define NGP_FRAG(local_id) lds_w[(local_id) * 64 + lane]
-
-// sum the four waves' accumulator tiles in the workgroup's LDS image (wave after wave, so the order of
-// the additions is fixed and the result bitwise reproducible), then dump it to the partial slab
-__device__ __forceinline__ void flush_acc(float *lds_acc, const f32x16 (&g)[8], uint32_t lane, float *__restrict__ slab)
-{
-    const uint32_t wid = threadIdx.x >> 6;
-    __syncthreads();   // everyone is done reading weight fragments from this LDS
-    for (uint32_t turn = 0; turn < 4; turn++) {
-        if (wid == turn) {
-#pragma unroll
-            for (int b = 0; b < 8; b++)
-#pragma unroll
-                for (int v = 0; v < 16; v++) {
-                    float *p = &lds_acc[(b * 16 + v) * 64 + lane];
-                    *p = turn == 0 ? g[b][v] : *p + g[b][v];
-                }
-        }
-        __syncthreads();
-    }
-    for (uint32_t i = threadIdx.x; i < kAccFloats; i += 256) slab[i] = lds_acc[i];
-}
+// Diagnostic build only (-DNGP_STAMP, never shipped): s_memtime stamps around the sections of a tile, summed per wave and
+// added to a device array that tools read back with ngp_dbg_read_stamps().  No stamp executes in the product build.
+#ifdef NGP_STAMP
+__device__ unsigned long long ngp_dbg_stamps[16];
+#define NGP_STAMP_DECL unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0
+#define NGP_STAMP_BEGIN()                                                                         \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#define NGP_STAMP_AT(i)                                                                           \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        st_acc[i] += st_t1 - st_t0;                                                               \
+        st_t0 = st_t1;                                                                            \
+    } while (0)
+#define NGP_STAMP_FLUSH()                                                                         \
+    do {                                                                                          \
+        if ((threadIdx.x & 63u) == 0)                                                             \
+            for (int i_ = 0; i_ < 10; i_++) atomicAdd(&ngp_dbg_stamps[i_], st_acc[i_]);            \
+    } while (0)
+#else
+#define NGP_STAMP_DECL
+#define NGP_STAMP_BEGIN()
+#define NGP_STAMP_AT(i)
+#define NGP_STAMP_FLUSH()
+#endif
 
 // ---- view kernel ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
@@ -220,9 +232,11 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 #pragma unroll
     for (int i = 0; i < 8; i++) g[i] = zero16();
 
+    NGP_STAMP_DECL;
     RawTile nxt = fetch_raw<true>(enc, stride, dirs, dsigma, drgb, nullptr, wave * 32u + n, wave * 32u + n < M, h);
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         asm volatile("" ::: "memory");   // keep the weight fragments in LDS: no hoisting of 46 KiB into VGPRs
+        NGP_STAMP_BEGIN();
         const uint32_t row = tile * 32u + n;
         const bool valid = row < M;
         const RawTile cur = nxt;
@@ -241,7 +255,9 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             }
             continue;
         }
+        NGP_STAMP_AT(0);      // prefetch issue + skip test
         const TileInB<true> in = convert_raw<true>(cur, h);
+        NGP_STAMP_AT(1);      // conversion of the tile's inputs (waits for last iteration's loads), SH
 
         // ---------------- recompute the forward pass
         f32x16 a[2];
@@ -307,6 +323,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 #pragma unroll
             for (int s = 0; s < 2; s++) c = mfma(NGP_FRAG(F_W6 + kb * 2 + s), h4[kb][s], c);
 
+        NGP_STAMP_AT(2);      // forward recompute (32 MFMAs)
+
         // ---------------- output deltas (scaled by loss_scale so that they survive f16)
         const float gs = cur.gs, gr0 = cur.gr[0], gr1 = cur.gr[1], gr2 = cur.gr[2];
         f32x16 d6 = zero16();
@@ -340,6 +358,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             p5[rb][0] = pack_masked<0>(dh, h4[rb][0]);
             p5[rb][1] = pack_masked<1>(dh, h4[rb][1]);
         }
+        NGP_STAMP_AT(3);      // deltas 6, dW6, delta 5
         // ---------------- layer 5: dW5 = delta5 x H3^T ; delta4 = W5^T delta5 (masked)
         {
             half8 a5[2][2];
@@ -372,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             p4[rb][0] = pack_masked<0>(dh, h3[rb][0]);
             p4[rb][1] = pack_masked<1>(dh, h3[rb][1]);
         }
+        NGP_STAMP_AT(4);      // dW5, delta 4
         // ---------------- layer 4: dW4 = delta4 x X3^T ; dX3 = W4^T delta4
         {
             const f32x16 tx = transpose_tile(x3a, in.sh, I0, I1);
@@ -394,8 +414,16 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
         // delta3: rows 1..15 = d features, row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp)
         if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
         if (valid) d3buf[(size_t)row * 2 + h] = pack<0, false>(dx3);
+        NGP_STAMP_AT(5);      // dW4, d x3, store
     }
-    flush_acc(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kAccFloats);
+    NGP_STAMP_BEGIN();
+#ifdef NGP_STAMP_SPLIT_FLUSH   // diagnostic: where inside the flush
+    __syncthreads();
+    NGP_STAMP_AT(7);          // arrival skew at the first barrier
+#endif
+    flush_tiles_parallel<8>(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kAccFloats);
+    NGP_STAMP_AT(6);          // partial-sum flush
+    NGP_STAMP_FLUSH();
 }
 
 // ---- grid kernel ---------------------------------------------------------------------------------
@@ -581,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
             }
         }
     }
-    flush_acc(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kAccFloats);
+    flush_tiles_parallel<8>(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kAccFloats);
 }
 
 // ---- partial-slab reduction -----------------------------------------------------------------------
@@ -683,15 +711,31 @@ __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restr
     }
 }
 
+// the backward kernels stage their partial sums in 64 KiB of dynamic LDS (the default limit)
+static bool mlp_backward_lds_ok()
+{
+    static const bool ok = [] {
+        bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_view_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kViewLds) == hipSuccess;
+        r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
+        r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
+        return r;
+    }();
+    return ok;
+}
+
 int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
                              const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
                              float *partial, uint32_t blocks, hipStream_t st)
 {
+    NGP_REQUIRE(mlp_backward_lds_ok(), "mlp_backward_grid: cannot raise the dynamic LDS limit");
     if (level_w)
-        mlp_backward_grid_kernel<true><<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
+        mlp_backward_grid_kernel<true><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
                                                                                   d3buf, denc, partial, level_w, t3_base);
     else
-        mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
+        mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
                                                                                    d3buf, denc, partial, nullptr, t3_base);
     NGP_CHECK_LAUNCH("mlp_backward_grid");
     return NGP_OK;
@@ -700,6 +744,16 @@ int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *lev
 }  // namespace ngp
 
 using namespace ngp;
+
+#ifdef NGP_STAMP
+extern "C" int ngp_dbg_read_stamps(unsigned long long *out16, int reset)
+{
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ngp_dbg_stamps), sizeof(zero)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ngp_dbg_stamps), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 static uint32_t mlp_bwd_blocks(uint32_t M)
 {
@@ -727,14 +781,15 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
     NGP_REQUIRE(((uintptr_t)workspace & 15u) == 0, "mlp_backward: workspace must be 16-byte aligned");
     NGP_REQUIRE(loss_scale > 0.0f, "mlp_backward: loss_scale must be positive");
     hipStream_t st = as_stream(stream);
+    NGP_REQUIRE(mlp_backward_lds_ok(), "mlp_backward: cannot raise the dynamic LDS limit");
     const uint32_t blocks = mlp_bwd_blocks(max(M, 1u));
     half8 *d3buf = reinterpret_cast<half8 *>(workspace);
     float *part_view = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (((size_t)M * 32 + 255) & ~(size_t)255));
     float *part_grid = part_view + (size_t)256 * kAccFloats;
     const half8 *img = reinterpret_cast<const half8 *>(image);
-    mlp_backward_view_kernel<<<dim3(blocks), dim3(256), 46 * 1024, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
+    mlp_backward_view_kernel<<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
                                                                         loss_scale, d3buf, part_view);
-    mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), 32 * 1024, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
+    mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
                                                                                d3buf, denc, part_grid, nullptr, T_W3);
     if (reduce_now)
         mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, st>>>(part_view, part_grid, blocks, 1.0f / loss_scale,

@@ -277,28 +277,6 @@ __device__ __forceinline__ f32x16 transpose2(half8 f0, half8 f1, half8 I0, half8
 }
 __device__ __forceinline__ f32x16 transpose1(half8 f0, half8 I0) { return mfma(f0, I0, zero16()); }
 
-// sum the four waves' NT accumulator tiles in the workgroup's LDS image in wave order (fixed order: reproducible), then
-// dump it to the workgroup's partial slab
-template <int NT>
-__device__ __forceinline__ void flush_tiles(float *lds_acc, const f32x16 (&g)[NT], uint32_t lane, float *__restrict__ slab)
-{
-    const uint32_t wid = threadIdx.x >> 6;
-    __syncthreads();   // everyone is done reading weight fragments from this LDS
-    for (uint32_t turn = 0; turn < 4; turn++) {
-        if (wid == turn) {
-#pragma unroll
-            for (int b = 0; b < NT; b++)
-#pragma unroll
-                for (int v = 0; v < 16; v++) {
-                    float *p = &lds_acc[(b * 16 + v) * 64 + lane];
-                    *p = turn == 0 ? g[b][v] : *p + g[b][v];
-                }
-        }
-        __syncthreads();
-    }
-    for (uint32_t i = threadIdx.x; i < (uint32_t)NT * 1024u; i += 256) slab[i] = lds_acc[i];
-}
-
 constexpr uint32_t kRfScratch = 11;   // per lane: delta4 (5), h4 (5), delta6 (1) fragments, layout [fragment][2 row + h]
 constexpr uint32_t kRfTilesV = 9, kRfTilesG = 8;
 
@@ -457,7 +435,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
             scratch[(size_t)10 * plane + at] = p6;
         }
     }
-    flush_tiles<(int)kRfTilesV>(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kRfTilesV * 1024u);
+    flush_tiles_parallel<(int)kRfTilesV>(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kRfTilesV * 1024u);
 }
 
 // ------------------------------------------------------------------ backward, view half 2: dW4, dW6
@@ -540,7 +518,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v2_kernel(
             }
         }
     }
-    flush_tiles<(int)kRfTilesV>(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kRfTilesV * 1024u);
+    flush_tiles_parallel<(int)kRfTilesV>(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kRfTilesV * 1024u);
 }
 
 // ------------------------------------------------------------------ partial-slab reduction
@@ -664,9 +642,13 @@ extern "C" int ngp_x_mlp_rf_backward(const float *enc, uint32_t stride, const fl
     NGP_REQUIRE(workspace_bytes >= ngp_x_mlp_rf_backward_workspace_bytes(M), "mlp_rf_backward: workspace too small");
     NGP_REQUIRE(((uintptr_t)workspace & 15u) == 0, "mlp_rf_backward: workspace must be 16-byte aligned");
     NGP_REQUIRE(loss_scale > 0.0f, "mlp_rf_backward: loss_scale must be positive");
+    constexpr size_t kV1Lds = flush_lds_bytes((int)kRfTilesV) > (size_t)RF_T3 * 1024 ? flush_lds_bytes((int)kRfTilesV) : (size_t)RF_T3 * 1024;
+    constexpr size_t kV2Lds = flush_lds_bytes((int)kRfTilesV);
     static const bool lds_ok = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_rf_backward_v1_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RF_T3 * 1024) == hipSuccess;
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kV1Lds) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_rf_backward_v2_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kV2Lds) == hipSuccess;
     }();
     NGP_REQUIRE(lds_ok, "mlp_rf_backward: cannot raise the dynamic LDS limit");
     hipStream_t st = as_stream(stream);
@@ -678,9 +660,9 @@ extern "C" int ngp_x_mlp_rf_backward(const float *enc, uint32_t stride, const fl
     float *part_v2 = part_v1 + (size_t)256 * kRfTilesV * 1024;
     float *part_g = part_v2 + (size_t)256 * kRfTilesV * 1024;
     const half8 *img = reinterpret_cast<const half8 *>(image);
-    mlp_rf_backward_v1_kernel<<<dim3(blocks), dim3(256), (size_t)RF_T3 * 1024, st>>>(
+    mlp_rf_backward_v1_kernel<<<dim3(blocks), dim3(256), kV1Lds, st>>>(
         enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, loss_scale, d3buf, scratch, ddirs, part_v1);
-    mlp_rf_backward_v2_kernel<<<dim3(blocks), dim3(256), (size_t)kRfTilesV * 4096, st>>>(
+    mlp_rf_backward_v2_kernel<<<dim3(blocks), dim3(256), kV2Lds, st>>>(
         enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, scratch, part_v2);
     const int rc = launch_mlp_backward_grid(enc, stride, level_w, M_dev, M, img, RF_T3, 1.0f / loss_scale, d3buf, denc,
                                             part_g, blocks, st);

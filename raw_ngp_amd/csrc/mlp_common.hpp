@@ -154,6 +154,53 @@ __device__ __forceinline__ LaneWindow load_window(const float *__restrict__ leve
     return lw;
 }
 
+// Weight-gradient accumulators of a workgroup's four waves -> one partial slab in global memory, summed in wave order
+// ((w0 + w1) + w2) + w3: a fixed order, so the result is bitwise reproducible.  Every wave parks its tiles in LDS at once
+// (16-byte stores, its own region), one barrier, then all 256 lanes add the four copies and store the slab; done in two
+// rounds of NT / 2 tiles so that 4 x NT/2 x 4 KiB of LDS suffice (64 KiB for 8 tiles, 80 KiB for 9).
+// (The first version took turns -- wave k adds its tiles to the image while the other three wait at a barrier, four
+// times -- and cost 24 000 cycles per wave, 43 % of the view kernel's run time: in-kernel stamps, tools/mlp_stamps.py.)
+// slab element (tile b, register v, lane l) at (b * 16 + v) * 64 + l, as the reduction kernels expect.
+template <int NT>
+__device__ __forceinline__ void flush_tiles_parallel(float *lds_acc, const f32x16 (&g)[NT], uint32_t lane,
+                                                     float *__restrict__ slab)
+{
+    constexpr int HALF = (NT + 1) / 2;
+    const uint32_t wid = threadIdx.x >> 6;
+    float4 *mine = reinterpret_cast<float4 *>(lds_acc) + (size_t)wid * HALF * 256;
+    const float4 *all = reinterpret_cast<const float4 *>(lds_acc);
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        const int b0 = round * HALF, nb = round == 0 ? HALF : NT - HALF;
+        __syncthreads();   // round 0: everyone is done reading weight fragments from this LDS; round 1: round 0 was read
+#pragma unroll
+        for (int b = 0; b < nb; b++)
+#pragma unroll
+            for (int vq = 0; vq < 4; vq++)
+                mine[(b * 4 + vq) * 64 + lane] = make_float4(g[b0 + b][4 * vq], g[b0 + b][4 * vq + 1], g[b0 + b][4 * vq + 2],
+                                                             g[b0 + b][4 * vq + 3]);
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < (uint32_t)nb * 256u; q += 256) {
+            float4 s = all[q];
+#pragma unroll
+            for (uint32_t k = 1; k < 4; k++) {
+                const float4 t = all[(size_t)k * HALF * 256 + q];
+                s.x += t.x;
+                s.y += t.y;
+                s.z += t.z;
+                s.w += t.w;
+            }
+            const uint32_t b = b0 + (q >> 8), vq = (q >> 6) & 3u, l = q & 63u;
+            float *dst = slab + ((size_t)b * 16 + 4 * vq) * 64 + l;
+            dst[0] = s.x;
+            dst[64] = s.y;
+            dst[128] = s.z;
+            dst[192] = s.w;
+        }
+    }
+}
+constexpr size_t flush_lds_bytes(int NT) { return (size_t)4 * ((NT + 1) / 2) * 4096; }
+
 // the density MLP's backward kernel (fused_mlp_backward.hip) for callers in other translation units: level_w may be
 // NULL (no window); t3_base = first of the 14 transposed fragments (T_W3, T_W2, T_W1) in `image`
 int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
