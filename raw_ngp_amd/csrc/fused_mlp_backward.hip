@@ -155,9 +155,7 @@ __device__ __forceinline__ half8 pack_masked(const f32x16 &a, const half8 &act)
     // mask = all ones where act > 0, built with packed 16-bit integer ops on the f16 bit patterns (a positive f16 is
     // a positive int16; -0 is negative): clamp to {0, 1}, multiply by 0xffff
     typedef short short8 __attribute__((ext_vector_type(8)));
-    half8 o;
-#pragma unroll
-    for (int t = 0; t < 8; t++) o[t] = (_Float16)a[8 * S + t];
+    const half8 o = pack_sat<S>(a);   // deltas saturate instead of overflowing to inf (mlp_common.hpp)
     short8 m = __builtin_bit_cast(short8, act);
     m = __builtin_elementwise_min(__builtin_elementwise_max(m, (short8)0), (short8)1) * (short8)-1;
     return __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, o) & m));
@@ -334,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             d6[1] = e1 <= 5.0f ? gr1 * e1 * loss_scale : 0.0f;
             d6[2] = e2 <= 5.0f ? gr2 * e2 * loss_scale : 0.0f;
         }
-        const half8 p6 = pack<0, false>(d6);
+        const half8 p6 = pack_sat<0>(d6);
 
         // ---------------- layer 6: dW6 = delta6 x H4^T ; delta5 = W6^T delta6 (masked)
         half8 aT[2], bT[2];
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             for (int s = 0; s < 2; s++) dx3 = mfma(NGP_FRAG(T_W4 + kb * 2 + s), p4[kb][s], dx3);
         // delta3: rows 1..15 = d features, row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp)
         if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
-        if (valid) d3buf[(size_t)row * 2 + h] = pack<0, false>(dx3);
+        if (valid) d3buf[(size_t)row * 2 + h] = pack_sat<0>(dx3);
         NGP_STAMP_AT(5);      // dW4, d x3, store
     }
     NGP_STAMP_BEGIN();

@@ -78,15 +78,6 @@ __global__ __launch_bounds__(256) void mlp_rf_prepare_kernel(MlpWeights W, _Floa
 
 #define RF_FRAG(id) lds_w[(id) * 64 + lane]
 
-// conversion of a delta tile to f16 with saturation: a plain cast turns |x| > 65504 into inf, and one inf in a delta
-// becomes NaN weights for good (the reference's GradScaler would skip that step; here the sample's gradient is clipped)
-template <int S>
-__device__ __forceinline__ half8 pack_sat(const f32x16 &a)
-{
-    half8 o = pack<S, false>(a);
-    o = __builtin_elementwise_min(__builtin_elementwise_max(o, (half8)(_Float16)-65504.0f), (half8)(_Float16)65504.0f);
-    return o;
-}
 template <int S>
 __device__ __forceinline__ half8 pack_masked_sat(const f32x16 &a, const half8 &act)
 {

@@ -74,6 +74,15 @@ __device__ __forceinline__ half8 pack(const f32x16 &a)
     return o;
 }
 
+// conversion of a delta tile to f16 with saturation: a plain cast turns |x| > 65504 into inf, and one inf in a delta
+// becomes NaN weights for good (the reference's GradScaler would skip that step; here the sample's gradient is clipped)
+template <int S>
+__device__ __forceinline__ half8 pack_sat(const f32x16 &a)
+{
+    half8 o = pack<S, false>(a);
+    o = __builtin_elementwise_min(__builtin_elementwise_max(o, (half8)(_Float16)-65504.0f), (half8)(_Float16)65504.0f);
+    return o;
+}
 struct MlpWeights {
     const float *w1, *w2, *w3, *w4, *w5, *w6;
 };

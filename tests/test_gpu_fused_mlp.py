@@ -216,3 +216,18 @@ def test_backward_is_deterministic_and_independent_of_loss_scale():
         assert torch.equal(a, b)                      # fixed reduction order: bitwise reproducible
     for a, b in zip(outs[0], outs[2]):
         assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())
+
+
+def test_backward_saturates_instead_of_overflowing():
+    """An output gradient that would overflow f16 after the loss scale (dsigma * exp(raw) * 1024 > 65504) is clipped at the
+    f16 maximum instead of becoming inf: every gradient stays finite, so one bad sample cannot put NaN into the weights
+    (the reference's GradScaler would skip such a step; a static scale has to survive it)."""
+    W = make_weights(4)
+    M = 257
+    enc = torch.randn(16, M, 2, device="cuda") * 0.5
+    dirs = torch.randn(M, 3, device="cuda")
+    dsigma = torch.full((M,), 1e3, device="cuda")
+    drgb = torch.full((M, 3), 1e3, device="cuda")
+    denc, dws = run_backward(W, enc, M, dirs, dsigma, drgb, M)
+    assert torch.isfinite(denc).all() and all(torch.isfinite(g).all() for g in dws)
+    assert float(denc.abs().max()) > 0
