@@ -4,7 +4,7 @@ set -e
 name=$1
 root=$(pwd); out=$root/gpurun_out/$name; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pg_$name -- python3 $root/tools/grid_bench.py --iters 20 > $out/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pg_$name -- python3 $root/tools/grid_bench.py --iters 20 "${@:2}" > $out/run.log 2>&1
 f=$(find /tmp/pg_$name -name '*kernel_stats.csv' | head -1)
 python3 - "$f" > $out/kernel_stats.csv <<'PY'
 import csv, sys
