@@ -169,7 +169,10 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     arg_idx, bytes_per_sample = ROOFLINE_KERNELS[args.roofline_kernel]
     symbols = (args.roofline_kernel,)
     if args.roofline_kernel == "ngp_x_grid_backward_binned":
-        symbols = ("ngp_x_grid_backward_binned_apply", "ngp_x_grid_backward_binned_prepare")
+        # (one GPU, plain field: the apply call that also carries the MLP's weight-gradient reduction along)
+        ride = fused and trainer.fuse_adam and not trainer.rfield and not getattr(opt, "aux_stream", False) and \
+            os.environ.get("NGP_MLP_TAIL_RIDES", "1") != "0"
+        symbols = ("ngp_x_grid_backward_binned_apply" + ("_mlp" if ride else ""), "ngp_x_grid_backward_binned_prepare")
     # the north star also names the encoder's forward: timed the same way, reported as roofline_forward
     fwd_symbol = "ngp_x_grid_encode_forward_slab"
     probed = symbols + ((fwd_symbol,) if fused and fwd_symbol not in symbols else ())

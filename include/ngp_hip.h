@@ -222,6 +222,19 @@ int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, con
                                      void *workspace, size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
                                      float *adam_exp_avg_sq, const float *adam_hyper, float beta1, float beta2,
                                      float eps, int overwrite, ngp_stream_t stream);
+/* ngp_x_grid_backward_binned_apply with ngp_x_mlp_reduce_dw riding along (its arguments, mlp_ prefix, same meaning and
+ * checks): the weight-gradient reduction of the fused MLP runs as extra workgroups of the fill kernel instead of as a
+ * kernel of its own -- one launch and one dependent-launch gap fewer on the fused step's critical path.  Nothing in the
+ * table backward depends on it or vice versa. */
+int ngp_x_grid_backward_binned_apply_mlp(
+    const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, const int32_t *B_dev, uint32_t B,
+    uint32_t grad_stride, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
+    uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows, void *workspace, size_t workspace_bytes, float *adam_param,
+    float *adam_exp_avg, float *adam_exp_avg_sq, const float *adam_hyper, float beta1, float beta2, float eps, int overwrite,
+    uint32_t mlp_M, float mlp_loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6,
+    const void *mlp_workspace, size_t mlp_workspace_bytes, float *mlp_adam_param, const float *mlp_adam_grad,
+    float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq, uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1,
+    float mlp_beta2, float mlp_eps, void *mlp_adam_image, ngp_stream_t stream);
 /* overwrite != 0 (workspace prepared with single_segment, max_level == L): grad_embeddings = sums for EVERY row of every
  * level (zeros where nothing landed) instead of +=, so the caller neither zeroes the gradient nor pays its read.
  * overwrite == 2: the same, stored as bfloat16 (round to nearest even) -- grad_embeddings then points to

@@ -47,6 +47,10 @@ _SIGNATURES = {
                                            ctypes.c_size_t],
     "ngp_x_grid_backward_binned_apply": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
                                          ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i],
+    "ngp_x_grid_backward_binned_apply_mlp": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
+                                             ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i,
+                                             _u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f,
+                                             _f, _f, _p],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u, _i],
     "ngp_x_grid_encode_forward_jac": [_p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _p, _u, _i, _u, _i],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
@@ -335,10 +339,13 @@ class _GridBackend:
 
     @staticmethod
     def grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
-                                   workspace, gridtype=0, align_corners=False, interp=0, adam=None, overwrite=False):
+                                   workspace, gridtype=0, align_corners=False, interp=0, adam=None, overwrite=False,
+                                   mlp_tail=None):
         """Fill + reduce on a workspace prepared for the same positions.  adam = (param, exp_avg, exp_avg_sq, hyper,
         beta1, beta2, eps): apply the optimiser inside the reduce kernel instead of writing grad_embeddings.
-        overwrite: grad_embeddings = sums for every row (no +=); a bfloat16 grad_embeddings selects the 16-bit store."""
+        overwrite: grad_embeddings = sums for every row (no +=); a bfloat16 grad_embeddings selects the 16-bit store.
+        mlp_tail = (M, loss_scale, dws, workspace, adam, image), the arguments of mlp_backend.reduce_dw: that reduction
+        rides along as extra workgroups of the fill kernel (ngp_x_grid_backward_binned_apply_mlp)."""
         n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
         wire16 = grad_embeddings is not None and grad_embeddings.dtype == torch.bfloat16
         if wire16 and not overwrite:
@@ -348,12 +355,24 @@ class _GridBackend:
             p_, m_, v_, hyper, b1, b2, eps = adam
             extra = [_ptr(p_, "f", "adam_param"), _ptr(m_, "f", "adam_exp_avg"), _ptr(v_, "f", "adam_exp_avg_sq"),
                      _ptr(hyper, "f", "adam_hyper"), float(b1), float(b2), float(eps)]
-        _call("ngp_x_grid_backward_binned_apply", grad, _ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"),
-              _ptr(offsets, "i", "offsets"),
-              _ptr(grad_embeddings, "h" if wire16 else "f", "grad_embeddings", adam is not None),
-              _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
-              int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets),
-              workspace.data_ptr(), workspace.numel(), *extra, 2 if wire16 else int(bool(overwrite)))
+        args = [_ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"), _ptr(offsets, "i", "offsets"),
+                _ptr(grad_embeddings, "h" if wire16 else "f", "grad_embeddings", adam is not None),
+                _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
+                int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets),
+                workspace.data_ptr(), workspace.numel(), *extra, 2 if wire16 else int(bool(overwrite))]
+        if mlp_tail is None:
+            _call("ngp_x_grid_backward_binned_apply", grad, *args)
+            return
+        M, loss_scale, dws, mlp_ws, mlp_adam, image = mlp_tail
+        mextra = [None, None, None, None, 0, None, 0.0, 0.0, 0.0]
+        if mlp_adam is not None:
+            p_, g_, m_, v_, hyper, b1, b2, eps = mlp_adam
+            mextra = [_ptr(p_, "f", "mlp_adam_param"), _ptr(g_, "f", "mlp_adam_grad"), _ptr(m_, "f", "mlp_adam_exp_avg"),
+                      _ptr(v_, "f", "mlp_adam_exp_avg_sq"), g_.numel(), _ptr(hyper, "f", "mlp_adam_hyper"), float(b1),
+                      float(b2), float(eps)]
+        _call("ngp_x_grid_backward_binned_apply_mlp", grad, *args, M, float(loss_scale),
+              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], mlp_ws.data_ptr(), mlp_ws.numel(), *mextra,
+              image.data_ptr() if image is not None else None)
 
     @staticmethod
     def backward_workspace_bytes(B, L, rows):

@@ -20,7 +20,6 @@
 
 namespace ngp {
 
-constexpr uint32_t kAccFloats = 8 * 16 * 64;   // 8 accumulator tiles per kernel = 8192 floats per workgroup
 // dynamic LDS: the weight fragments during the tile loop (46 / 26 KiB), then the staging area of the partial-sum flush
 constexpr size_t kViewLds = flush_lds_bytes(8) > 46 * 1024 ? flush_lds_bytes(8) : 46 * 1024;
 constexpr size_t kGridLds = flush_lds_bytes(8) > 32 * 1024 ? flush_lds_bytes(8) : 32 * 1024;
@@ -615,98 +614,10 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
 // -> dW[32*rb + o][32*cb + j] with o = (v&3) + 8(v>>2) + 4(lane>>5), j = lane & 31
 // optional: torch.optim.Adam (as engine_kernels.hip: adam_span) on the flat MLP weight buffer, element by element as the
 // gradients come out of the reduction; dw1..dw6 must then be views of `grad`
-struct MlpAdam {
-    float *param;
-    const float *grad;
-    float *exp_avg, *exp_avg_sq;
-    const float *hyper;   // {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)}
-    float b1, b2, eps;
-    _Float16 *image;      // optional: the f16 operand image (ngp_x_mlp_prepare) is patched with the new weight
-};
-
-__global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(const float *__restrict__ part_view,
-                                                           const float *__restrict__ part_grid, uint32_t n_wg,
-                                                           float inv_loss_scale, float *__restrict__ dw1,
-                                                           float *__restrict__ dw2, float *__restrict__ dw3,
-                                                           float *__restrict__ dw4, float *__restrict__ dw5,
-                                                           float *__restrict__ dw6, MlpAdam adam)
+__global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(MlpDwReduce r)
 {
-    // 64 outputs per workgroup; wave q sums the slabs q, q + 4, q + 8, ... (eight loads in flight: the sum is
-    // latency-bound otherwise) and the four partial sums are added in wave order -- a fixed order, so the result is
-    // reproducible run to run
     __shared__ float part[4][64];
-    const uint32_t e = blockIdx.x * 64 + (threadIdx.x & 63u), q = threadIdx.x >> 6;
-    const bool view = e >= kAccFloats;
-    const uint32_t i = view ? e - kAccFloats : e;
-    const float *src = (view ? part_view : part_grid) + i;
-    float s = 0.0f;
-    uint32_t w = q;
-    for (; w + 28 < n_wg; w += 32) {
-        float t[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) t[k] = src[(size_t)(w + 4 * k) * kAccFloats];
-#pragma unroll
-        for (int k = 0; k < 8; k++) s += t[k];
-    }
-    for (; w < n_wg; w += 4) s += src[(size_t)w * kAccFloats];
-    part[q][threadIdx.x & 63u] = s;
-    __syncthreads();
-    if (q != 0) return;
-    s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-    s *= inv_loss_scale;
-    const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
-    const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;
-    float *dst = nullptr;   // padding elements of the tiles have no weight behind them
-    uint32_t pos_f = 0, pos_t = 0;   // the weight's two places in the f16 operand image (as-is and transposed block)
-    if (b < 2) {   // first-layer tiles: rb = b
-        if (view) {
-            if (j >= 1) {
-                dst = &dw4[(32 * b + o) * 31 + j - 1];
-                pos_f = frag_pos(F_W4 + b * 2, o, j);
-                pos_t = frag_pos(T_W4 + b * 2, j, o);
-            }
-        } else {
-            dst = &dw1[(32 * b + o) * 32 + j];
-            pos_f = frag_pos(F_W1 + b * 2, o, j);
-            pos_t = frag_pos(T_W1 + b * 2, j, o);
-        }
-    } else if (b < 6) {   // 64 x 64 tiles: rb = (b-2) >> 1, cb = (b-2) & 1
-        const uint32_t rb = (b - 2) >> 1, cb = (b - 2) & 1;
-        dst = &(view ? dw5 : dw2)[(32 * rb + o) * 64 + 32 * cb + j];
-        pos_f = frag_pos((view ? F_W5 : F_W2) + rb * 4 + cb * 2, o, j);
-        pos_t = frag_pos((view ? T_W5 : T_W2) + cb * 4 + rb * 2, j, o);
-    } else {   // last-layer tiles: cb = b - 6
-        const uint32_t cb = b - 6;
-        if (view) {
-            if (o < 3) {
-                dst = &dw6[o * 64 + 32 * cb + j];
-                pos_f = frag_pos(F_W6 + cb * 2, o, j);
-                pos_t = frag_pos(T_W6 + cb, j, o);
-            }
-        } else {
-            if (o < 16) {
-                dst = &dw3[o * 64 + 32 * cb + j];
-                pos_f = frag_pos(F_W3 + cb * 2, o, j);
-                pos_t = frag_pos(T_W3 + cb, j, o);
-            }
-        }
-    }
-    if (!dst) return;
-    *dst = s;
-    if (adam.param) {   // the six gradients are views of one flat buffer: Adam on the element just reduced
-        const size_t k = (size_t)(dst - adam.grad);
-        const float step_size = adam.hyper[0] / adam.hyper[1], rsqrt_bc2 = adam.hyper[2];
-        const float mi = adam.b1 * adam.exp_avg[k] + (1.0f - adam.b1) * s;
-        const float vi = adam.b2 * adam.exp_avg_sq[k] + (1.0f - adam.b2) * s * s;
-        adam.exp_avg[k] = mi;
-        adam.exp_avg_sq[k] = vi;
-        const float p = adam.param[k] - step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + adam.eps));
-        adam.param[k] = p;
-        if (adam.image) {   // next step's operand image without a prepare pass (its padding entries never change)
-            adam.image[pos_f] = (_Float16)p;
-            adam.image[pos_t] = (_Float16)p;
-        }
-    }
+    mlp_reduce_dw_group(r, blockIdx.x, threadIdx.x, part);
 }
 
 // the backward kernels stage their partial sums in 64 KiB of dynamic LDS (the default limit)
@@ -759,6 +670,32 @@ static uint32_t mlp_bwd_blocks(uint32_t M)
     return max(1u, min(ceil_div(tiles, 4u), 256u));
 }
 
+// arguments of the weight-gradient reduction over the partial slabs ngp_x_mlp_backward(M, ...) left in `workspace`
+// (checks as ngp_x_mlp_reduce_dw; also used by the table backward's launch, which can carry this reduction along)
+int ngp::mlp_dw_reduce_args(MlpDwReduce &r, const char *who, uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3,
+                            float *dw4, float *dw5, float *dw6, const void *workspace, size_t workspace_bytes,
+                            float *adam_param, const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq,
+                            uint32_t adam_n, const float *adam_hyper, float beta1, float beta2, float eps, void *adam_image)
+{
+    NGP_REQUIRE(dw1 && dw2 && dw3 && dw4 && dw5 && dw6 && workspace, "%s: null tensor", who);
+    NGP_REQUIRE(!adam_image || adam_param, "%s: the operand image is only patched together with Adam", who);
+    if (adam_param) {
+        NGP_REQUIRE(adam_grad && adam_exp_avg && adam_exp_avg_sq && adam_hyper, "%s: incomplete Adam state", who);
+        for (const float *d : {dw1, dw2, dw3, dw4, dw5, dw6})
+            NGP_REQUIRE(d >= adam_grad && d < adam_grad + adam_n, "%s: dw tensors must be views of adam_grad", who);
+    }
+    NGP_REQUIRE(workspace_bytes >= ngp_x_mlp_backward_workspace_bytes(M), "%s: workspace too small", who);
+    NGP_REQUIRE(loss_scale > 0.0f, "%s: loss_scale must be positive", who);
+    r.part_view = reinterpret_cast<const float *>(reinterpret_cast<const char *>(workspace) + (((size_t)M * 32 + 255) & ~(size_t)255));
+    r.part_grid = r.part_view + (size_t)256 * kAccFloats;
+    r.n_wg = mlp_bwd_blocks(max(M, 1u));
+    r.inv_loss_scale = 1.0f / loss_scale;
+    r.dw1 = dw1, r.dw2 = dw2, r.dw3 = dw3, r.dw4 = dw4, r.dw5 = dw5, r.dw6 = dw6;
+    r.adam = MlpAdam{adam_param, adam_grad, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps,
+                     reinterpret_cast<_Float16 *>(adam_image)};
+    return NGP_OK;
+}
+
 extern "C" size_t ngp_x_mlp_backward_workspace_bytes(uint32_t M)
 {
     return (size_t)M * 32 + 2 * (size_t)256 * kAccFloats * 4 + 256;
@@ -790,8 +727,8 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
     mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
                                                                                d3buf, denc, part_grid, nullptr, T_W3);
     if (reduce_now)
-        mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, st>>>(part_view, part_grid, blocks, 1.0f / loss_scale,
-                                                                              dw1, dw2, dw3, dw4, dw5, dw6, MlpAdam{});
+        mlp_reduce_dw_kernel<<<dim3(kDwGroups), dim3(256), 0, st>>>(
+            MlpDwReduce{part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, MlpAdam{}});
     NGP_CHECK_LAUNCH("mlp_backward");
     return NGP_OK;
 }
@@ -804,23 +741,12 @@ extern "C" int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, flo
                                    uint32_t adam_n, const float *adam_hyper, float beta1, float beta2, float eps,
                                    void *adam_image, ngp_stream_t stream)
 {
-    NGP_REQUIRE(dw1 && dw2 && dw3 && dw4 && dw5 && dw6 && workspace, "mlp_reduce_dw: null tensor");
-    NGP_REQUIRE(!adam_image || adam_param, "mlp_reduce_dw: the operand image is only patched together with Adam");
-    if (adam_param) {
-        NGP_REQUIRE(adam_grad && adam_exp_avg && adam_exp_avg_sq && adam_hyper, "mlp_reduce_dw: incomplete Adam state");
-        for (const float *d : {dw1, dw2, dw3, dw4, dw5, dw6})
-            NGP_REQUIRE(d >= adam_grad && d < adam_grad + adam_n, "mlp_reduce_dw: dw tensors must be views of adam_grad");
-    }
-    NGP_REQUIRE(workspace_bytes >= ngp_x_mlp_backward_workspace_bytes(M), "mlp_reduce_dw: workspace too small");
-    NGP_REQUIRE(loss_scale > 0.0f, "mlp_reduce_dw: loss_scale must be positive");
-    const uint32_t blocks = mlp_bwd_blocks(max(M, 1u));
-    const float *part_view = reinterpret_cast<const float *>(reinterpret_cast<const char *>(workspace) +
-                                                             (((size_t)M * 32 + 255) & ~(size_t)255));
-    const float *part_grid = part_view + (size_t)256 * kAccFloats;
-    mlp_reduce_dw_kernel<<<dim3(2 * kAccFloats / 64u), dim3(256), 0, as_stream(stream)>>>(
-        part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6,
-        MlpAdam{adam_param, adam_grad, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps,
-                reinterpret_cast<_Float16 *>(adam_image)});
+    MlpDwReduce r;
+    const int rc = mlp_dw_reduce_args(r, "mlp_reduce_dw", M, loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, workspace, workspace_bytes,
+                                      adam_param, adam_grad, adam_exp_avg, adam_exp_avg_sq, adam_n, adam_hyper, beta1, beta2,
+                                      eps, adam_image);
+    if (rc != NGP_OK) return rc;
+    mlp_reduce_dw_kernel<<<dim3(kDwGroups), dim3(256), 0, as_stream(stream)>>>(r);
     NGP_CHECK_LAUNCH("mlp_reduce_dw");
     return NGP_OK;
 }

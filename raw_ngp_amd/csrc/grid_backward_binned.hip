@@ -23,6 +23,7 @@
 // Result: the reference's sums, each rounded once (resolution 2^-37 of the largest contribution) instead of
 // once per atomic in hardware order; bitwise reproducible except for the few multi-segment chunks.
 #include "binned_common.hpp"
+#include "mlp_common.hpp"
 
 namespace ngp {
 
@@ -162,16 +163,25 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
                                                          const int32_t *__restrict__ B_dev, uint32_t B_cap, uint32_t gstride,
                                                          uint32_t ntiles, uint32_t nbins_cap, LevelRes lv,
                                                          uint32_t gridtype, bool align_corners, uint32_t interp,
-                                                         WsLayout w)
+                                                         WsLayout w, uint32_t n_tail, MlpDwReduce tail)
 {
     extern __shared__ uint32_t lds[];
+    // The first n_tail workgroups are passengers: they reduce the tiny MLPs' weight gradients (two groups of 64 outputs
+    // each, mlp_common.hpp) instead of filling records.  That reduction is 10 us of latency-bound loads which nothing
+    // waits for until the next step's MLP forward; as a kernel of its own it sat on the step's critical path with the
+    // gap of a dependent launch on top.
+    if (blockIdx.x < n_tail) {
+        float(*part)[64] = reinterpret_cast<float(*)[64]>(lds) + 4 * (threadIdx.x >> 8);
+        mlp_reduce_dw_group(tail, blockIdx.x * 2u + (threadIdx.x >> 8), threadIdx.x & 255u, part);
+        return;
+    }
     uint32_t *hist = lds, *lbase = lds + nbins_cap, *delta = lds + 2 * nbins_cap;
     uint32_t *stage_key = lds + 3 * nbins_cap;
     float2 *stage_val = reinterpret_cast<float2 *>(stage_key + 8 * kFillTile);   // 8-byte aligned: nbins_cap % 4 == 0
     __shared__ uint32_t s_total;
 
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
-    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t item = xcd_remap(blockIdx.x - n_tail, gridDim.x - n_tail);
     const uint32_t level = item / ntiles;
     const uint32_t b0 = (item - level * ntiles) * kFillTile;
     if (b0 >= B) return;
@@ -565,7 +575,7 @@ extern "C" int ngp_x_grid_backward_binned_prepare(const float *inputs, float in_
 }
 
 // fill + reduce on a prepared workspace (same inputs, in [0,1], and the same B_dev value as the prepare call)
-extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, const int32_t *offsets,
+static int binned_apply(const char *who, const MlpDwReduce *tail, const float *grad, const float *inputs, const int32_t *offsets,
                                                 float *grad_embeddings, const int32_t *B_dev, uint32_t B,
                                                 uint32_t grad_stride, uint32_t L, uint32_t max_level, float S,
                                                 uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
@@ -574,6 +584,7 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
                                                 float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
                                                 float beta2, float eps, int overwrite, ngp_stream_t stream)
 {
+    (void)who;
     if (B == 0 || max_level == 0) return NGP_OK;
     const bool fused = adam_param != nullptr;
     NGP_REQUIRE(!(fused && overwrite), "grid_backward_binned_apply: overwrite and fused Adam exclude each other");
@@ -594,9 +605,10 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
     NGP_REQUIRE(lds_ok, "grid_backward_binned_apply: cannot raise the dynamic LDS limit");
     hipStream_t st = as_stream(stream);
     const uint32_t ft = ceil_div(B, kFillTile);
-    bin_fill_kernel<<<ft * max_level, kFillBlock, c.fill_lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft,
-                                                                   c.nbins_cap, c.lv, gridtype, align_corners != 0, interp,
-                                                                   c.w);
+    const uint32_t n_tail = tail ? kDwGroups / 2u : 0u;   // two groups of 64 outputs per 512-lane workgroup
+    bin_fill_kernel<<<ft * max_level + n_tail, kFillBlock, c.fill_lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft,
+                                                                            c.nbins_cap, c.lv, gridtype, align_corners != 0,
+                                                                            interp, c.w, n_tail, tail ? *tail : MlpDwReduce{});
     const uint32_t n_items_max = c.n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
     const AdamArgs opt{adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps};
     if (fused)   // prepared with single_segment: one workgroup owns each chunk's rows
@@ -609,6 +621,46 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
         bin_reduce_kernel<0><<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
     NGP_CHECK_LAUNCH("grid_backward_binned_apply");
     return NGP_OK;
+}
+
+extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, const int32_t *offsets,
+                                                float *grad_embeddings, const int32_t *B_dev, uint32_t B,
+                                                uint32_t grad_stride, uint32_t L, uint32_t max_level, float S,
+                                                uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
+                                                size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
+                                                float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
+                                                float beta2, float eps, int overwrite, ngp_stream_t stream)
+{
+    return binned_apply("grid_backward_binned_apply", nullptr, grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L,
+                        max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
+                        workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
+                        stream);
+}
+
+// the same launch sequence with ngp_x_mlp_reduce_dw (same arguments, mlp_ prefix) riding along as extra workgroups of the
+// fill kernel: one kernel and one dependent-launch gap fewer on the fused step's critical path
+extern "C" int ngp_x_grid_backward_binned_apply_mlp(
+    const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, const int32_t *B_dev, uint32_t B,
+    uint32_t grad_stride, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
+    uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows, void *workspace, size_t workspace_bytes, float *adam_param,
+    float *adam_exp_avg, float *adam_exp_avg_sq, const float *adam_hyper, float beta1, float beta2, float eps, int overwrite,
+    uint32_t mlp_M, float mlp_loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6,
+    const void *mlp_workspace, size_t mlp_workspace_bytes, float *mlp_adam_param, const float *mlp_adam_grad,
+    float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq, uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1,
+    float mlp_beta2, float mlp_eps, void *mlp_adam_image, ngp_stream_t stream)
+{
+    NGP_REQUIRE(B != 0 && max_level != 0, "grid_backward_binned_apply_mlp: nothing to launch the reduction with");
+    MlpDwReduce r;
+    const int rc = mlp_dw_reduce_args(r, "grid_backward_binned_apply_mlp", mlp_M, mlp_loss_scale, dw1, dw2, dw3, dw4, dw5, dw6,
+                                      mlp_workspace, mlp_workspace_bytes, mlp_adam_param, mlp_adam_grad, mlp_adam_exp_avg,
+                                      mlp_adam_exp_avg_sq, mlp_adam_n, mlp_adam_hyper, mlp_beta1, mlp_beta2, mlp_eps,
+                                      mlp_adam_image);
+    if (rc != NGP_OK) return rc;
+    return binned_apply("grid_backward_binned_apply_mlp", &r, grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L,
+                        max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
+                        workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
+                        stream);
 }
 
 extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,

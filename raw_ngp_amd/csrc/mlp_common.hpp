@@ -216,4 +216,114 @@ int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *lev
                              const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
                              float *partial, uint32_t blocks, hipStream_t st);
 
+
+// ---- weight-gradient reduction over the backward kernels' partial slabs ----------------------------------------------
+// element e of a workgroup slab: tile b = e / 1024, register v = (e / 64) % 16, lane = e % 64
+// -> dW[32*rb + o][32*cb + j] with o = (v&3) + 8(v>>2) + 4(lane>>5), j = lane & 31
+// optional: torch.optim.Adam (as engine_kernels.hip: adam_span) on the flat MLP weight buffer, element by element as the
+// gradients come out of the reduction; dw1..dw6 must then be views of `grad`
+constexpr uint32_t kAccFloats = 8 * 16 * 64;   // 8 accumulator tiles per kernel = 8192 floats per workgroup
+constexpr uint32_t kDwGroups = 2 * kAccFloats / 64u;   // groups of 64 outputs (view kernel's slab, then the grid kernel's)
+struct MlpAdam {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq;
+    const float *hyper;   // {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)}
+    float b1, b2, eps;
+    _Float16 *image;      // optional: the f16 operand image (ngp_x_mlp_prepare) is patched with the new weight
+};
+struct MlpDwReduce {
+    const float *part_view, *part_grid;
+    uint32_t n_wg;
+    float inv_loss_scale;
+    float *dw1, *dw2, *dw3, *dw4, *dw5, *dw6;
+    MlpAdam adam;
+};
+int mlp_dw_reduce_args(MlpDwReduce &r, const char *who, uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3,
+                       float *dw4, float *dw5, float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
+                       const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,
+                       const float *adam_hyper, float beta1, float beta2, float eps, void *adam_image);
+
+// One group = 64 outputs, reduced by 256 lanes (tid 0..255; every lane of the group must call: there is a barrier inside).
+// Wave q sums the slabs q, q + 4, q + 8, ... (eight loads in flight: the sum is latency-bound otherwise) and the four partial
+// sums are added in wave order -- a fixed order, so the result is reproducible run to run.
+// A kernel of its own (ngp_x_mlp_reduce_dw), or extra workgroups of another launch: the reduction is ten microseconds of
+// latency-bound loads that nothing waits for until the next step's MLP forward.
+__device__ __forceinline__ void mlp_reduce_dw_group(const MlpDwReduce &a, uint32_t group, uint32_t tid, float (*part)[64])
+{
+    const uint32_t e = group * 64 + (tid & 63u), q = tid >> 6;
+    const bool view = e >= kAccFloats;
+    const uint32_t i = view ? e - kAccFloats : e;
+    const float *src = (view ? a.part_view : a.part_grid) + i;
+    float s = 0.0f;
+    uint32_t w = q;
+    for (; w + 28 < a.n_wg; w += 32) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = src[(size_t)(w + 4 * k) * kAccFloats];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += t[k];
+    }
+    for (; w < a.n_wg; w += 4) s += src[(size_t)w * kAccFloats];
+    part[q][tid & 63u] = s;
+    __syncthreads();
+    if (q != 0) return;
+    s = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+    s *= a.inv_loss_scale;
+    const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
+    const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;
+    float *dst = nullptr;   // padding elements of the tiles have no weight behind them
+    uint32_t pos_f = 0, pos_t = 0;   // the weight's two places in the f16 operand image (as-is and transposed block)
+    if (b < 2) {   // first-layer tiles: rb = b
+        if (view) {
+            if (j >= 1) {
+                dst = &a.dw4[(32 * b + o) * 31 + j - 1];
+                pos_f = frag_pos(F_W4 + b * 2, o, j);
+                pos_t = frag_pos(T_W4 + b * 2, j, o);
+            }
+        } else {
+            dst = &a.dw1[(32 * b + o) * 32 + j];
+            pos_f = frag_pos(F_W1 + b * 2, o, j);
+            pos_t = frag_pos(T_W1 + b * 2, j, o);
+        }
+    } else if (b < 6) {   // 64 x 64 tiles: rb = (b-2) >> 1, cb = (b-2) & 1
+        const uint32_t rb = (b - 2) >> 1, cb = (b - 2) & 1;
+        dst = &(view ? a.dw5 : a.dw2)[(32 * rb + o) * 64 + 32 * cb + j];
+        pos_f = frag_pos((view ? F_W5 : F_W2) + rb * 4 + cb * 2, o, j);
+        pos_t = frag_pos((view ? T_W5 : T_W2) + cb * 4 + rb * 2, j, o);
+    } else {   // last-layer tiles: cb = b - 6
+        const uint32_t cb = b - 6;
+        if (view) {
+            if (o < 3) {
+                dst = &a.dw6[o * 64 + 32 * cb + j];
+                pos_f = frag_pos(F_W6 + cb * 2, o, j);
+                pos_t = frag_pos(T_W6 + cb, j, o);
+            }
+        } else {
+            if (o < 16) {
+                dst = &a.dw3[o * 64 + 32 * cb + j];
+                pos_f = frag_pos(F_W3 + cb * 2, o, j);
+                pos_t = frag_pos(T_W3 + cb, j, o);
+            }
+        }
+    }
+    if (!dst) return;
+    *dst = s;
+    const MlpAdam &adam = a.adam;
+    if (adam.param) {   // the six gradients are views of one flat buffer: Adam on the element just reduced
+        const size_t k = (size_t)(dst - adam.grad);
+        const float step_size = adam.hyper[0] / adam.hyper[1], rsqrt_bc2 = adam.hyper[2];
+        const float mi = adam.b1 * adam.exp_avg[k] + (1.0f - adam.b1) * s;
+        const float vi = adam.b2 * adam.exp_avg_sq[k] + (1.0f - adam.b2) * s * s;
+        adam.exp_avg[k] = mi;
+        adam.exp_avg_sq[k] = vi;
+        const float p = adam.param[k] - step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + adam.eps));
+        adam.param[k] = p;
+        if (adam.image) {   // next step's operand image without a prepare pass (its padding entries never change)
+            adam.image[pos_f] = (_Float16)p;
+            adam.image[pos_t] = (_Float16)p;
+        }
+    }
+}
+
 }  // namespace ngp

@@ -20,6 +20,7 @@ loss + backward -> MLP backward (2) -> dW reduction (+Adam on the MLP weights, +
 -> fill -> reduce (+Adam on the table).  Same seed, same bits: no float atomic feeds back into the state.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -201,7 +202,8 @@ class FusedTrainer:
             self.t_v = torch.zeros(self.shard.n_shard, **f32)
         self._main_symbols = {"ngp_x_mlp_rf_forward", "ngp_x_mlp_rf_backward", "ngp_x_mlp_rf_prepare",
                               "ngp_x_grid_encode_forward_slab_jac", "ngp_x_composite_hdr_train",
-                              "ngp_x_grid_backward_binned_apply", "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
+                              "ngp_x_grid_backward_binned_apply", "ngp_x_grid_backward_binned_apply_mlp",
+                              "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
                               "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
                               "ngp_x_composite_mse_backward", "ngp_x_composite_mse_train", "ngp_x_adam_step_dev2", "ngp_x_adam_step_dev",
                               "ngp_x_step_begin", "ngp_x_mlp_prepare", "ngp_x_mlp_reduce_dw",
@@ -319,7 +321,7 @@ class FusedTrainer:
             op()
 
     def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False, split_weights=False,
-                   overwrite=False, fuse_composite=False):
+                   overwrite=False, fuse_composite=False, mlp_tail=None):
         """The field part of the step as (C entry point, thunk) pairs, in launch order.  split_weights: the step path --
         the f16 weight image was prepared at the end of the previous step and the weight-gradient reduction is left to
         the caller (it goes to the aux stream together with the MLP's Adam step)."""
@@ -377,9 +379,9 @@ class FusedTrainer:
                 self.image)),
             ("ngp_x_composite_mse_backward", loss_and_composite_backward),
             ("ngp_x_mlp_backward", mlp_backward),
-            ("ngp_x_grid_backward_binned_apply", lambda: gb.grid_backward_binned_apply(
+            ("ngp_x_grid_backward_binned_apply" + ("_mlp" if mlp_tail is not None else ""), lambda: gb.grid_backward_binned_apply(
                 self.denc, self.x01, offsets, self._wire if overwrite and self.wire16 else self.table_grad, cnt, cap, cap,
-                self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite)),
+                self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite, mlp_tail=mlp_tail)),
         ]
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
@@ -575,9 +577,16 @@ class FusedTrainer:
         ops = []
         # separate Adam (data parallel, or fuse_adam off): the reduction writes every row of the gradient, so nothing
         # has to zero it and the accumulate's read disappears (TV / weight decay are added afterwards, in optimizer_step)
+        # one GPU, plain field: the MLP's weight-gradient reduction (+ Adam on the MLP weights + their entries in the f16
+        # operand image) rides along with the table backward's fill launch instead of being a kernel of its own
+        ride = split and not self.rfield and not bool(getattr(opt, "aux_stream", False)) and \
+            os.environ.get("NGP_MLP_TAIL_RIDES", "1") != "0"
+        mlp_tail = (self.cap, opt.loss_scale, self.dws, self.ws_mlp,
+                    (self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps), self.mlp_image) if ride else None
+        self.table_backward_symbol = "ngp_x_grid_backward_binned_apply" + ("_mlp" if ride else "")   # (what bench.py times)
         field = self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False,
                                 fused_adam=self.fuse_adam, split_weights=split, overwrite=not self.fuse_adam,
-                                fuse_composite=True)
+                                fuse_composite=True, mlp_tail=mlp_tail)
         field = self._without(field, "ngp_x_grid_backward_binned_prepare")          # folded into step_begin
         field.insert(1, begin)                                                      # right after the encoder's forward
         if self.pose:
