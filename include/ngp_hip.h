@@ -415,6 +415,14 @@ int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0, double de
 /* binned_workspace != NULL: the same launch also does ngp_x_grid_backward_binned_prepare(stage 2) on that workspace
  * (L levels, n_rows_total table rows) -- call it after the encoder's counting forward pass. */
 
+/* ngp_x_mlp_forward with ngp_x_step_begin (same arguments, same checks) as one more workgroup of the same launch: the
+ * step's one-workgroup bookkeeping leaves the critical path (nothing reads its results before the compositor). */
+int ngp_x_mlp_forward_step_begin(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
+                                 const void *image, float *sigma, float *rgb, uint32_t *step_counter, float *hyper,
+                                 double lr0, double decay_steps, double beta1, double beta2, float *loss_out,
+                                 int64_t *samples_seen, const int32_t *sample_counter, void *binned_workspace, uint32_t L,
+                                 uint32_t n_rows_total, int single_segment, ngp_stream_t stream);
+
 /* counter[0] += delta, stream-ordered. */
 int ngp_x_counter_add(uint32_t *counter, uint32_t delta, ngp_stream_t stream);
 

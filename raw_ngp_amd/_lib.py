@@ -82,6 +82,7 @@ _SIGNATURES = {
     "ngp_x_adam_step_dev": [_p, _p, _p, _p, ctypes.c_uint64, _p, _f, _f, _f, _i],
     "ngp_x_schedule_step": [_p, _p, _d, _d, _d, _d],
     "ngp_x_step_begin": [_p, _p, _d, _d, _d, _d, _p, _p, _p, _p, _u, _u, _i],
+    "ngp_x_mlp_forward_step_begin": [_p, _u, _p, _p, _u, _p, _p, _p, _p, _p, _d, _d, _d, _d, _p, _p, _p, _p, _u, _u, _i],
     "ngp_x_adam_step_dev2": [_p, _p, _p, _p, ctypes.c_uint64, _i, _p, _p, _p, _p, ctypes.c_uint64, _i, _p, _f, _f, _f, _i],
     "ngp_x_counter_add": [_p, _u],
     "ngp_x_sample_rays": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p],
@@ -545,10 +546,22 @@ class _MlpBackend:
               image.data_ptr())
 
     @staticmethod
-    def forward(enc, stride, dirs, M_dev, M, image, sigma, rgb):
-        _call("ngp_x_mlp_forward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs", True),
-              _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), _ptr(sigma, "f", "sigma"),
-              _ptr(rgb, "f", "rgb", True))
+    def forward(enc, stride, dirs, M_dev, M, image, sigma, rgb, step_begin=None):
+        """step_begin = (step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out, samples_seen, sample_counter,
+        binned_workspace, L, n_rows_total, single_segment), the arguments of engine_backend.step_begin: that bookkeeping
+        rides along as one more workgroup of this launch (ngp_x_mlp_forward_step_begin)."""
+        args = [_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs", True), _ptr(M_dev, "i", "M_dev", True), M,
+                image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb", True)]
+        if step_begin is None:
+            _call("ngp_x_mlp_forward", enc, *args)
+            return
+        ctr, hyper, lr0, decay, b1, b2, loss_out, seen, counter, ws, L, n_rows, single = step_begin
+        if seen is not None and (seen.dtype != torch.int64 or not seen.is_cuda):
+            raise RuntimeError("samples_seen must be an int64 CUDA tensor")
+        _call("ngp_x_mlp_forward_step_begin", enc, *args, _ptr(ctr, "u", "step_counter"), _ptr(hyper, "f", "hyper"),
+              float(lr0), float(decay), float(b1), float(b2), _ptr(loss_out, "f", "loss_out", True),
+              seen.data_ptr() if seen is not None else None, _ptr(counter, "i", "sample_counter", True),
+              ws.data_ptr() if ws is not None else None, int(L), int(n_rows), int(bool(single)))
 
 
     @staticmethod

@@ -95,16 +95,16 @@ __device__ __forceinline__ bool run_shape(uint32_t key, bool live, uint32_t &dis
 }
 
 // exclusive prefix of the per-chunk record counts (4-record aligned) -> record offsets, plus the reduce work items; to be
-// run by ONE workgroup of 1024 lanes (bin_scan_kernel, or the fused step's step_begin kernel)
+// run by ONE workgroup of 256 .. 1024 lanes (bin_scan_kernel, or the fused step's step_begin work)
 __device__ __forceinline__ void bin_scan_block(uint32_t L, const WsLayout &w, bool single_segment)
 {
     __shared__ uint32_t wave_a[16], wave_b[16];
     __shared__ uint32_t carry_a, carry_b;
     const uint32_t n = w.chunk_base[L];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6, width = blockDim.x, nw = width >> 6;
     if (tid == 0) carry_a = carry_b = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024u) {
+    for (uint32_t base = 0; base < n; base += width) {
         const uint32_t i = base + tid;
         const uint32_t cnt = i < n ? w.count[i] : 0u;
         const uint32_t cnt4 = (cnt + 3u) & ~3u;   // 4-record alignment: 16-byte loads in the reduce kernel
@@ -125,7 +125,7 @@ __device__ __forceinline__ void bin_scan_block(uint32_t L, const WsLayout &w, bo
         }
         __syncthreads();
         uint32_t oa = 0, ob = 0, ta = 0, tb = 0;
-        for (uint32_t k = 0; k < 16u; k++) {
+        for (uint32_t k = 0; k < nw; k++) {
             if (k < wid) {
                 oa += wave_a[k];
                 ob += wave_b[k];
@@ -150,5 +150,45 @@ __device__ __forceinline__ void bin_scan_block(uint32_t L, const WsLayout &w, bo
         w.seg_base[n] = carry_b;
     }
 }
+
+// ------------------------------------------------------------------ per-step scalars (+ the scan above)
+// What the fused step does once per step with one workgroup: learning rate and Adam bias corrections (the LambdaLR of
+// main.py:261 and torch.optim.Adam's), loss = 0, samples_seen += this batch's sample count, step counter + 1 -- and, if
+// asked, the record offsets of the binned table backward.  A kernel of its own (ngp_x_step_begin), or one extra workgroup
+// of the MLP forward's launch (ngp_x_mlp_forward_step_begin): nothing consumes any of it before the compositor.
+struct StepBegin {
+    uint32_t *step_counter;
+    float *hyper;
+    double lr0, decay_steps, b1, b2;
+    float *loss_out;
+    long long *samples_seen;
+    const int32_t *sample_counter;
+    bool scan, single_segment;
+    uint32_t L;
+    WsLayout w;
+};
+__device__ __forceinline__ void step_begin_block(const StepBegin &a)
+{
+    // the three scalars cost a double-precision pow each (~1 us on a lone lane): three different waves take one each
+    // while the others already wait on the scan's first loads
+    const uint32_t done = a.step_counter[0];
+    const uint32_t nw = blockDim.x >> 6, wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) {
+        const double t = (double)done + 1.0;
+        if (wid == nw - 1) a.hyper[0] = (float)(a.lr0 * pow(0.1, fmin((double)done / a.decay_steps, 1.0)));
+        if (wid == (nw >= 2 ? nw - 2 : 0)) a.hyper[1] = (float)(1.0 - pow(a.b1, t));
+        if (wid == (nw >= 3 ? nw - 3 : 0)) a.hyper[2] = (float)(1.0 / sqrt(1.0 - pow(a.b2, t)));
+    }
+    if (a.scan) bin_scan_block(a.L, a.w, a.single_segment);
+    __syncthreads();   // every wave has read the step counter
+    if (threadIdx.x != 0) return;
+    a.step_counter[0] = done + 1u;
+    if (a.loss_out) a.loss_out[0] = 0.0f;
+    if (a.samples_seen && a.sample_counter) a.samples_seen[0] += (long long)a.sample_counter[0];
+}
+// host side: checks and packing shared by the two entry points
+int step_begin_args(StepBegin &a, const char *who, uint32_t *step_counter, float *hyper, double lr0, double decay_steps,
+                    double beta1, double beta2, float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
+                    void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment);
 
 }  // namespace ngp

@@ -530,30 +530,7 @@ __global__ void schedule_kernel(uint32_t *step_counter, float *hyper, double lr0
 
 __global__ void counter_add_kernel(uint32_t *counter, uint32_t delta) { counter[0] += delta; }
 
-// (optionally also the binned backward's scan: both are one-workgroup jobs between the encoder's forward pass and the
-// MLP, and each launch on the critical path costs ~6 us)
-__global__ __launch_bounds__(1024) void step_begin_kernel(uint32_t *step_counter, float *hyper, double lr0,
-                                                         double decay_steps, double b1, double b2, float *loss_out,
-                                                         long long *samples_seen, const int32_t *sample_counter,
-                                                         bool scan, uint32_t L, WsLayout w, bool single_segment)
-{
-    // the three scalars cost a double-precision pow each (~1 us on a lone lane): three different waves take one each
-    // while the others already wait on the scan's first loads
-    const uint32_t done = step_counter[0];
-    const uint32_t nw = blockDim.x >> 6, wid = threadIdx.x >> 6;
-    if ((threadIdx.x & 63u) == 0) {
-        const double t = (double)done + 1.0;
-        if (wid == nw - 1) hyper[0] = (float)(lr0 * pow(0.1, fmin((double)done / decay_steps, 1.0)));
-        if (wid == (nw >= 2 ? nw - 2 : 0)) hyper[1] = (float)(1.0 - pow(b1, t));
-        if (wid == (nw >= 3 ? nw - 3 : 0)) hyper[2] = (float)(1.0 / sqrt(1.0 - pow(b2, t)));
-    }
-    if (scan) bin_scan_block(L, w, single_segment);
-    __syncthreads();   // every wave has read the step counter
-    if (threadIdx.x != 0) return;
-    step_counter[0] = done + 1u;
-    if (loss_out) loss_out[0] = 0.0f;
-    if (samples_seen && sample_counter) samples_seen[0] += (long long)sample_counter[0];
-}
+__global__ __launch_bounds__(1024) void step_begin_kernel(StepBegin a) { step_begin_block(a); }
 
 // ------------------------------------------------------------------ ray batch sampling
 // The random_image_batch collate + get_rays + target gather of the harness (nerf/provider.py, nerf/train_utils.py:96-172)
@@ -859,25 +836,36 @@ extern "C" int ngp_x_schedule_step(uint32_t *step_counter, float *hyper, double 
     return NGP_OK;
 }
 
+int ngp::step_begin_args(StepBegin &a, const char *who, uint32_t *step_counter, float *hyper, double lr0, double decay_steps,
+                         double beta1, double beta2, float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
+                         void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment)
+{
+    NGP_REQUIRE(step_counter && hyper, "%s: null tensor", who);
+    NGP_REQUIRE(decay_steps > 0.0, "%s: decay_steps must be positive", who);
+    NGP_REQUIRE((samples_seen == nullptr) == (sample_counter == nullptr), "%s: samples_seen and sample_counter go together", who);
+    WsLayout w{};
+    if (binned_workspace) {   // = ngp_x_grid_backward_binned_prepare(stage 2) for that workspace
+        NGP_REQUIRE(L >= 1 && L <= kMaxLevels && n_rows_total > 0 && ((uintptr_t)binned_workspace & 15u) == 0,
+                    "%s: bad binned workspace arguments", who);
+        const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
+        NGP_REQUIRE(n_chunks_max <= kMaxChunks, "%s: table too large for the binned backward", who);
+        w = ws_layout(binned_workspace, n_chunks_max);
+    }
+    a = StepBegin{step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out, reinterpret_cast<long long *>(samples_seen),
+                  sample_counter, binned_workspace != nullptr, single_segment != 0, L, w};
+    return NGP_OK;
+}
+
 extern "C" int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1,
                                 double beta2, float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
                                 void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment,
                                 ngp_stream_t stream)
 {
-    NGP_REQUIRE(step_counter && hyper, "step_begin: null tensor");
-    NGP_REQUIRE(decay_steps > 0.0, "step_begin: decay_steps must be positive");
-    NGP_REQUIRE((samples_seen == nullptr) == (sample_counter == nullptr), "step_begin: samples_seen and sample_counter go together");
-    WsLayout w{};
-    if (binned_workspace) {   // = ngp_x_grid_backward_binned_prepare(stage 2) for that workspace
-        NGP_REQUIRE(L >= 1 && L <= kMaxLevels && n_rows_total > 0 && ((uintptr_t)binned_workspace & 15u) == 0,
-                    "step_begin: bad binned workspace arguments");
-        const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
-        NGP_REQUIRE(n_chunks_max <= kMaxChunks, "step_begin: table too large for the binned backward");
-        w = ws_layout(binned_workspace, n_chunks_max);
-    }
-    step_begin_kernel<<<dim3(1), dim3(binned_workspace ? 1024 : 64), 0, as_stream(stream)>>>(
-        step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out, reinterpret_cast<long long *>(samples_seen),
-        sample_counter, binned_workspace != nullptr, L, w, single_segment != 0);
+    StepBegin a;
+    const int rc = step_begin_args(a, "step_begin", step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out, samples_seen,
+                                   sample_counter, binned_workspace, L, n_rows_total, single_segment);
+    if (rc != NGP_OK) return rc;
+    step_begin_kernel<<<dim3(1), dim3(binned_workspace ? 1024 : 64), 0, as_stream(stream)>>>(a);
     NGP_CHECK_LAUNCH("step_begin");
     return NGP_OK;
 }

@@ -9,6 +9,7 @@
 // One wave = 32 samples; the six layers are chained through MFMA accumulators (see mlp_common.hpp), so no
 // activation ever leaves the register file in the forward pass; the encoder output is consumed in the
 // level-major [L, stride, 2] slab layout the grid kernel writes (no permute), SH is evaluated in-kernel.
+#include "binned_common.hpp"
 #include "mlp_common.hpp"
 #include "sh_eval.hpp"
 
@@ -79,14 +80,24 @@ __device__ __forceinline__ TileIn load_tile(const float *__restrict__ enc, size_
     } while (0)
 
 // ------------------------------------------------------------------ forward
+// PASSENGER: workgroup 0 does the step's one-workgroup bookkeeping (binned_common.hpp: step_begin_block) instead of
+// evaluating the field -- as a kernel of its own it sat on the step's critical path with a dependent-launch gap on top,
+// although nothing consumes its results before the compositor
+template <bool PASSENGER>
 __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const float *__restrict__ enc, uint32_t stride,
                                                             const float *__restrict__ dirs,
                                                             const int32_t *__restrict__ M_dev, uint32_t M_host,
                                                             const half8 *__restrict__ image,
-                                                            float *__restrict__ sigma, float *__restrict__ rgb)
+                                                            float *__restrict__ sigma, float *__restrict__ rgb,
+                                                            StepBegin begin)
 {
+    if (PASSENGER && blockIdx.x == 0) {
+        step_begin_block(begin);
+        return;
+    }
+    const uint32_t first = PASSENGER ? 1u : 0u;
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
-    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+    const uint32_t wave = ((blockIdx.x - first) * 256u + threadIdx.x) >> 6, n_waves = ((gridDim.x - first) * 256u) >> 6;
     const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_host) : M_host;
     const uint32_t n_tiles = (M + 31u) >> 5;
 
@@ -194,8 +205,32 @@ extern "C" int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float 
     NGP_REQUIRE(stride >= M, "mlp_forward: encoder slab stride smaller than M");
     const uint32_t tiles = ceil_div(M, 32u);
     const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * 2u);
-    mlp_forward_kernel<<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(enc, stride, dirs, M_dev, M,
-                                                                         reinterpret_cast<const half8 *>(image), sigma, rgb);
+    mlp_forward_kernel<false><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(
+        enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, StepBegin{});
     NGP_CHECK_LAUNCH("mlp_forward");
+    return NGP_OK;
+}
+
+// ngp_x_mlp_forward with ngp_x_step_begin (same arguments) as one more workgroup of the same launch
+extern "C" int ngp_x_mlp_forward_step_begin(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev,
+                                            uint32_t M, const void *image, float *sigma, float *rgb, uint32_t *step_counter,
+                                            float *hyper, double lr0, double decay_steps, double beta1, double beta2,
+                                            float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
+                                            void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment,
+                                            ngp_stream_t stream)
+{
+    NGP_REQUIRE(M != 0, "mlp_forward_step_begin: M must be positive");
+    NGP_REQUIRE(enc && image && sigma, "mlp_forward_step_begin: null tensor");
+    NGP_REQUIRE(rgb == nullptr || dirs != nullptr, "mlp_forward_step_begin: dirs missing");
+    NGP_REQUIRE(stride >= M, "mlp_forward_step_begin: encoder slab stride smaller than M");
+    StepBegin a;
+    const int rc = step_begin_args(a, "mlp_forward_step_begin", step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out,
+                                   samples_seen, sample_counter, binned_workspace, L, n_rows_total, single_segment);
+    if (rc != NGP_OK) return rc;
+    const uint32_t tiles = ceil_div(M, 32u);
+    const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * 2u);
+    mlp_forward_kernel<true><<<dim3(blocks + 1), dim3(256), 0, as_stream(stream)>>>(
+        enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, a);
+    NGP_CHECK_LAUNCH("mlp_forward_step_begin");
     return NGP_OK;
 }

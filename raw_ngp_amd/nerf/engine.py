@@ -203,7 +203,7 @@ class FusedTrainer:
         self._main_symbols = {"ngp_x_mlp_rf_forward", "ngp_x_mlp_rf_backward", "ngp_x_mlp_rf_prepare",
                               "ngp_x_grid_encode_forward_slab_jac", "ngp_x_composite_hdr_train",
                               "ngp_x_grid_backward_binned_apply", "ngp_x_grid_backward_binned_apply_mlp",
-                              "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward",
+                              "ngp_x_grid_encode_forward_slab", "ngp_x_mlp_forward", "ngp_x_mlp_forward_step_begin",
                               "ngp_x_mlp_backward", "ngp_x_composite_rays_train_forward",
                               "ngp_x_composite_mse_backward", "ngp_x_composite_mse_train", "ngp_x_adam_step_dev2", "ngp_x_adam_step_dev",
                               "ngp_x_step_begin", "ngp_x_mlp_prepare", "ngp_x_mlp_reduce_dw",
@@ -283,12 +283,13 @@ class FusedTrainer:
     def _mlp_prepare(self):
         self.mb.prepare(self.weights, self.mlp_image)
 
-    def _mlp_forward(self, stride, dirs, ldirs, cnt, M, sigma, rgb):
-        """Field evaluation on self.enc (rgb None: density only).  rfield: light directions + the level window."""
+    def _mlp_forward(self, stride, dirs, ldirs, cnt, M, sigma, rgb, step_begin=None):
+        """Field evaluation on self.enc (rgb None: density only).  rfield: light directions + the level window.
+        step_begin: the step's scalar bookkeeping rides along with this launch (plain field only)."""
         if self.rfield:
             self.mb.forward(self.enc, stride, dirs, ldirs, self.level_w, cnt, M, self.mlp_image, sigma, rgb)
         else:
-            self.mb.forward(self.enc, stride, dirs, cnt, M, self.mlp_image, sigma, rgb)
+            self.mb.forward(self.enc, stride, dirs, cnt, M, self.mlp_image, sigma, rgb, step_begin=step_begin)
 
     def march(self, slot, rays_o, rays_d, noises, aabb=None, plan=True):
         """rays -> sample arena of `slot` (near/far, count, scan, expand); runs on the current stream."""
@@ -588,7 +589,17 @@ class FusedTrainer:
                                 fused_adam=self.fuse_adam, split_weights=split, overwrite=not self.fuse_adam,
                                 fuse_composite=True, mlp_tail=mlp_tail)
         field = self._without(field, "ngp_x_grid_backward_binned_prepare")          # folded into step_begin
-        field.insert(1, begin)                                                      # right after the encoder's forward
+        if not self.rfield and not self.pose and os.environ.get("NGP_STEP_BEGIN_RIDES", "1") != "0":
+            # ... which in turn is one more workgroup of the MLP forward's launch (nothing reads its results before the
+            # compositor): one kernel and one dependent-launch gap fewer on the critical path
+            ar, cap = slot.arena, self.cap
+            sb = (self.step_ctr, self.hyper, self.lr0, float(opt.iters), *self.betas, self.loss, self.samples_seen,
+                  ar.counter, slot.ws_grid, self.L, self.rows, True)
+            field = [("ngp_x_mlp_forward_step_begin", lambda: self._mlp_forward(cap, ar.dirs, ar.ldirs, ar.counter, cap, self.sigma,
+                                                                               self.rgb, step_begin=sb))
+                     if o[0] == "ngp_x_mlp_forward" else o for o in field]
+        else:
+            field.insert(1, begin)                                                  # right after the encoder's forward
         if self.pose:
             # the level window of THIS step and whether the cameras still move (annealing < end_annealing), from the step
             # counter before step_begin advances it
