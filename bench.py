@@ -179,6 +179,11 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     _lib.set_probe(None if (args.no_probe or not probe_on) else probed, arg_idx, every=args.probe_every)
     trainer.train(args.burnin)
     trainer.train(args.warmup)
+    if fused and args.precapture:
+        # every run of up to --group-steps regular steps between two refreshes / timed steps becomes ONE graph launch; the
+        # captures (ms each) happen here, outside the timed region, and execute nothing.  Pays on long regions (200 steps:
+        # -1 %); on the driver's 20-step region the first launch of a never-launched graph costs more than it saves
+        trainer.precapture_groups()
 
     # ---- timed region -------------------------------------------------------------------------
     parallel.barrier()
@@ -274,6 +279,7 @@ def main():
     ap.add_argument("--torch-mlp", action="store_true", help="fp32 nn.Linear MLPs instead of the fused f16 MFMA field")
     ap.add_argument("--group-steps", type=int, default=8,
                     help="fused step: consecutive steps per captured graph (1 = one graph launch per step)")
+    ap.add_argument("--precapture", action="store_true", help="capture step groups of every length up front instead of 2/4/8 on demand")
     ap.add_argument("--probe-every", type=int, default=8,
                     help="time every N-th launch of the roofline entry point with HIP events (each timed launch drains the queue)")
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event roofline probe (roofline: null)")

@@ -263,6 +263,7 @@ class FusedTrainer:
             slot.ws_grid = torch.empty(gb.backward_workspace_bytes(cap, self.L, self.rows), dtype=torch.uint8, device=dev)
         self._image_ready = False                      # the step path expects the f16 weight image of the current weights
         self.global_step = 0
+        self._groups_precaptured = False
         self.samples_seen = torch.zeros(1, dtype=torch.int64, device=dev)     # running total, never read per step
         self.ray_gen = torch.Generator(device=dev).manual_seed(seed * 1000 + self.rank)   # torch sampling path
         self.last_loss = None
@@ -797,32 +798,19 @@ class FusedTrainer:
         if not (self.use_graph and self.prefetch and self.device_sampler and self.march_mode != "index" and not self.dp
                 and s >= 2 and s % every != 0 and self._image_ready):
             return 0
-        G = min(limit, every - s % every, int(getattr(opt, "group_steps", 8)), _lib.probe_untimed_run())
+        G = min(limit, every - s % every, _lib.probe_untimed_run())
         slot = self.slots[s % 2]
         if G < 2 or slot.step != s:
             return 0
-        G = 1 << (G.bit_length() - 1)              # 2, 4, 8: a handful of graph variants, all captured early in a run
-                                                   # (a capture takes milliseconds: none may fall into a timed region)
+        # (longer groups save launch boundaries, but a graph launch costs host time in proportion to its nodes, which is
+        # exposed whenever the GPU has nothing queued -- e.g. at the start of a short timed region)
+        G = min(G, int(getattr(opt, "group_steps", 8)))
+        if not self._groups_precaptured:           # 2, 4, 8: a handful of graph variants, all captured early in a run
+            G = 1 << (G.bit_length() - 1)          # (a capture takes milliseconds: none may fall into a timed region)
         last_ahead = (s + G) % every != 0          # does the group's last step draw the rays of the step after it?
         key = ("multi", s % 2, G, last_ahead)
         if key not in self.graphs:
-            if self.graph_pool is None:
-                self.graph_pool = torch.cuda.graph_pool_handle()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
-                main = torch.cuda.current_stream(self.device)
-                for k in range(G):
-                    cur = self.slots[(s + k) % 2]
-                    nxt = self.slots[(s + k + 1) % 2] if (k + 1 < G or last_ahead) else None
-                    if nxt is not None:         # fork: the next step's rays, on the side stream
-                        self.side.wait_stream(main)
-                        with torch.cuda.stream(self.side):
-                            self._load_slot(nxt)
-                    self._run_ops(self._step_ops(cur), fork=bool(getattr(opt, "aux_stream", False)))
-                    if nxt is not None:
-                        main.wait_stream(self.side)     # join
-            self._graphs_alive.append(g)
-            self.graphs[key] = [g.replay]
+            self._capture_group(s % 2, G, last_ahead)
         for part in self.graphs[key]:           # (capturing does not execute anything)
             part()
         probed = [n for n in _lib.probed_symbols() if n in self._main_symbols]
@@ -836,6 +824,45 @@ class FusedTrainer:
         self.last_loss = self.loss
         self.last_graph_key = key
         return G
+
+    def _capture_group(self, parity, G, last_ahead):
+        """G consecutive regular steps (the first one on slot `parity`) as one hipGraph; nothing is executed."""
+        if self.graph_pool is None:
+            self.graph_pool = torch.cuda.graph_pool_handle()
+        opt = self.opt
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
+            main = torch.cuda.current_stream(self.device)
+            for k in range(G):
+                cur = self.slots[(parity + k) % 2]
+                nxt = self.slots[(parity + k + 1) % 2] if (k + 1 < G or last_ahead) else None
+                if nxt is not None:         # fork: the next step's rays, on the side stream
+                    self.side.wait_stream(main)
+                    with torch.cuda.stream(self.side):
+                        self._load_slot(nxt)
+                self._run_ops(self._step_ops(cur), fork=bool(getattr(opt, "aux_stream", False)))
+                if nxt is not None:
+                    main.wait_stream(self.side)     # join
+        self._graphs_alive.append(g)
+        self.graphs[("multi", parity, G, last_ahead)] = [g.replay]
+
+    def precapture_groups(self):
+        """Capture the step groups of every length (2 .. update_extra_interval - 1, both slot parities, with and without
+        the trailing prefetch) now, so that any run of regular steps between two density-grid refreshes -- or between two
+        steps bench.py times -- is ONE graph launch and no capture (milliseconds) falls into a timed region.  Call after
+        the first few steps (lazy initialisation done); nothing is executed.  Returns the number of graphs captured."""
+        if not (self.use_graph and self.prefetch and self.device_sampler and self.march_mode != "index" and not self.dp
+                and self.global_step >= 2 and self._image_ready):
+            return 0
+        n = 0
+        for parity in (0, 1):
+            for G in range(2, min(self.opt.update_extra_interval - 1, int(getattr(self.opt, "group_steps", 8))) + 1):
+                for last_ahead in (True, False):
+                    if ("multi", parity, G, last_ahead) not in self.graphs:
+                        self._capture_group(parity, G, last_ahead)
+                        n += 1
+        self._groups_precaptured = True
+        return n
 
     def train(self, steps, log_every=0):
         done = 0

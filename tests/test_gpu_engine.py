@@ -450,6 +450,35 @@ def test_fused_training_is_bitwise_reproducible(lib):
     assert torch.equal(out[0][0], out[1][0])
 
 
+def test_step_groups_of_any_length_train_the_same_bits(lib):
+    """train() replays consecutive regular steps from multi-step graphs: groups of 2 / 4 / 8 captured on demand, or, after
+    precapture_groups(), of any length.  Either way the parameters after 40 steps are the bits of 40 single steps."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    out = []
+    for mode in ("single", "groups", "precaptured"):
+        torch.manual_seed(0)
+        opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True, group_steps=15)
+        data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
+        eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
+        if mode == "single":
+            for _ in range(40):
+                eng.train_step()
+        else:
+            eng.train(4)
+            if mode == "precaptured":
+                assert eng.precapture_groups() > 0
+            eng.train(36)
+        torch.cuda.synchronize()
+        assert eng.global_step == 40
+        out.append((eng.table.clone(), eng.w_flat.clone(), int(eng.samples_seen)))
+    for other in out[1:]:
+        assert other[2] == out[0][2]
+        assert torch.equal(other[1], out[0][1]) and torch.equal(other[0], out[0][0])
+
+
 def test_bf16_wire_gradient_store_and_adam(lib, orc):
     """Data-parallel wire format: the overwrite-mode reduction can store the table gradient as bfloat16 (round to
     nearest even == torch's conversion of the f32 result, bit for bit), and Adam reads it as if it were widened."""
