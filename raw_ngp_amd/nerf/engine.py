@@ -435,7 +435,8 @@ class FusedTrainer:
         n_uni, n_occ = (cells, 0) if full else (cells // 4, cells // 4)
         total = n_uni + n_occ
         offsets = m.grid_encoder.offsets
-        self._mlp_prepare()
+        if not (self.fuse_adam and self._image_ready):     # (the fused step keeps the f16 operand image in step with the weights)
+            self._mlp_prepare()
         for cas in range(m.cascade):
             bound = min(2 ** cas, m.bound)
             half = bound / H
