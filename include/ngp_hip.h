@@ -174,6 +174,19 @@ int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const
  * (far - near) / dt_min + 1 candidate parameters per ray (max_steps * ceil(bound) + 2 always does).  counter then
  * needs 4 ints: counter[2] becomes non-zero (and stays so) if a ray's chain did not fit. */
 
+/* The same march in two halves (chain-parallel variant only, chain != NULL).  stage 0: everything (= the call above);
+ * 1: the first kernel alone -- every ray's candidate parameters, from rays, near/far and noise: it does not read the
+ * occupancy grid; 2: everything after it.  A caller whose grid is still being rebuilt (density-grid refresh) can run stage 1
+ * early and stage 2 once the grid is final; together they are stage 0 bit for bit. */
+int ngp_x_march_rays_train_arena_stage(const float *rays_o, const float *rays_d, const float *rays_ldir,
+                                       const uint8_t *grid, float bound, int contract, float dt_gamma,
+                                       uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                       const float *nears, const float *fars, const float *noises,
+                                       float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
+                                       float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
+                                       const uint32_t *occ_index, float *chain, uint16_t *chain_code, int32_t *chain_len,
+                                       uint32_t chain_cap, int stage, ngp_stream_t stream);
+
 /* Compressed copy of the occupancy bitfield that the arena march can keep in LDS (occ_index above; NULL = probe
  * the bitfield in global memory).  The bitfield is Morton-ordered (raymarching.cu:56-81), so 64 consecutive bits
  * are one 4x4x4 block; the index stores which blocks are non-zero plus the non-zero blocks themselves.  Rebuild it

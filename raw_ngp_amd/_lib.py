@@ -89,6 +89,8 @@ _SIGNATURES = {
     "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_march_rays_train_arena": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _u, _p, _p, _p,
                                      _p, _p, _p, _p, _p, _p, _p, _p, _u],
+    "ngp_x_march_rays_train_arena_stage": [_p, _p, _p, _p, _f, _i, _f, _u, _u, _u, _u, _p, _p, _p, _p, _u, _p, _p, _p,
+                                     _p, _p, _p, _p, _p, _p, _p, _p, _u, _i],
     "ngp_x_build_occupancy_index": [_p, _u, _u, _p],
     "ngp_x_density_grid_sample": [_p, _u, _f, _f, _u, _u, _i, ctypes.c_uint64, _p, _u, _p, ctypes.c_size_t, _p, _p],
     "ngp_x_density_grid_scatter": [_p, _p, _u, _p],
@@ -501,16 +503,18 @@ class _RayBackend:
     @staticmethod
     def march_rays_train_arena(rays_o, rays_d, rays_ldir, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears,
                                fars, noises, t_scratch, M_cap, xyzs, dirs, ts, ldirs, rays, counter, ray_idx,
-                               occ_index=None, chain=None):
+                               occ_index=None, chain=None, stage=0):
         """chain: (chain f32 [chain_cap, N], code int16 [chain_cap, N], len int32 [N]) scratch of the chain-parallel
-        first pass, or None for the serial one."""
+        first pass, or None for the serial one.  stage 1 / 2 (chain variant): the grid-independent first kernel alone /
+        everything after it."""
         ch, code, clen = chain if chain is not None else (None, None, None)
         if chain is not None and (ch.shape[0] != code.shape[0] or ch.shape[1] < N or code.shape[1] != ch.shape[1]
                                   or clen.numel() < N or code.dtype != torch.int16 or counter.numel() < 3):
             raise RuntimeError("march_rays_train_arena: malformed chain buffers")
         if chain is not None and ch.shape[1] != N:
             raise RuntimeError("march_rays_train_arena: chain buffers must be laid out for exactly N rays")
-        _call("ngp_x_march_rays_train_arena", rays_o, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
+        _call("ngp_x_march_rays_train_arena_stage" if stage else "ngp_x_march_rays_train_arena", rays_o,
+              _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
               _ptr(rays_ldir, "f", "rays_ldir", True), _ptr(grid, "b", "grid"), float(bound), int(bool(contract)),
               float(dt_gamma), max_steps, N, C, H, _ptr(nears, "f", "nears"), _ptr(fars, "f", "fars"),
               _ptr(noises, "f", "noises"), _ptr(t_scratch, "f", "t_scratch"), M_cap, _ptr(xyzs, "f", "xyzs"),
@@ -518,7 +522,7 @@ class _RayBackend:
               _ptr(rays, "i", "rays"), _ptr(counter, "i", "counter"), _ptr(ray_idx, "i", "ray_idx", True),
               _ptr(occ_index, "i", "occ_index", True), _ptr(ch, "f", "chain", True),
               code.data_ptr() if code is not None else None, _ptr(clen, "i", "chain_len", True),
-              ch.shape[0] if ch is not None else 0)
+              ch.shape[0] if ch is not None else 0, *((int(stage),) if stage else ()))
 
     @staticmethod
     def occupancy_index_bytes(C, H):

@@ -921,16 +921,20 @@ extern "C" int ngp_march_rays_train(const float *rays_o, const float *rays_d, co
     return NGP_OK;
 }
 
-extern "C" int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const float *rays_ldir,
-                                            const uint8_t *grid, float bound, int contract, float dt_gamma,
-                                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
-                                            const float *nears, const float *fars, const float *noises,
-                                            float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
-                                            float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
-                                            const uint32_t *occ_index, float *chain, uint16_t *chain_code,
-                                            int32_t *chain_len, uint32_t chain_cap, ngp_stream_t stream)
+// stage 0: the whole march.  Chain-parallel variant only: 1 = its first kernel alone (the candidate parameters of every
+// ray: reads rays, near/far and noise, not the occupancy grid), 2 = everything after it -- so that a caller whose grid is
+// still being rebuilt can get the grid-independent third of the march out of the way
+extern "C" int ngp_x_march_rays_train_arena_stage(const float *rays_o, const float *rays_d, const float *rays_ldir,
+                                                  const uint8_t *grid, float bound, int contract, float dt_gamma,
+                                                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                  const float *nears, const float *fars, const float *noises,
+                                                  float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
+                                                  float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
+                                                  const uint32_t *occ_index, float *chain, uint16_t *chain_code,
+                                                  int32_t *chain_len, uint32_t chain_cap, int stage, ngp_stream_t stream)
 {
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(stage >= 0 && stage <= 2 && (stage == 0 || chain), "march_rays_train_arena: stages 1 / 2 need the chain buffers");
     NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && t_scratch && xyzs && dirs && ts,
                 "march_rays_train_arena: null tensor");
     NGP_REQUIRE(max_steps > 0 && H > 0 && C > 0 && M_cap > 0, "march_rays_train_arena: bad sizes");
@@ -939,8 +943,13 @@ extern "C" int ngp_x_march_rays_train_arena(const float *rays_o, const float *ra
         NGP_REQUIRE(chain_code && chain_len && chain_cap > 0 && chain_cap < 65536u,
                     "march_rays_train_arena: chain buffers incomplete (chain_cap must be in 1..65535)");
         const float dt_min = 2.0f * kSqrt3 / (float)max_steps, dt_max = 2.0f * kSqrt3 * bound / (float)H;
-        march_chain_kernel<<<NGP_1D(N, kRayBlock)>>>(nears, fars, noises, dt_gamma, dt_min, dt_max, N, chain_cap, chain,
-                                                    chain_len, counter);
+        if (stage != 2)
+            march_chain_kernel<<<NGP_1D(N, kRayBlock)>>>(nears, fars, noises, dt_gamma, dt_min, dt_max, N, chain_cap, chain,
+                                                        chain_len, counter);
+        if (stage == 1) {
+            NGP_CHECK_LAUNCH("march_rays_train_arena");
+            return NGP_OK;
+        }
         march_classify_kernel<<<dim3(ceil_div(N, 256u), chain_cap), dim3(256), 0, as_stream(stream)>>>(
             rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, chain, chain_len, chain_code);
         march_walk_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(chain, chain_len, chain_code, N,
@@ -974,6 +983,20 @@ extern "C" int ngp_x_march_rays_train_arena(const float *rays_o, const float *ra
         rays_ldir ? ldirs : nullptr, ray_idx);
     NGP_CHECK_LAUNCH("march_rays_train_arena");
     return NGP_OK;
+}
+
+extern "C" int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const float *rays_ldir,
+                                            const uint8_t *grid, float bound, int contract, float dt_gamma,
+                                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                            const float *nears, const float *fars, const float *noises,
+                                            float *t_scratch, uint32_t M_cap, float *xyzs, float *dirs, float *ts,
+                                            float *ldirs, int32_t *rays, int32_t *counter, int32_t *ray_idx,
+                                            const uint32_t *occ_index, float *chain, uint16_t *chain_code,
+                                            int32_t *chain_len, uint32_t chain_cap, ngp_stream_t stream)
+{
+    return ngp_x_march_rays_train_arena_stage(rays_o, rays_d, rays_ldir, grid, bound, contract, dt_gamma, max_steps, N, C, H,
+                                              nears, fars, noises, t_scratch, M_cap, xyzs, dirs, ts, ldirs, rays, counter,
+                                              ray_idx, occ_index, chain, chain_code, chain_len, chain_cap, 0, stream);
 }
 
 extern "C" size_t ngp_x_occupancy_index_bytes(uint32_t C, uint32_t H)

@@ -48,6 +48,7 @@ class _Slot:
         self.noises = torch.empty(N, **f32)
         self.nears, self.fars = torch.empty(N, **f32), torch.empty(N, **f32)
         self.step = -1                     # training step whose rays the slot holds
+        self.head_step = -1                # ... or whose rays are drawn and half marched (in front of a grid refresh)
 
 
 class FusedTrainer:
@@ -264,6 +265,10 @@ class FusedTrainer:
         self._image_ready = False                      # the step path expects the f16 weight image of the current weights
         self.global_step = 0
         self._groups_precaptured = False
+        # the march's first kernel does not read the occupancy bitfield: in front of a density-grid refresh the next batch
+        # can still be drawn and that kernel run (chain-parallel march only)
+        self._split_march = self.prefetch and self.slots[0].arena.chain is not None and \
+            os.environ.get("NGP_SPLIT_MARCH", "1") != "0"
         self.samples_seen = torch.zeros(1, dtype=torch.int64, device=dev)     # running total, never read per step
         self.ray_gen = torch.Generator(device=dev).manual_seed(seed * 1000 + self.rank)   # torch sampling path
         self.last_loss = None
@@ -292,20 +297,23 @@ class FusedTrainer:
         else:
             self.mb.forward(self.enc, stride, dirs, cnt, M, self.mlp_image, sigma, rgb, step_begin=step_begin)
 
-    def march(self, slot, rays_o, rays_d, noises, aabb=None, plan=True):
-        """rays -> sample arena of `slot` (near/far, count, scan, expand); runs on the current stream."""
+    def march(self, slot, rays_o, rays_d, noises, aabb=None, plan=True, stage=0):
+        """rays -> sample arena of `slot` (near/far, count, scan, expand); runs on the current stream.
+        stage 1: only what does not read the occupancy bitfield (near/far, the chain kernel); 2: the rest."""
         opt, m, ar, N = self.opt, self.model, slot.arena, self.N
-        version = getattr(m, "bitfield_version", 0)
-        if self.occ_index is not None and version != self._occ_version:      # the bitfield was re-packed
-            rb.build_occupancy_index(m.density_bitfield, m.cascade, m.grid_size, self.occ_index)
-            self._occ_version = version
-        eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train if aabb is None else aabb, N, m.min_near, slot.nears,
-                                 slot.fars)
+        if stage != 1:
+            version = getattr(m, "bitfield_version", 0)
+            if self.occ_index is not None and version != self._occ_version:      # the bitfield was re-packed
+                rb.build_occupancy_index(m.density_bitfield, m.cascade, m.grid_size, self.occ_index)
+                self._occ_version = version
+        if stage != 2:
+            eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train if aabb is None else aabb, N, m.min_near, slot.nears,
+                                     slot.fars)
         rb.march_rays_train_arena(rays_o, rays_d, slot.rays_ldir, m.density_bitfield, m.real_bound, opt.contract,
                                   opt.dt_gamma, opt.max_steps, N, m.cascade, m.grid_size, slot.nears, slot.fars, noises,
                                   ar.t_scratch, self.cap, ar.xyzs, ar.dirs, ar.ts, ar.ldirs, ar.rays, ar.counter, None,
-                                  self.occ_index, ar.chain)
-        if not plan:
+                                  self.occ_index, ar.chain, stage=stage)
+        if not plan or stage == 1:
             return
         # reset the bookkeeping of the binned table backward for this batch (stage 1: plan); the encoder's forward
         # pass counts the records per chunk while it has the rows in registers, a scan (stage 2) follows it
@@ -533,9 +541,14 @@ class FusedTrainer:
         eb.adam_step(self.w_flat, self.w_grad, self.w_m, self.w_v, lr, *self.betas, self.eps, step, zero_grad=False)
 
     # ------------------------------------------------------------------ one optimiser step
-    def _load_slot(self, slot, batch=None, noises=None):
-        """Draw (or take) a ray batch into the slot's fixed buffers and march it, on the current stream."""
+    def _load_slot(self, slot, batch=None, noises=None, stage=0):
+        """Draw (or take) a ray batch into the slot's fixed buffers and march it, on the current stream.
+        stage 1: the part that does not read the occupancy bitfield (draw the rays, near/far, the march's chain kernel) --
+        what a step in front of a density-grid refresh can still do for the next batch; 2: the rest of the march."""
         opt = self.opt
+        if stage == 2:
+            self.march(slot, slot.rays_o, slot.rays_d, slot.noises, stage=2)
+            return
         if batch is None and self.device_sampler:
             d = self.data
             # pose refinement: rays are cast from the refined cameras (the dataset's pose_fn hook, provider.py:298-300)
@@ -563,7 +576,7 @@ class FusedTrainer:
                 torch.rand(slot.noises.shape, out=slot.noises, generator=self.ray_gen)
             else:
                 slot.noises.copy_(noises)
-        self.march(slot, slot.rays_o, slot.rays_d, slot.noises)
+        self.march(slot, slot.rays_o, slot.rays_d, slot.noises, stage=stage)
 
     def _step_ops(self, slot):
         """Everything one step does after the rays are marched, as (name, thunk, lane) triples.  Lane "aux" marks the
@@ -684,13 +697,13 @@ class FusedTrainer:
         self._graphs_alive.append(g)
         return [g.replay]
 
-    def _load_slot_fast(self, slot):
+    def _load_slot_fast(self, slot, stage=0):
         """_load_slot (device sampler + march + binning reset) replayed from a graph: 9 launches -> 1."""
         if not (self.use_graph and self.device_sampler and self.global_step >= 2 and self.march_mode != "index"):
-            return self._load_slot(slot)
-        key = ("load", id(slot))
+            return self._load_slot(slot, stage=stage)
+        key = ("load", id(slot), stage)
         if key not in self.graphs:
-            self.graphs[key] = self._capture_ops([lambda: self._load_slot(slot)])
+            self.graphs[key] = self._capture_ops([lambda: self._load_slot(slot, stage=stage)])
         for part in self.graphs[key]:
             part()
 
@@ -748,19 +761,26 @@ class FusedTrainer:
             self._load_slot(slot, batch, noises)
             slot.step = step
         elif slot.step != step:                         # first step, or just after a grid refresh
-            self._load_slot_fast(slot)
+            # (after a refresh: the previous step has already drawn this batch and run the part of its march that does
+            # not read the bitfield)
+            self._load_slot_fast(slot, stage=2 if slot.head_step == step else 0)
             slot.step = step
         # the occupancy bitfield the next step marches through is final unless that step refreshes it first
         ahead = self.prefetch and batch is None and (step + 1) % opt.update_extra_interval != 0
-        nxt = self.slots[(step + 1) % 2] if ahead else None
+        head = self.prefetch and batch is None and not ahead and self._split_march
+        nxt = self.slots[(step + 1) % 2] if (ahead or head) else None
         main = torch.cuda.current_stream(self.device) if self.prefetch else None
         if nxt is not None:
             # fork: the next step's rays are drawn and marched on the side stream, concurrently with everything
-            # this step does on the main stream (nxt's previous user, step - 1, is already behind this point)
+            # this step does on the main stream (nxt's previous user, step - 1, is already behind this point).  In front
+            # of a refresh: only what does not depend on the bitfield (a third of the march)
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
-                self._load_slot_fast(nxt)
-            nxt.step = step + 1
+                self._load_slot_fast(nxt, stage=0 if ahead else 1)
+            if ahead:
+                nxt.step = step + 1
+            else:
+                nxt.head_step = step + 1
         if self.use_graph and batch is None and step >= 2:      # the first steps run eagerly (lazy init, caches)
             from .. import _lib
             probed = [n for n in _lib.probed_symbols() if n in self._main_symbols]
@@ -819,6 +839,8 @@ class FusedTrainer:
             nxt_step = s + k + 1
             if k + 1 < G or last_ahead:
                 self.slots[nxt_step % 2].step = nxt_step
+            elif self._split_march:
+                self.slots[nxt_step % 2].head_step = nxt_step
             if probed:
                 _lib.probe_skip(probed)
         self.global_step += G
@@ -836,11 +858,12 @@ class FusedTrainer:
             main = torch.cuda.current_stream(self.device)
             for k in range(G):
                 cur = self.slots[(parity + k) % 2]
-                nxt = self.slots[(parity + k + 1) % 2] if (k + 1 < G or last_ahead) else None
+                whole = k + 1 < G or last_ahead         # (else a refresh follows: only the bitfield-independent part)
+                nxt = self.slots[(parity + k + 1) % 2] if (whole or self._split_march) else None
                 if nxt is not None:         # fork: the next step's rays, on the side stream
                     self.side.wait_stream(main)
                     with torch.cuda.stream(self.side):
-                        self._load_slot(nxt)
+                        self._load_slot(nxt, stage=0 if whole else 1)
                 self._run_ops(self._step_ops(cur), fork=bool(getattr(opt, "aux_stream", False)))
                 if nxt is not None:
                     main.wait_stream(self.side)     # join

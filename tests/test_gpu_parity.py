@@ -357,6 +357,42 @@ def test_march_rays_train_arena(be, orc, case, mode):
             assert np.array_equal(host(ar.ldirs)[:w], rl[:w])
 
 
+def test_march_arena_in_two_stages(be, orc):
+    """The chain-parallel march split where the occupancy grid first matters: stage 1 (candidate parameters: rays, near/far,
+    noise) with a bitfield that is still garbage, stage 2 with the real one == the one-call march, bit for bit; and the
+    stages refuse to run without chain buffers."""
+    case = MARCH_CASES[0]
+    N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
+    bits, o, d, ld, nears, fars, noises = march_inputs(orc, case, seed=3)
+    chain_cap = max_steps * int(np.ceil(bound)) + 2
+    from raw_ngp_amd.raymarching import MarchArena
+    rb = be.raymarching_backend
+    res = []
+    for staged in (False, True):
+        ar = MarchArena(N, max_steps, 1 << 18, "cuda", with_ldirs=ldir, chain_cap=chain_cap)
+
+        def run(grid, stage):
+            rb.march_rays_train_arena(dev(o), dev(d), dev(ld) if ldir else None, grid, bound, contract, dt_gamma, max_steps, N,
+                                      C, H, dev(nears), dev(fars), dev(noises), ar.t_scratch, 1 << 18, ar.xyzs, ar.dirs,
+                                      ar.ts, ar.ldirs, ar.rays, ar.counter, ar.ray_idx, None, ar.chain, stage=stage)
+        if staged:
+            run(torch.full_like(dev(bits), 0xA5), 1)
+            run(dev(bits), 2)
+        else:
+            run(dev(bits), 0)
+        w = int(host(ar.counter)[0])
+        res.append((host(ar.counter)[:3].copy(), host(ar.rays).copy(), host(ar.xyzs)[:w].copy(), host(ar.ts)[:w].copy(),
+                    host(ar.dirs)[:w].copy()))
+    assert res[0][0][0] > 0
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    ar = MarchArena(N, max_steps, 1 << 18, "cuda", with_ldirs=ldir, chain_cap=0)
+    with pytest.raises(RuntimeError):
+        rb.march_rays_train_arena(dev(o), dev(d), None, dev(bits), bound, contract, dt_gamma, max_steps, N, C, H, dev(nears),
+                                  dev(fars), dev(noises), ar.t_scratch, 1 << 18, ar.xyzs, ar.dirs, ar.ts, ar.ldirs, ar.rays,
+                                  ar.counter, ar.ray_idx, None, None, stage=1)
+
+
 def test_march_arena_index_too_big_for_lds_falls_back_to_bitfield(be, orc):
     """Dense random bitfield: every 4x4x4 block is non-zero (32768 blocks > LDS budget) -> global probes, same result."""
     case = (2000, 128, 1024, 1, 1.0, False, 0.0, False)
