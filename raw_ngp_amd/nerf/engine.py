@@ -168,7 +168,8 @@ class FusedTrainer:
         self.fuse_adam = bool(getattr(opt, "fuse_adam", True)) and not self.dp and opt.lambda_tv == 0 \
             and opt.lambda_wd == 0
         self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
-        self._refresh_graph = None
+        self._refresh_graph = {}                       # steady-state refresh as graphs: 0 whole, 1 cell draw, 2 the rest
+        self._refresh_head_step = -1                   # step whose refresh already has its cells drawn
         self._eval_slot = None
         # 16-bit wire format of the table gradient under data parallelism: the reduce kernel stores bfloat16, RCCL
         # averages it in place, Adam reads it -- no conversion passes, half the bytes on xGMI
@@ -427,30 +428,50 @@ class FusedTrainer:
         the bitfield with thresh = min(mean, density_thresh)."""
         m = self.model
         full = m.iter_density < 16
+        # (the cells may have been drawn already, on the side stream of the step in front of this one: refresh_head)
+        part = 2 if self._refresh_head_step == self.global_step and not full else 0
         if self.use_graph and not full:             # the steady-state variant has fixed launch arguments: replay it
-            if self._refresh_graph is None:
-                self._refresh_graph = self._capture_ops([lambda: self._refresh_launches(decay, False)])
-            for part in self._refresh_graph:
-                part()
+            if self._refresh_graph.get(part) is None:
+                self._refresh_graph[part] = self._capture_ops([lambda: self._refresh_launches(decay, False, part)])
+            for piece in self._refresh_graph[part]:
+                piece()
         else:
             self._refresh_launches(decay, full)
         m.iter_density += 1
         m.bitfield_version = getattr(m, "bitfield_version", 0) + 1
 
-    def _refresh_launches(self, decay, full):
+    def _refresh_head_ok(self):
+        """May the cell draw of the next refresh (a third kernel chain that reads the density grid but no weights) run
+        ahead, beside the step in front of it?  Steady state, one cascade (the draws of several share their buffers)."""
+        m = self.model
+        return bool(self._split_march and self.native_refresh and self.use_graph and m.cascade == 1 and m.iter_density >= 16)
+
+    def refresh_head(self, for_step):
+        """The weight-independent head of the refresh that step `for_step` will do: draw the cells (current stream)."""
+        if self._refresh_graph.get(1) is None:
+            self._refresh_graph[1] = self._capture_ops([lambda: self._refresh_launches(0.95, False, 1)])
+        for piece in self._refresh_graph[1]:
+            piece()
+        self._refresh_head_step = for_step
+
+    def _refresh_launches(self, decay, full, part=0):
+        """part 1: only the cell draw (one cascade); part 2: everything after it; 0: all."""
         m, cap = self.model, self.cap
         H, cells = m.grid_size, m.grid_size ** 3
         n_uni, n_occ = (cells, 0) if full else (cells // 4, cells // 4)
         total = n_uni + n_occ
         offsets = m.grid_encoder.offsets
-        if not (self.fuse_adam and self._image_ready):     # (the fused step keeps the f16 operand image in step with the weights)
+        if part != 1 and not (self.fuse_adam and self._image_ready):     # (the fused step keeps the f16 operand image current)
             self._mlp_prepare()
         for cas in range(m.cascade):
             bound = min(2 ** cas, m.bound)
             half = bound / H
-            eb.density_grid_sample(m.density_grid[cas], H, bound - half, half, n_uni, n_occ, full, self.dg_seed,
-                                   self.dg_draw, self.dg_ws, self.dg_indices[:total], self.dg_xyzs[:total])
-            eb.counter_add(self.dg_draw, 1)
+            if part != 2:
+                eb.density_grid_sample(m.density_grid[cas], H, bound - half, half, n_uni, n_occ, full, self.dg_seed,
+                                       self.dg_draw, self.dg_ws, self.dg_indices[:total], self.dg_xyzs[:total])
+                eb.counter_add(self.dg_draw, 1)
+            if part == 1:
+                return
             for s in range(0, total, cap):
                 k = min(cap, total - s)
                 eb.grid_encode_forward_slab(self.dg_xyzs[s:s + k], m.bound, self.table, offsets, self.enc, None, None, k,
@@ -777,6 +798,8 @@ class FusedTrainer:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 self._load_slot_fast(nxt, stage=0 if ahead else 1)
+                if not ahead and self._refresh_head_ok():
+                    self.refresh_head(step + 1)
             if ahead:
                 nxt.step = step + 1
             else:
@@ -829,9 +852,10 @@ class FusedTrainer:
         if not self._groups_precaptured:           # 2, 4, 8: a handful of graph variants, all captured early in a run
             G = 1 << (G.bit_length() - 1)          # (a capture takes milliseconds: none may fall into a timed region)
         last_ahead = (s + G) % every != 0          # does the group's last step draw the rays of the step after it?
-        key = ("multi", s % 2, G, last_ahead)
+        head = not last_ahead and self._refresh_head_ok()      # ... or the cells of the refresh that follows it?
+        key = ("multi", s % 2, G, last_ahead, head)
         if key not in self.graphs:
-            self._capture_group(s % 2, G, last_ahead)
+            self._capture_group(s % 2, G, last_ahead, head)
         for part in self.graphs[key]:           # (capturing does not execute anything)
             part()
         probed = [n for n in _lib.probed_symbols() if n in self._main_symbols]
@@ -841,6 +865,8 @@ class FusedTrainer:
                 self.slots[nxt_step % 2].step = nxt_step
             elif self._split_march:
                 self.slots[nxt_step % 2].head_step = nxt_step
+                if head:
+                    self._refresh_head_step = nxt_step
             if probed:
                 _lib.probe_skip(probed)
         self.global_step += G
@@ -848,7 +874,7 @@ class FusedTrainer:
         self.last_graph_key = key
         return G
 
-    def _capture_group(self, parity, G, last_ahead):
+    def _capture_group(self, parity, G, last_ahead, head=False):
         """G consecutive regular steps (the first one on slot `parity`) as one hipGraph; nothing is executed."""
         if self.graph_pool is None:
             self.graph_pool = torch.cuda.graph_pool_handle()
@@ -864,11 +890,13 @@ class FusedTrainer:
                     self.side.wait_stream(main)
                     with torch.cuda.stream(self.side):
                         self._load_slot(nxt, stage=0 if whole else 1)
+                        if not whole and head:
+                            self._refresh_launches(0.95, False, 1)
                 self._run_ops(self._step_ops(cur), fork=bool(getattr(opt, "aux_stream", False)))
                 if nxt is not None:
                     main.wait_stream(self.side)     # join
         self._graphs_alive.append(g)
-        self.graphs[("multi", parity, G, last_ahead)] = [g.replay]
+        self.graphs[("multi", parity, G, last_ahead, head)] = [g.replay]
 
     def precapture_groups(self):
         """Capture the step groups of every length (2 .. update_extra_interval - 1, both slot parities, with and without
@@ -882,8 +910,9 @@ class FusedTrainer:
         for parity in (0, 1):
             for G in range(2, min(self.opt.update_extra_interval - 1, int(getattr(self.opt, "group_steps", 8))) + 1):
                 for last_ahead in (True, False):
-                    if ("multi", parity, G, last_ahead) not in self.graphs:
-                        self._capture_group(parity, G, last_ahead)
+                    head = not last_ahead and self._refresh_head_ok()
+                    if ("multi", parity, G, last_ahead, head) not in self.graphs:
+                        self._capture_group(parity, G, last_ahead, head)
                         n += 1
         self._groups_precaptured = True
         return n

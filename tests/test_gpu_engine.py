@@ -479,6 +479,31 @@ def test_step_groups_of_any_length_train_the_same_bits(lib):
         assert torch.equal(other[1], out[0][1]) and torch.equal(other[0], out[0][0])
 
 
+def test_work_done_ahead_of_a_grid_refresh_trains_the_same_bits(lib, monkeypatch):
+    """In front of a density-grid refresh the side stream draws the next batch, runs the grid-independent part of its march
+    and draws the refresh's cells (steady state).  None of it may change a bit of the result."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    out = []
+    for ahead in ("0", "1"):
+        monkeypatch.setenv("NGP_SPLIT_MARCH", ahead)
+        torch.manual_seed(0)
+        opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True, update_extra_interval=4)
+        data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
+        eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
+        eng.train(60)                   # 15 refreshes, then steady state
+        eng.train(41)                   # groups of 3 between refreshes, one refresh step in between each
+        for _ in range(9):
+            eng.train_step()            # and the single-step path
+        torch.cuda.synchronize()
+        assert (eng._refresh_head_step > 100) == (ahead == "1")
+        out.append((eng.table.clone(), eng.w_flat.clone(), eng.model.density_bitfield.clone(), int(eng.samples_seen)))
+    assert out[0][3] == out[1][3]
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
+
+
 def test_bf16_wire_gradient_store_and_adam(lib, orc):
     """Data-parallel wire format: the overwrite-mode reduction can store the table gradient as bfloat16 (round to
     nearest even == torch's conversion of the f32 result, bit for bit), and Adam reads it as if it were widened."""
