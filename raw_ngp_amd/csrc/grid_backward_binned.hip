@@ -409,8 +409,13 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
             const uint32_t i = threadIdx.x + j * kReduceBlock;
             if (i < rows_here) {
                 pp[j] = p2[i];
-                mm[j] = m2[i];
-                vv[j] = v2[i];
+                // (the moments are touched once per step, here: streamed past the caches, so that the 98 MB of them do not
+                // evict the table the next forward pass gathers from -- measured -0.75 % step time)
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 tm = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(m2 + i));
+                const f2 tv = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(v2 + i));
+                mm[j] = make_float2(tm.x, tm.y);
+                vv[j] = make_float2(tv.x, tv.y);
             }
         }
     }
@@ -474,8 +479,10 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
                 vv[j].y = b2 * vv[j].y + (1.0f - b2) * gy * gy;
                 pp[j].y -= step_size * (mm[j].y / (sqrtf(vv[j].y) * rsqrt_bc2 + eps));
                 p2[i] = pp[j];
-                m2[i] = mm[j];
-                v2[i] = vv[j];
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 tm = {mm[j].x, mm[j].y}, tv = {vv[j].x, vv[j].y};
+                __builtin_nontemporal_store(tm, reinterpret_cast<f2 *>(m2 + i));
+                __builtin_nontemporal_store(tv, reinterpret_cast<f2 *>(v2 + i));
             }
         }
     } else if (MODE == 2) {
