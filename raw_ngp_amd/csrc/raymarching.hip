@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kFastBlock) void march_count_indexed_kernel(
 // SAME recurrence whether it emits a sample or skips empty space, so a ray's chain of candidate parameters does
 // not depend on the occupancy grid.  Only which elements are visited does: an occupied element is a sample and moves on
 // to the next element; an empty one jumps to the first element >= the exit of its cell.  That splits the march into
-//   chain     lane = ray: generate the chain (one add per element), stored element-major so a wave's stores coalesce
+//   chain     lane = ray: generate the chain (one add per element), stored ray-major (transposed through LDS)
 //   classify  thread = (element, ray): cell lookup + exit parameter -> code[k] = 0 for a sample, else the jump length.
 //             ~2.5 M independent probes on the whole chip instead of ~600 dependent ones on 64 waves
 //   walk      wave = ray: follow the codes through 64-element windows (runs of samples are emitted by all lanes at
@@ -410,77 +410,89 @@ __global__ __launch_bounds__(kRayBlock) void march_chain_kernel(const float *__r
                                                                float *__restrict__ chain, int32_t *__restrict__ chain_len,
                                                                int32_t *__restrict__ counter)
 {
-    const uint32_t n = blockIdx.x * kRayBlock + threadIdx.x;
-    if (n >= N) return;
-    const float far = fars[n];
-    float t = nears[n];
-    t = fmaf(clampf(t * dt_gamma, dt_min, dt_max), noises[n], t);
-    // A lone wave pays ~8 cycles per instruction, so the loop is unrolled 8x with the exit test once per group:
-    // elements past a lane's end are still stored (never read: consumers stop at chain_len) and its length is the
-    // number of elements that were < far, which is the same thing because t only grows.
-    uint32_t len = 0, k = 0;
-    float *p = chain + n;
-    const size_t stride = N;
-    while (k + 8u <= chain_cap && __any(t < far)) {
-#pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) {
-            p[(size_t)u * stride] = t;
-            len += t < far ? 1u : 0u;
-            t += clampf(t * dt_gamma, dt_min, dt_max);
+    // Layout: RAY-major, chain[ray * chain_cap + element] (as the codes below): the walk kernel reads 64 consecutive
+    // elements of ONE ray per load -- element-major that was 64 cache lines per load instruction, 4.9 M line requests per
+    // batch, as many as the encoder's forward pass issues, on the stream that runs beside the step's MLP kernels.
+    // The generator itself is one lane per ray, so a block of 64 elements x 64 rays is transposed through LDS and leaves
+    // as 256-byte rows.
+    __shared__ float tile[64][65];
+    static_assert(kRayBlock == 64, "one wave per workgroup");
+    const uint32_t lane = threadIdx.x, n0 = blockIdx.x * kRayBlock, n = n0 + lane;
+    const bool have = n < N;
+    const float far = have ? fars[n] : 0.0f;
+    float t = have ? nears[n] : 0.0f;
+    if (have) t = fmaf(clampf(t * dt_gamma, dt_min, dt_max), noises[n], t);
+    // (elements past a lane's end are still generated and stored -- never read: consumers stop at chain_len -- and its
+    // length is the number of elements that were < far, which is the same thing because t only grows)
+    uint32_t len = 0;
+    const uint32_t rows = min(64u, N - n0);
+    for (uint32_t k0 = 0; k0 < chain_cap; k0 += 64u) {
+        const unsigned long long alive = __ballot(have && t < far);   // rays whose chain reaches into this block
+        if (alive == 0ull) break;
+        const uint32_t cols = min(64u, chain_cap - k0);
+#pragma unroll 8
+        for (uint32_t e = 0; e < 64u; e++) {
+            tile[e][lane] = t;
+            const bool in = e < cols && t < far;
+            len += in ? 1u : 0u;
+            if (e < cols) t += clampf(t * dt_gamma, dt_min, dt_max);
         }
-        p += 8u * stride;
-        k += 8u;
+        __syncthreads();   // (one wave per workgroup: just the ordering of its own LDS traffic)
+        for (uint32_t r = 0; r < rows; r++)
+            if (((alive >> r) & 1ull) && lane < cols) chain[(size_t)(n0 + r) * chain_cap + k0 + lane] = tile[lane][r];
+        __syncthreads();
     }
-    while (t < far && k < chain_cap) {   // fewer than 8 slots left in the buffer
-        chain[(size_t)k * N + n] = t;
-        len++;
-        t += clampf(t * dt_gamma, dt_min, dt_max);
-        k++;
+    if (have) {
+        chain_len[n] = (int32_t)len;
+        if (t < far) atomicOr(counter + 2, 1);   // chain buffer too short: the ray was cut (reported, never silent)
     }
-    chain_len[n] = (int32_t)len;
-    if (t < far) atomicOr(counter + 2, 1);   // chain buffer too short: the ray was cut (reported, never silent)
 }
 
+// thread = (element, ray) with the ELEMENT index fastest: a workgroup works on 256 consecutive elements of one ray (its
+// origin / direction are uniform loads; chain reads, the jump search and the code stores are contiguous)
 __global__ __launch_bounds__(256) void march_classify_kernel(
     const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid, float bound,
-    bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+    bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t chain_cap,
     const float *__restrict__ chain, const int32_t *__restrict__ chain_len, uint16_t *__restrict__ code)
 {
-    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t k = blockIdx.y;
-    if (n >= N) return;
-    const uint32_t len = (uint32_t)chain_len[n];
-    if (k >= len) return;
-    Marcher m;
-    m.setup(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, false, bound, contract, dt_gamma, max_steps, C, H, grid);
-    const float t = chain[(size_t)k * N + n];
-    float dt, px, py, pz, tt;
-    const uint8_t *__restrict__ g = grid;
-    uint32_t c = 0;
-    if (!m.classify(t, dt, px, py, pz, tt, [g](uint32_t bit) { return (g[bit >> 3] >> (bit & 7u)) & 1u; })) {
-        uint32_t j = k + 1;
-        while (j < len && chain[(size_t)j * N + n] < tt) j++;
-        c = j - k;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t n = blockIdx.y; n < N; n += gridDim.y) {   // (more rays than grid rows: rare)
+        const uint32_t len = (uint32_t)chain_len[n];
+        if (k >= len) continue;
+        Marcher m;
+        m.setup(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, false, bound, contract, dt_gamma, max_steps, C, H, grid);
+        const float *__restrict__ row = chain + (size_t)n * chain_cap;
+        const float t = row[k];
+        float dt, px, py, pz, tt;
+        const uint8_t *__restrict__ g = grid;
+        uint32_t c = 0;
+        if (!m.classify(t, dt, px, py, pz, tt, [g](uint32_t bit) { return (g[bit >> 3] >> (bit & 7u)) & 1u; })) {
+            uint32_t j = k + 1;
+            while (j < len && row[j] < tt) j++;
+            c = j - k;
+        }
+        code[(size_t)n * chain_cap + k] = (uint16_t)c;
     }
-    code[(size_t)k * N + n] = (uint16_t)c;
 }
 
 __global__ __launch_bounds__(256) void march_walk_kernel(const float *__restrict__ chain,
                                                         const int32_t *__restrict__ chain_len,
-                                                        const uint16_t *__restrict__ code, uint32_t N,
+                                                        const uint16_t *__restrict__ code, uint32_t N, uint32_t chain_cap,
                                                         uint32_t max_steps, int32_t *__restrict__ rays,
                                                         float *__restrict__ t_scratch)
 {
     const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (n >= N) return;
+    chain += (size_t)n * chain_cap;   // ray-major: this ray's elements and codes are contiguous
+    code += (size_t)n * chain_cap;
     const uint32_t len = (uint32_t)chain_len[n];
     float *slab = t_scratch + (size_t)n * max_steps;
     uint32_t k = 0, step = 0;   // wave-uniform
     while (k < len && step < max_steps) {
         const uint32_t e = k + lane;
         const bool have = e < len;
-        const uint32_t c = have ? (uint32_t)code[(size_t)e * N + n] : 0xffffu;
-        const float t = have ? chain[(size_t)e * N + n] : 0.0f;
+        const uint32_t c = have ? (uint32_t)code[e] : 0xffffu;
+        const float t = have ? chain[e] : 0.0f;
         const unsigned long long samples = __ballot(have && c == 0u);
         uint32_t pos = 0;
         while (pos < 64u && k + pos < len && step < max_steps) {
@@ -950,10 +962,10 @@ extern "C" int ngp_x_march_rays_train_arena_stage(const float *rays_o, const flo
             NGP_CHECK_LAUNCH("march_rays_train_arena");
             return NGP_OK;
         }
-        march_classify_kernel<<<dim3(ceil_div(N, 256u), chain_cap), dim3(256), 0, as_stream(stream)>>>(
-            rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, chain, chain_len, chain_code);
+        march_classify_kernel<<<dim3(ceil_div(chain_cap, 256u), min(N, 65535u)), dim3(256), 0, as_stream(stream)>>>(
+            rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, chain_cap, chain, chain_len, chain_code);
         march_walk_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(chain, chain_len, chain_code, N,
-                                                                                     max_steps, rays, t_scratch);
+                                                                                     chain_cap, max_steps, rays, t_scratch);
     } else if (occ_index) {
         NGP_REQUIRE(n_bits % 2048u == 0 && ((uintptr_t)grid & 7u) == 0 && ((uintptr_t)occ_index & 7u) == 0,
                     "march_rays_train_arena: occupancy index needs C*H^3 to be a multiple of 2048 and 8-byte aligned buffers");
