@@ -170,7 +170,7 @@ int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const
                                  const uint32_t *occ_index, float *chain, uint16_t *chain_code, int32_t *chain_len,
                                  uint32_t chain_cap, ngp_stream_t stream);
 /* chain != NULL selects the chain-parallel first pass (same result, no serial per-ray loop over the grid): chain
- * [chain_cap, N] f32 and chain_code [chain_cap, N] u16 are scratch, chain_len [N] i32; chain_cap must cover
+ * (chain_cap * N f32) and chain_code (chain_cap * N u16) are scratch (stored ray-major), chain_len [N] i32; chain_cap must cover
  * (far - near) / dt_min + 1 candidate parameters per ray (max_steps * ceil(bound) + 2 always does).  counter then
  * needs 4 ints: counter[2] becomes non-zero (and stays so) if a ray's chain did not fit. */
 
