@@ -504,6 +504,74 @@ def test_work_done_ahead_of_a_grid_refresh_trains_the_same_bits(lib, monkeypatch
     assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
 
 
+def test_passenger_launches_equal_their_separate_forms(lib, orc):
+    """The fused step's two launch fusions against the separate kernels, bit for bit:
+    ngp_x_mlp_forward_step_begin == ngp_x_step_begin (scalars + record-offset scan) followed by ngp_x_mlp_forward, and
+    ngp_x_grid_backward_binned_apply_mlp == ngp_x_mlp_reduce_dw (+ Adam + operand image) and ngp_x_grid_backward_binned_apply."""
+    rng = np.random.default_rng(31)
+    gb, e, mb = lib.gridencoder_backend, lib.engine_backend, lib.mlp_backend
+    L, H, B = 16, 16, 20000
+    offsets, scale = orc.grid_offsets(desired_resolution=2048)
+    S, rows = float(np.log2(scale)), int(offsets[-1])
+    off = dev(offsets)
+    xyz = dev(rng.uniform(-0.9, 0.9, (B, 3)).astype(np.float32))
+    table0 = dev(rng.uniform(-1e-2, 1e-2, (rows, 2)).astype(np.float32))
+    dirs = dev(rng.normal(size=(B, 3)).astype(np.float32))
+    dsigma, drgb = dev((rng.normal(size=B) * 1e-3).astype(np.float32)), dev((rng.normal(size=(B, 3)) * 1e-3).astype(np.float32))
+    cnt = torch.tensor([B, B, 0, 0], dtype=torch.int32, device="cuda")
+    shapes = [(64, 32), (64, 64), (16, 64), (64, 31), (64, 64), (3, 64)]
+    g = torch.Generator().manual_seed(5)
+    flat0 = torch.cat([(torch.randn(o, i, generator=g) * (2.0 / i) ** 0.5).reshape(-1) for o, i in shapes]).cuda()
+
+    def views(flat):
+        out, at = [], 0
+        for o, i in shapes:
+            out.append(flat[at:at + o * i].view(o, i))
+            at += o * i
+        return out
+    results = []
+    for fused in (False, True):
+        table, t_m, t_v = table0.clone(), torch.zeros_like(table0), torch.zeros_like(table0)
+        w_flat, w_grad = flat0.clone(), torch.zeros_like(flat0)
+        w_m, w_v = torch.zeros_like(flat0), torch.zeros_like(flat0)
+        W, dws = views(w_flat), views(w_grad)
+        image = torch.empty(mb.image_bytes(), dtype=torch.uint8, device="cuda")
+        mb.prepare(W, image)
+        enc, x01 = torch.empty(L, B, 2, device="cuda"), torch.empty(B, 3, device="cuda")
+        denc = torch.empty(L, B, 2, device="cuda")
+        sigma, rgb = torch.empty(B, device="cuda"), torch.empty(B, 3, device="cuda")
+        ws = torch.zeros(gb.backward_workspace_bytes(B, L, rows), dtype=torch.uint8, device="cuda")
+        ws_mlp = torch.empty(mb.backward_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+        ctr = torch.tensor([7], dtype=torch.int32, device="cuda")
+        hyper, loss = torch.zeros(4, device="cuda"), torch.full((1,), 3.0, device="cuda")
+        seen = torch.tensor([100], dtype=torch.int64, device="cuda")
+        gb.grid_backward_binned_prepare(None, 0.0, off, rows, cnt, B, L, L, S, H, ws, merge_max_res=414, stage=1)
+        e.grid_encode_forward_slab(xyz, 1.0, table, off, enc, x01, cnt, B, B, L, L, S, H, binned_workspace=ws)
+        begin = (ctr, hyper, 1e-2, 300.0, 0.9, 0.999, loss, seen, cnt, ws, L, rows, True)
+        if fused:
+            mb.forward(enc, B, dirs, cnt, B, image, sigma, rgb, step_begin=begin)
+        else:
+            e.step_begin(*begin[:9], binned_workspace=ws, L=L, n_rows_total=rows, single_segment=True)
+            mb.forward(enc, B, dirs, cnt, B, image, sigma, rgb)
+        mb.backward(enc, B, dirs, dsigma, drgb, cnt, B, image, 1024.0, denc, None, ws_mlp)
+        table_adam = (table, t_m, t_v, hyper, 0.9, 0.999, 1e-15)
+        mlp_adam = (w_flat, w_grad, w_m, w_v, hyper, 0.9, 0.999, 1e-15)
+        if fused:
+            gb.grid_backward_binned_apply(denc, x01, off, None, cnt, B, B, L, L, S, H, ws, adam=table_adam,
+                                          mlp_tail=(B, 1024.0, dws, ws_mlp, mlp_adam, image))
+        else:
+            mb.reduce_dw(B, 1024.0, dws, ws_mlp, adam=mlp_adam, image=image)
+            gb.grid_backward_binned_apply(denc, x01, off, None, cnt, B, B, L, L, S, H, ws, adam=table_adam)
+        torch.cuda.synchronize()
+        results.append(dict(sigma=sigma, rgb=rgb, hyper=hyper, loss=loss, seen=seen, ctr=ctr, table=table, t_m=t_m, t_v=t_v,
+                            w_flat=w_flat, w_grad=w_grad, w_m=w_m, w_v=w_v, image=image))
+    a, b = results
+    assert int(a["ctr"]) == 8 and float(a["loss"]) == 0.0 and int(a["seen"]) == 100 + B and float(a["hyper"][0]) > 0
+    assert float(a["w_grad"].abs().max()) > 0 and not torch.equal(a["table"], table0)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_bf16_wire_gradient_store_and_adam(lib, orc):
     """Data-parallel wire format: the overwrite-mode reduction can store the table gradient as bfloat16 (round to
     nearest even == torch's conversion of the f32 result, bit for bit), and Adam reads it as if it were widened."""
