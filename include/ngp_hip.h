@@ -457,12 +457,15 @@ int ngp_x_sample_rays_lit(const uint8_t *images, uint32_t V, uint32_t H, uint32_
 
 /* ... and adaptive batch sizes (`--adaptive_num_rays`, train_utils.py:563-564) decided on the device: the batch gets
  * live[0] = clamp(round(num_points / prev_samples[0] * prev_live[0]), 1, N) rays (prev_samples / prev_live NULL: N), written
- * by the kernel; ray slots >= live[0] are parked outside the volume (no samples; index -1). */
+ * by the kernel; ray slots >= live[0] are parked outside the volume (no samples; index -1; exposure 1).  prev_live may be
+ * the same word as live (one ray slot): the count is then formed by a one-thread launch in front of the sampler.
+ * view_exposure [V] + exposure [N] (both or neither): exposure[n] = view_exposure[view] (colmap_provider.py:605-606). */
 int ngp_x_sample_rays_adaptive(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W, uint32_t C, const float *poses,
                                float fx, float fy, float cx, float cy, uint32_t N, uint64_t seed, const uint32_t *draw_dev,
                                uint32_t draw, float *rays_o, float *rays_d, float *gt_rgba, float *noises, float *bg_rgb,
                                int32_t *index, const float *view_ldirs, float *rays_ldir, const int32_t *prev_samples,
-                               const int32_t *prev_live, int32_t *live, uint32_t num_points, ngp_stream_t stream);
+                               const int32_t *prev_live, int32_t *live, uint32_t num_points, const float *view_exposure,
+                               float *exposure, ngp_stream_t stream);
 /* ngp_x_composite_mse_train (exposure == NULL) / ngp_x_composite_hdr_train with the loss taken over the first n_live[0]
  * of the N ray slots only (mean over those rays; n_live == NULL: all N). */
 int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,

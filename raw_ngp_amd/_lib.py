@@ -67,7 +67,7 @@ _SIGNATURES = {
     "ngp_x_sample_rays_lit": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p,
                               _p, _p],
     "ngp_x_sample_rays_adaptive": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p,
-                                   _p, _p, _p, _p, _p, _p, _u],
+                                   _p, _p, _p, _p, _p, _p, _u, _p, _p],
     "ngp_x_composite_train_live": [_p, _p, _f, _p, _p, _f, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
     "ngp_x_step_window": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_ray_gradients": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _u, _p, _p],
@@ -789,9 +789,9 @@ class _EngineBackend:
 
     @staticmethod
     def sample_rays(images, poses, intrinsics, N, seed, draw, rays_o, rays_d, gt_rgba, noises=None, bg_rgb=None,
-                    index=None, view_ldirs=None, rays_ldir=None, adaptive=None):
+                    index=None, view_ldirs=None, rays_ldir=None, adaptive=None, exposure=None):
         """`draw`: int32 device tensor (read at run time) or a Python int.  view_ldirs [V,3] + rays_ldir [N,3]: per-ray
-        light directions of the light-conditioned configuration."""
+        light directions of the light-conditioned configuration.  exposure = (view_exposure [V], out [N])."""
         V, H, W, C = images.shape
         fx, fy, cx, cy = [float(v) for v in intrinsics]
         on_dev = torch.is_tensor(draw)
@@ -800,11 +800,14 @@ class _EngineBackend:
                 0 if on_dev else int(draw) & 0xffffffff, _ptr(rays_o, "f", "rays_o"), _ptr(rays_d, "f", "rays_d"),
                 _ptr(gt_rgba, "f", "gt_rgba"), _ptr(noises, "f", "noises", True), _ptr(bg_rgb, "f", "bg_rgb", True),
                 _ptr(index, "i", "index", True))
-        if adaptive is not None:        # (prev_samples, prev_live, live, num_points): see ngp_x_sample_rays_adaptive
-            prev_samples, prev_live, live, num_points = adaptive
+        if adaptive is not None or exposure is not None:
+            # (prev_samples, prev_live, live, num_points): see ngp_x_sample_rays_adaptive
+            prev_samples, prev_live, live, num_points = adaptive if adaptive is not None else (None, None, None, 0)
+            vexp, out_exp = exposure if exposure is not None else (None, None)
             _call("ngp_x_sample_rays_adaptive", images, *args, _ptr(view_ldirs, "f", "view_ldirs", True),
                   _ptr(rays_ldir, "f", "rays_ldir", True), _ptr(prev_samples, "i", "prev_samples", True),
-                  _ptr(prev_live, "i", "prev_live", True), _ptr(live, "i", "live"), int(num_points))
+                  _ptr(prev_live, "i", "prev_live", True), _ptr(live, "i", "live", True), int(num_points),
+                  _ptr(vexp, "f", "view_exposure", True), _ptr(out_exp, "f", "exposure", True))
         elif view_ldirs is None and rays_ldir is None:
             _call("ngp_x_sample_rays", images, *args)
         else:

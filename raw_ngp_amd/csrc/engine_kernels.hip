@@ -545,7 +545,19 @@ struct AdaptiveRays {
     const int32_t *prev_live = nullptr;      // rays of the previous batch
     int32_t *live = nullptr;                 // out: rays of this batch
     uint32_t num_points = 0;                 // target samples per batch
+    bool resolved = false;                   // live[0] was computed by adaptive_live_kernel (prev_live aliases live)
 };
+
+__device__ __forceinline__ uint32_t adaptive_live_count(const AdaptiveRays &ad, uint32_t N)
+{   // python: int(round(num_points / num_points_seen * num_rays)), kept inside [1, N]
+    const double ratio = (double)ad.num_points / (double)max(ad.prev_samples[0], 1);
+    return (uint32_t)fmin(fmax(rint(ratio * (double)max(ad.prev_live[0], 1)), 1.0), (double)N);
+}
+
+// One ray slot (no prefetch, pose refinement): the previous batch's ray count and this batch's are the SAME device word.
+// Every workgroup of the sampler reads it while thread 0 would overwrite it, so the new count is formed here, by one
+// thread, in a launch of its own in front of the sampler, which then only reads it.
+__global__ void adaptive_live_kernel(AdaptiveRays ad, uint32_t N) { ad.live[0] = (int32_t)adaptive_live_count(ad, N); }
 
 __global__ __launch_bounds__(256) void sample_rays_kernel(
     const uint8_t *__restrict__ images, uint32_t V, uint32_t H, uint32_t W, uint32_t C, const float *__restrict__ poses,
@@ -553,17 +565,18 @@ __global__ __launch_bounds__(256) void sample_rays_kernel(
     const uint32_t *__restrict__ draw_dev, uint32_t draw, float *__restrict__ rays_o, float *__restrict__ rays_d,
     float *__restrict__ gt, float *__restrict__ noises, float *__restrict__ bg, int32_t *__restrict__ index,
     const float *__restrict__ view_ldirs = nullptr, float *__restrict__ rays_ldir = nullptr,
-    AdaptiveRays ad = AdaptiveRays{})
+    AdaptiveRays ad = AdaptiveRays{}, const float *__restrict__ view_exposure = nullptr,
+    float *__restrict__ exposure = nullptr)
 {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     if (ad.live) {
         uint32_t n_live = N;
-        if (ad.prev_samples) {   // python: int(round(num_points / num_points_seen * num_rays)), kept inside [1, N]
-            const double ratio = (double)ad.num_points / (double)max(ad.prev_samples[0], 1);
-            n_live = (uint32_t)fmin(fmax(rint(ratio * (double)max(ad.prev_live[0], 1)), 1.0), (double)N);
-        }
-        if (n == 0) ad.live[0] = (int32_t)n_live;
+        if (ad.resolved)
+            n_live = (uint32_t)ad.live[0];
+        else if (ad.prev_samples)
+            n_live = adaptive_live_count(ad, N);
+        if (n == 0 && !ad.resolved) ad.live[0] = (int32_t)n_live;
         if (n >= n_live) {       // a parked slot: the ray starts far outside the volume and points away from it
             rays_o[(size_t)n * 3] = rays_o[(size_t)n * 3 + 1] = 0.0f;
             rays_o[(size_t)n * 3 + 2] = 1e6f;
@@ -578,6 +591,7 @@ __global__ __launch_bounds__(256) void sample_rays_kernel(
                 rays_ldir[(size_t)n * 3] = rays_ldir[(size_t)n * 3 + 1] = 0.0f;
                 rays_ldir[(size_t)n * 3 + 2] = 1.0f;
             }
+            if (exposure) exposure[n] = 1.0f;
             return;
         }
     }
@@ -612,6 +626,7 @@ __global__ __launch_bounds__(256) void sample_rays_kernel(
 #pragma unroll
         for (int k = 0; k < 3; k++) rays_ldir[(size_t)n * 3 + k] = view_ldirs[(size_t)view * 3 + k];
     }
+    if (exposure) exposure[n] = view_exposure[view];   // the exposure of the ray's image (colmap_provider.py:605-606)
 }
 
 // ------------------------------------------------------------------ near / far (torch semantics of run_cuda)
@@ -919,7 +934,7 @@ extern "C" int ngp_x_sample_rays_lit(const uint8_t *images, uint32_t V, uint32_t
 {
     return ngp_x_sample_rays_adaptive(images, V, H, W, C, poses, fx, fy, cx, cy, N, seed, draw_dev, draw, rays_o, rays_d,
                                       gt_rgba, noises, bg_rgb, index, view_ldirs, rays_ldir, nullptr, nullptr, nullptr, 0,
-                                      stream);
+                                      nullptr, nullptr, stream);
 }
 
 extern "C" int ngp_x_sample_rays_adaptive(const uint8_t *images, uint32_t V, uint32_t H, uint32_t W, uint32_t C,
@@ -928,9 +943,10 @@ extern "C" int ngp_x_sample_rays_adaptive(const uint8_t *images, uint32_t V, uin
                                           float *rays_d, float *gt_rgba, float *noises, float *bg_rgb, int32_t *index,
                                           const float *view_ldirs, float *rays_ldir, const int32_t *prev_samples,
                                           const int32_t *prev_live, int32_t *live, uint32_t num_points,
-                                          ngp_stream_t stream)
+                                          const float *view_exposure, float *exposure, ngp_stream_t stream)
 {
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE((view_exposure == nullptr) == (exposure == nullptr), "sample_rays: view_exposure and exposure go together");
     NGP_REQUIRE((prev_samples == nullptr) == (prev_live == nullptr), "sample_rays: prev_samples and prev_live go together");
     NGP_REQUIRE(!prev_samples || (live && num_points > 0), "sample_rays: adaptive batches need `live` and num_points");
     AdaptiveRays ad;
@@ -942,9 +958,14 @@ extern "C" int ngp_x_sample_rays_adaptive(const uint8_t *images, uint32_t V, uin
     NGP_REQUIRE(images && poses && rays_o && rays_d && gt_rgba, "sample_rays: null tensor");
     NGP_REQUIRE(V > 0 && H > 0 && W > 0 && (uint64_t)H * W < (1ull << 32), "sample_rays: bad image shape");
     NGP_REQUIRE(C == 3 || C == 4, "sample_rays: images must be RGB or RGBA (uint8)");
+    if (prev_live && prev_live == live) {   // one ray slot: the count is one device word, see adaptive_live_kernel
+        adaptive_live_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(ad, N);
+        NGP_CHECK_LAUNCH("sample_rays (live count)");
+        ad.resolved = true;
+    }
     sample_rays_kernel<<<dim3(ceil_div(N, 256u)), dim3(256), 0, as_stream(stream)>>>(
         images, V, H, W, C, poses, fx, fy, cx, cy, N, (uint32_t)seed, (uint32_t)(seed >> 32), draw_dev, draw, rays_o, rays_d,
-        gt_rgba, noises, bg_rgb, index, view_ldirs, rays_ldir, ad);
+        gt_rgba, noises, bg_rgb, index, view_ldirs, rays_ldir, ad, view_exposure, exposure);
     NGP_CHECK_LAUNCH("sample_rays");
     return NGP_OK;
 }

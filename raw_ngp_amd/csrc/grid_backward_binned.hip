@@ -424,7 +424,8 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     int e;
     const float gmax = __uint_as_float(w.chunk_base[kMaxLevels + 1]);
     // a non-finite gradient anywhere in the batch (the fill turns NaN into inf): no fixed-point scale exists and an Adam
-    // step on it would poison the table for good -- skip the update, like the reference's GradScaler skips the step
+    // step on it would poison the table for good -- skip the table's update, as the reference's GradScaler skips the step
+    // (the MLP weights are protected element by element: mlp_reduce_dw_group)
     if (ADAM && !(gmax < __uint_as_float(0x7f800000u))) return;
     frexpf(gmax, &e);
     const int k = 62 - kHeadroomBits - e;

@@ -310,7 +310,12 @@ __device__ __forceinline__ void mlp_reduce_dw_group(const MlpDwReduce &a, uint32
     if (!dst) return;
     *dst = s;
     const MlpAdam &adam = a.adam;
-    if (adam.param) {   // the six gradients are views of one flat buffer: Adam on the element just reduced
+    // (a non-finite weight gradient -- one NaN dsigma / drgb in the batch -- leaves this weight, its moments and its
+    // image entries alone: the update would poison it for good.  The table's half of that rule is in bin_reduce_kernel,
+    // which skips the whole table when the batch's largest feature gradient is not finite.  Unlike a GradScaler the skip
+    // is per MLP weight, not per step: this reduction runs beside the fill, before the batch's maximum is known; the
+    // step counter and the bias corrections advance either way.)
+    if (adam.param && fabsf(s) < __uint_as_float(0x7f800000u)) {   // Adam on the element just reduced
         const size_t k = (size_t)(dst - adam.grad);
         const float step_size = adam.hyper[0] / adam.hyper[1], rsqrt_bc2 = adam.hyper[2];
         const float mi = adam.b1 * adam.exp_avg[k] + (1.0f - adam.b1) * s;

@@ -20,7 +20,11 @@ namespace ngp {
 // The reference keeps the annealing value as numpy float16 and evaluates alpha = (annealing - start) / (end - start) * L in
 // that type (every operation rounds to half precision; the python floats are cast to float16 first), then the cosine
 // window in float32 torch ops (network.py:101-108).  level_w[0] is forced to 1 (weights[0:2] = 1).
-// flags[0] = 1 while annealing < end_annealing (the pose optimiser steps), flags[1] = the step index.
+// flags[0] = 1 while annealing < end_annealing (the pose optimiser steps), flags[1] = steps done before this one (the
+// pose optimiser's own step index).  The reference increments global_step BEFORE train_step (train_utils.py:887-888) and
+// forms annealing from the incremented value (:488): the training step with s steps behind it sees (s + 1) / iters --
+// step_offset = 1 -- while the density-grid refresh in front of it still sees the previous step's window (s / iters; 0.0
+// before the first step, :411).
 __global__ void step_window_kernel(const uint32_t *__restrict__ step_counter, uint32_t step_offset, double iters,
                                    float start, float end, uint32_t L, float *__restrict__ level_w,
                                    int32_t *__restrict__ flags)
@@ -41,7 +45,7 @@ __global__ void step_window_kernel(const uint32_t *__restrict__ step_counter, ui
     }
     if (k == 0 && flags) {
         flags[0] = ann < e16 ? 1 : 0;
-        flags[1] = (int32_t)step;
+        flags[1] = (int32_t)step_counter[0];
     }
 }
 

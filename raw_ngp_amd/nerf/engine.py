@@ -94,11 +94,44 @@ class FusedTrainer:
         self.H = enc.base_resolution
         self.table = enc.embeddings.data
         self.rows = self.table.shape[0]
-        # the six MLP matrices become views of one flat buffer (one Adam launch, one all-reduce)
         layers = list(model.grid_mlp.net) + list(model.view_mlp.net)
         sizes = [l.weight.numel() for l in layers]
-        self.w_flat = torch.empty(sum(sizes), **f32)
-        self.w_grad = torch.zeros(sum(sizes), **f32)
+        n_t, n_w = self.table.numel(), sum(sizes)
+        plain = opt.lambda_tv == 0 and opt.lambda_wd == 0
+        # Adam on the hash table fused into the table-gradient reduction: one rank, nothing else touching the gradient
+        self.fuse_adam = bool(getattr(opt, "fuse_adam", True)) and not self.dp and plain
+        # Everything else -- data parallel, or a separate optimiser pass on one GPU -- is the EXCHANGE step: the reduce kernel
+        # overwrites a flat gradient buffer, collectives average it (none on one rank), ONE Adam launch updates what this
+        # rank owns, collectives publish it (parallel.Exchange; `dp_exchange` picks the carrier).  "shard": reduce_scatter ->
+        # Adam on this rank's 1/R of the flat parameter, moments for that shard only -> all_gather (variant 2);
+        # "allreduce": gradient all-reduce + Adam over everything on every rank.  TV / weight decay need the whole gradient.
+        self.dp_mode = (getattr(opt, "dp_mode", "shard") if plain else "allreduce") if not self.fuse_adam else None
+        # 16-bit wire format of the table gradient: the reduce kernel stores bfloat16, RCCL averages it in place, Adam
+        # reads it -- no conversion passes, half the bytes on xGMI (the MLP gradients then travel on their own, in f32)
+        self.wire16 = self.dp_mode is not None and getattr(opt, "grad_wire", "f32") == "bf16" and plain
+        self.xchg, self.flat, self.gflat = None, None, None
+        self.collective_events = None           # bench.py: [(start, stop)] HIP events around the collectives of timed steps
+        self.collective_steps = 0               # ... and how many steps they cover
+        if self.dp_mode is not None:
+            self.xchg = parallel.Exchange(dev, carrier=getattr(opt, "dp_exchange", None) if self.dp else "none")
+            if self.xchg.carrier == "rccl" and self.world_size > 1 and not self.xchg.self_test():
+                # (known answers, eagerly and replayed from a graph, agreed on by all ranks)
+                if self.rank == 0:
+                    print("[raw_ngp_amd] direct RCCL exchange failed its self-test: falling back to torch.distributed", flush=True)
+                self.xchg = parallel.Exchange(dev, carrier="torch")
+            # f32 wire: table and MLP weights share ONE flat parameter (and one flat gradient): one collective each way
+            n_flat = parallel.padded_numel(n_t + (0 if self.wire16 else n_w))
+            self.flat = torch.zeros(n_flat, **f32)
+            self.flat[:n_t].copy_(self.table.reshape(-1))
+            self.table = self.flat[:n_t].view(self.rows, 2)
+            enc.embeddings.data = self.table                # the module's parameter lives in the padded buffer
+            self.gflat = torch.zeros(n_flat, dtype=torch.bfloat16 if self.wire16 else torch.float32, device=dev)
+        # the six MLP matrices become views of one flat buffer (one Adam launch, one all-reduce)
+        if self.flat is not None and not self.wire16:
+            self.w_flat, self.w_grad = self.flat[n_t:n_t + n_w], self.gflat[n_t:n_t + n_w]
+        else:
+            self.w_flat = torch.empty(n_w, **f32)
+            self.w_grad = torch.zeros(n_w, **f32)
         self.weights, self.dws, off = [], [], 0
         for l, n in zip(layers, sizes):
             view = self.w_flat[off:off + n].view_as(l.weight)
@@ -109,9 +142,21 @@ class FusedTrainer:
             off += n
         # optimiser state
         self.betas, self.eps, self.lr0 = betas, eps, opt.lr
-        self.t_m, self.t_v = torch.zeros_like(self.table), torch.zeros_like(self.table)
-        self.w_m, self.w_v = torch.zeros_like(self.w_flat), torch.zeros_like(self.w_flat)
-        self.table_grad = torch.zeros_like(self.table)
+        self._wire = None
+        if self.xchg is None:
+            self.t_m, self.t_v = torch.zeros_like(self.table), torch.zeros_like(self.table)
+            self.w_m, self.w_v = torch.zeros_like(self.w_flat), torch.zeros_like(self.w_flat)
+            self.table_grad = torch.zeros_like(self.table)
+        else:
+            own = self.xchg.shard_of(self.flat) if self.dp_mode == "shard" else self.flat
+            self.t_m, self.t_v = torch.zeros_like(own), torch.zeros_like(own)      # moments of what this rank updates
+            if self.wire16:
+                self.w_m, self.w_v = torch.zeros_like(self.w_flat), torch.zeros_like(self.w_flat)
+                self._wire = self.gflat[:n_t].view(self.rows, 2)
+                self.table_grad = None
+            else:
+                self.w_m = self.w_v = None                                           # (inside t_m / t_v)
+                self.table_grad = self.gflat[:n_t].view(self.rows, 2)
         # per-ray and per-sample buffers
         # two ray-batch slots: while step i trains out of one, step i+1's rays are drawn and marched into the
         # other on a second stream (the march is a long, narrow kernel -- 64 waves -- that hides under backward)
@@ -164,44 +209,10 @@ class FusedTrainer:
         # run merging in the binned backward pays while consecutive samples share cells: res * (step in [0,1]) < ~0.7
         step01 = (2 * math.sqrt(3) / opt.max_steps) / (2 * model.bound)
         self.merge_max_res = int(min(1024, max(16, 0.7 / step01)))
-        # Adam on the hash table fused into the table-gradient reduction: one rank, nothing else touching the gradient
-        self.fuse_adam = bool(getattr(opt, "fuse_adam", True)) and not self.dp and opt.lambda_tv == 0 \
-            and opt.lambda_wd == 0
         self.graphs, self.graph_pool, self.last_graph_key, self._graphs_alive = {}, None, None, []
         self._refresh_graph = {}                       # steady-state refresh as graphs: 0 whole, 1 cell draw, 2 the rest
         self._refresh_head_step = -1                   # step whose refresh already has its cells drawn
         self._eval_slot = None
-        # 16-bit wire format of the table gradient under data parallelism: the reduce kernel stores bfloat16, RCCL
-        # averages it in place, Adam reads it -- no conversion passes, half the bytes on xGMI
-        self.wire16 = getattr(opt, "grad_wire", "f32") == "bf16" and not self.fuse_adam \
-            and opt.lambda_tv == 0 and opt.lambda_wd == 0
-        self._wire = self._wire_flat = self._wire_w = None
-        if self.wire16:     # table gradient, then the MLP gradients (converted by two tiny copies): ONE collective
-            n_t = self.table_grad.numel()
-            self._wire_flat = torch.zeros(n_t + self.w_grad.numel(), dtype=torch.bfloat16, device=dev)
-            self._wire = self._wire_flat[:n_t].view(self.table_grad.shape)
-            self._wire_w = self._wire_flat[n_t:]
-        # data parallel, "shard" mode: reduce_scatter the table gradient, Adam on this rank's 1/R of the (flat, padded) table
-        # with moments that exist for that shard only, all_gather the updated rows (parallel.ShardedStep)
-        self.shard = None
-        self.collective_events = None           # bench.py: [(start, stop)] HIP events around the collectives of a step
-        if self.dp and getattr(opt, "dp_mode", "shard") == "shard" and opt.lambda_tv == 0 and opt.lambda_wd == 0:
-            n = self.table.numel()
-            n_pad = parallel.padded_numel(n)
-            flat = torch.zeros(n_pad, **f32)
-            flat[:n].copy_(self.table.reshape(-1))
-            self.table = flat[:n].view(self.rows, 2)
-            enc.embeddings.data = self.table                # the module's parameter lives in the padded buffer
-            gdt = torch.bfloat16 if self.wire16 else torch.float32
-            gflat = torch.zeros(n_pad, dtype=gdt, device=dev)
-            if self.wire16:
-                self._wire = gflat[:n].view(self.rows, 2)
-                self._wire_flat = self._wire_w = None       # (the MLP gradients travel on their own, in f32)
-            else:
-                self.table_grad = gflat[:n].view(self.rows, 2)
-            self.shard = parallel.ShardedStep(flat, gflat)
-            self.t_m = torch.zeros(self.shard.n_shard, **f32)
-            self.t_v = torch.zeros(self.shard.n_shard, **f32)
         self._main_symbols = {"ngp_x_mlp_rf_forward", "ngp_x_mlp_rf_backward", "ngp_x_mlp_rf_prepare",
                               "ngp_x_grid_encode_forward_slab_jac", "ngp_x_composite_hdr_train",
                               "ngp_x_grid_backward_binned_apply", "ngp_x_grid_backward_binned_apply_mlp",
@@ -557,9 +568,16 @@ class FusedTrainer:
                               (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
             return
         assert self.shard is None, "data parallel 'shard' mode: only the step path (train_step) owns the optimiser"
+        self._image_ready = False                       # the f16 operand image is of the weights before this update
         step, lr = self.global_step + 1, self.lr()
         eb.adam_step(self.table, self.table_grad, self.t_m, self.t_v, lr, *self.betas, self.eps, step, zero_grad=True)
         eb.adam_step(self.w_flat, self.w_grad, self.w_m, self.w_v, lr, *self.betas, self.eps, step, zero_grad=False)
+
+    def invalidate_weights(self):
+        """Call after changing the MLP weights from outside the step (load_state_dict into the w_flat views, an external
+        optimiser): the next step / density-grid refresh rebuilds the f16 operand image instead of trusting the one the
+        fused Adam keeps in step."""
+        self._image_ready = False
 
     # ------------------------------------------------------------------ one optimiser step
     def _load_slot(self, slot, batch=None, noises=None, stage=0):
@@ -576,10 +594,10 @@ class FusedTrainer:
             eb.sample_rays(d.images, self.poses_refined if self.pose else d.poses, d.intrinsics, self.N, self.seed64,
                            self.draw_ctr, slot.rays_o, slot.rays_d, slot.gt, slot.noises,
                            slot.bg if opt.background == "random" else None, slot.index, self.view_ldirs, slot.rays_ldir,
-                           adaptive=self._adaptive_args(slot))
+                           adaptive=self._adaptive_args(slot),
+                           # the exposure of each ray's image (colmap_provider.py:605-606); parked ray slots get 1
+                           exposure=(self.view_exposure, slot.exposure) if self.hdr else None)
             eb.counter_add(self.draw_ctr, 1)
-            if self.hdr:        # the exposure of each ray's image (colmap_provider.py:605-606)
-                torch.index_select(self.view_exposure, 0, slot.index[:, 0].long(), out=slot.exposure)
         else:
             if batch is None:
                 batch = self.data.sample_rays(self.N, self.ray_gen)
@@ -638,9 +656,10 @@ class FusedTrainer:
             field.insert(1, begin)                                                  # right after the encoder's forward
         if self.pose:
             # the level window of THIS step and whether the cameras still move (annealing < end_annealing), from the step
-            # counter before step_begin advances it
+            # counter before step_begin advances it; + 1: the reference counts the step before it trains it
+            # (train_utils.py:887-888 in front of :488)
             field.insert(1, ("ngp_x_step_window", lambda: eb.step_window(
-                self.step_ctr, 0, float(opt.iters), opt.start_annealing, opt.end_annealing, self.L, self.level_w, self.flags)))
+                self.step_ctr, 1, float(opt.iters), opt.start_annealing, opt.end_annealing, self.L, self.level_w, self.flags)))
         # pose refinement, after the field's own backward: ray gradients (encoder input backward + segment sums) ->
         # per-camera pose gradients -> se(3) Adam step and the refined poses the next batch is cast from
         pose_tail = []

@@ -61,7 +61,9 @@ class Trainer:
         refine = self.pose_optimizer is not None
         if refine:
             # a numpy float16, like the reference (train_utils.py:488): the level windows see its rounding
-            self.annealing = np.clip(self.global_step / opt.iters, 0, 1).astype(np.float16)
+            # (global_step is incremented in front of train_step there, train_utils.py:887-888: step s sees (s + 1) / iters;
+            # the density-grid refresh above still saw the previous step's value, 0.0 before the first one, :411)
+            self.annealing = np.clip((self.global_step + 1) / opt.iters, 0, 1).astype(np.float16)
             model.update_annealing(self.annealing)
             self.pose_optimizer.update_annealing(self.annealing)
             data = self.data.sample_rays(opt.num_rays, self.ray_gen, pose_fn=self.pose_optimizer)

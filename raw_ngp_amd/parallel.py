@@ -167,3 +167,134 @@ class ShardedStep:
         else:
             self._send.copy_(self.param_shard)
             dist.all_gather_into_tensor(self.param, self._send)
+
+
+class Exchange:
+    """The collectives of one data-parallel optimiser step on flat buffers, behind one face for three carriers:
+
+      "rccl"   bare RCCL calls on the current HIP stream (raw_ngp_amd.rccl): in place, capturable -- a hipGraph of several
+               training steps contains its reduce-scatters and all-gathers like any other kernel node
+      "torch"  torch.distributed on an initialised "nccl" group: eager calls between the captured segments of a step
+      "gloo"   torch.distributed over gloo: CPU tests and the two-ranks-on-one-GPU rehearsal (no in-place forms, no AVG)
+
+    reduce_scatter_avg(buf) leaves the mean of shard `rank` in shard_of(buf) -- a view of buf for "rccl" / "torch", a
+    buffer of its own for gloo; all_gather(buf) publishes every rank's shard of buf in place; all_reduce_avg(*bufs)
+    averages whole buffers.  Buffers are flat, padded_numel() long."""
+
+    def __init__(self, device, carrier=None):
+        self.R, self.r = world_size(), rank()
+        self.device = torch.device(device)
+        backend = dist.get_backend() if is_dist() else None
+        if carrier is None:
+            carrier = "rccl" if (backend == "nccl" and self.device.type == "cuda") else "torch"
+        if backend != "nccl" and carrier != "none":
+            carrier = "gloo" if is_dist() else "none"
+        self.carrier = carrier
+        self.capturable = carrier in ("rccl", "none")
+        self.comm = None
+        self._recv, self._send = {}, {}
+        if carrier == "rccl":
+            from . import rccl
+            self.comm = rccl.Communicator(self.device)
+
+    def shard_bounds(self, buf):
+        n = buf.numel()
+        assert buf.dim() == 1 and n % (4 * self.R) == 0, "Exchange: flat buffers of padded_numel() elements"
+        k = n // self.R
+        return self.r * k, (self.r + 1) * k
+
+    def shard_of(self, buf):
+        """Where reduce_scatter_avg(buf) leaves this rank's result."""
+        lo, hi = self.shard_bounds(buf)
+        if self.carrier != "gloo":
+            return buf[lo:hi]
+        key = (buf.data_ptr(), buf.dtype)
+        if key not in self._recv:
+            self._recv[key] = torch.empty(hi - lo, dtype=buf.dtype, device=buf.device)
+        return self._recv[key]
+
+    def reduce_scatter_avg(self, buf):
+        out = self.shard_of(buf)
+        if self.carrier == "rccl":
+            self.comm.reduce_scatter_(buf)
+        elif self.carrier == "torch":
+            dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.AVG)
+        elif self.carrier == "gloo":
+            dist.reduce_scatter_tensor(out, buf)
+            out.div_(self.R)
+        return out
+
+    def all_gather(self, buf):
+        lo, hi = self.shard_bounds(buf)
+        if self.carrier == "rccl":
+            self.comm.all_gather_(buf)
+        elif self.carrier == "torch":
+            dist.all_gather_into_tensor(buf, buf[lo:hi])
+        elif self.carrier == "gloo":
+            key = (buf.data_ptr(), buf.dtype)
+            if key not in self._send:
+                self._send[key] = torch.empty(hi - lo, dtype=buf.dtype, device=buf.device)
+            self._send[key].copy_(buf[lo:hi])
+            dist.all_gather_into_tensor(buf, self._send[key])
+
+    def all_reduce_avg(self, *bufs):
+        if self.carrier == "rccl":
+            self.comm.all_reduce_(*bufs)
+        elif self.carrier == "torch":
+            # blocking collectives are enqueued on the CURRENT stream by ProcessGroupNCCL; one ncclGroup for all of them
+            with dist._coalescing_manager(device=self.device):
+                for b in bufs:
+                    dist.all_reduce(b, op=dist.ReduceOp.AVG)
+        elif self.carrier == "gloo":
+            for b in bufs:
+                if b.dtype == torch.bfloat16 and not b.is_cuda:
+                    t = b.float()
+                    dist.all_reduce(t)
+                    b.copy_(t.div_(self.R))
+                else:
+                    dist.all_reduce(b)
+                    b.div_(self.R)
+
+    def self_test(self, graph=True):
+        """Known-answer check of the three collectives on this carrier (rank r contributes r + 1), eagerly and -- for a
+        capturable carrier on a GPU -- replayed from a captured graph.  Returns True when every rank agrees that every
+        result is right (the verdict itself is reduced over torch.distributed)."""
+        ok = True
+        try:
+            n = 4 * self.R * 256
+            want = sum(range(1, self.R + 1)) / self.R
+
+            def fill():
+                return torch.full((n,), float(self.r + 1), device=self.device)
+
+            def run(a, b):
+                self.reduce_scatter_avg(a)
+                lo, hi = self.shard_bounds(a)
+                if self.carrier == "gloo":
+                    a[lo:hi].copy_(self.shard_of(a))
+                self.all_gather(a)
+                self.all_reduce_avg(b)
+            a, b = fill(), fill()
+            run(a, b)
+            ok = bool(torch.all(a == want)) and bool(torch.all(b == want))
+            if ok and graph and self.capturable and self.device.type == "cuda" and self.carrier == "rccl":
+                a.fill_(float(self.r + 1))
+                b.fill_(float(self.r + 1))
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    run(a, b)
+                for _ in range(2):
+                    a.fill_(float(self.r + 1))
+                    b.fill_(float(self.r + 1))
+                    g.replay()
+                    torch.cuda.synchronize(self.device)
+                    ok = ok and bool(torch.all(a == want)) and bool(torch.all(b == want))
+        except Exception as e:      # noqa: BLE001 -- any failure means "do not use this carrier"
+            print(f"[rank {self.r}] Exchange.self_test({self.carrier}) failed: {e}", flush=True)
+            ok = False
+        if is_dist():
+            on = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
+            v = torch.tensor([1.0 if ok else 0.0], device=on)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            ok = bool(v.item() == 1.0)
+        return ok

@@ -1,0 +1,119 @@
+"""RCCL, called directly: the collectives of the data-parallel step as plain `nccl*` calls on the caller's HIP stream.
+
+Why not torch.distributed for these: a ProcessGroupNCCL collective brings its own stream hops and event bookkeeping, and
+inside a hipGraph capture that bookkeeping is the fragile part.  A bare ncclReduceScatter / ncclAllGather on the capture
+stream is one kernel node of the step graph like any other, so a group of training steps -- collectives included --
+replays from ONE graph launch (raw_ngp_amd.nerf.engine, `dp_exchange = "rccl"`).  torch.distributed stays what it is good
+at: rendezvous (the unique id travels over the default process group), barriers, the CPU/gloo rehearsal.
+
+The library is the librccl.so PyTorch already links (same symbols, one copy in the process).  Everything here is in place:
+  reduce_scatter(buf): every rank passes its full-length buffer, rank r ends with the reduction of shard r AT shard r
+  all_gather(buf):     rank r's shard r is published into every rank's buffer
+which is what RCCL treats as its in-place forms (recvbuff == sendbuff + rank * count).
+"""
+import ctypes
+import os
+
+import torch
+
+NCCL_UNIQUE_ID_BYTES = 128                     # rccl.h:40
+ncclSum, ncclMax, ncclAvg = 0, 2, 4            # rccl.h: ncclRedOp_t
+_DTYPES = {torch.float32: 7, torch.bfloat16: 9, torch.float16: 6, torch.int32: 2}   # rccl.h: ncclDataType_t
+
+
+class _UniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_byte * NCCL_UNIQUE_ID_BYTES)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.environ.get("NGP_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        L = ctypes.CDLL(path)
+        vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L.ncclGetErrorString.restype = ctypes.c_char_p
+        L.ncclGetErrorString.argtypes = [i]
+        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
+        L.ncclCommInitRank.argtypes = [ctypes.POINTER(vp), i, _UniqueId, i]
+        L.ncclCommDestroy.argtypes = [vp]
+        L.ncclReduceScatter.argtypes = [vp, vp, sz, i, i, vp, vp]         # send, recv, recvcount, dtype, op, comm, stream
+        L.ncclAllGather.argtypes = [vp, vp, sz, i, vp, vp]                # send, recv, sendcount, dtype, comm, stream
+        L.ncclAllReduce.argtypes = [vp, vp, sz, i, i, vp, vp]             # send, recv, count, dtype, op, comm, stream
+        L.ncclGroupStart.argtypes = []
+        L.ncclGroupEnd.argtypes = []
+        for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclReduceScatter", "ncclAllGather",
+                     "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd"):
+            getattr(L, name).restype = i
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"RCCL: {what} failed: {lib().ncclGetErrorString(rc).decode()}")
+
+
+class Communicator:
+    """One RCCL communicator over the ranks of torch.distributed's default group (one process per GPU)."""
+
+    def __init__(self, device):
+        import torch.distributed as dist
+        assert dist.is_initialized(), "rccl.Communicator: initialise torch.distributed first (it carries the unique id)"
+        self.device = torch.device(device)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        L = lib()
+        uid = _UniqueId()
+        if self.rank == 0:
+            _check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        on = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=on)
+        dist.broadcast(t, src=0)
+        ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().tolist()), NCCL_UNIQUE_ID_BYTES)
+        self.comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(L.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _shard(self, buf):
+        if not (buf.is_cuda and buf.is_contiguous() and buf.dim() == 1) or buf.dtype not in _DTYPES:
+            raise RuntimeError("rccl: flat contiguous device tensor of a supported dtype expected")
+        if buf.numel() % self.world:
+            raise RuntimeError("rccl: buffer length must be a multiple of the number of ranks")
+        n = buf.numel() // self.world
+        return n, buf.data_ptr(), buf.data_ptr() + self.rank * n * buf.element_size()
+
+    def reduce_scatter_(self, buf, op=ncclAvg):
+        """In place: afterwards buf[rank * n : (rank + 1) * n] holds the reduction of that shard over all ranks."""
+        n, base, mine = self._shard(buf)
+        with torch.cuda.device(self.device):
+            _check(lib().ncclReduceScatter(base, mine, n, _DTYPES[buf.dtype], op, self.comm, self._stream()), "ncclReduceScatter")
+
+    def all_gather_(self, buf):
+        """In place: every rank's shard buf[rank * n : (rank + 1) * n] is published into every rank's buf."""
+        n, base, mine = self._shard(buf)
+        with torch.cuda.device(self.device):
+            _check(lib().ncclAllGather(mine, base, n, _DTYPES[buf.dtype], self.comm, self._stream()), "ncclAllGather")
+
+    def all_reduce_(self, *bufs, op=ncclAvg):
+        """In place; several buffers go out as one group (one launch)."""
+        L = lib()
+        with torch.cuda.device(self.device):
+            if len(bufs) > 1:
+                _check(L.ncclGroupStart(), "ncclGroupStart")
+            for b in bufs:
+                if not (b.is_cuda and b.is_contiguous()) or b.dtype not in _DTYPES:
+                    raise RuntimeError("rccl: contiguous device tensor of a supported dtype expected")
+                _check(L.ncclAllReduce(b.data_ptr(), b.data_ptr(), b.numel(), _DTYPES[b.dtype], op, self.comm, self._stream()),
+                       "ncclAllReduce")
+            if len(bufs) > 1:
+                _check(L.ncclGroupEnd(), "ncclGroupEnd")
+
+    def destroy(self):
+        if self.comm:
+            lib().ncclCommDestroy(self.comm)
+            self.comm = ctypes.c_void_p()

@@ -694,19 +694,23 @@ def test_fast_evaluation_renders_what_the_inference_loop_renders(lib):
     assert eng.global_step == before + 5 and torch.isfinite(eng.loss).all()
 
 
-def test_adaptive_ray_batches_follow_the_reference_rule(lib):
+@pytest.mark.parametrize("prefetch", [True, False])
+def test_adaptive_ray_batches_follow_the_reference_rule(lib, prefetch):
     """`--adaptive_num_rays` on the device (train_utils.py:563-564): every batch gets round(num_points / samples * rays) rays
-    of the previous batch's counts, nothing is read back by the step; samples per step settle at num_points."""
+    of the previous batch's counts, nothing is read back by the step; samples per step settle at num_points.
+    prefetch off = ONE ray slot: the previous batch's ray count and the new one are the same device word (the sampler's
+    workgroups must all see the same count: adaptive_live_kernel)."""
     from raw_ngp_amd.nerf.network import NeRFNetwork
     from raw_ngp_amd.nerf.options import Options
     from raw_ngp_amd.nerf.scene import SyntheticDataset
     from raw_ngp_amd.nerf.engine import FusedTrainer
     dev = torch.device("cuda")
     torch.manual_seed(0)
-    opt = Options(bound=1.0, num_rays=1024, iters=400, adaptive_num_rays=True, num_points=2 ** 15, max_ray_batch=8192)
+    opt = Options(bound=1.0, num_rays=1024, iters=400, adaptive_num_rays=True, num_points=2 ** 15, max_ray_batch=8192,
+                  prefetch_march=prefetch)
     data = SyntheticDataset(opt, dev, "train", n_views=6, H=96, W=96)
     ft = FusedTrainer(opt, NeRFNetwork(opt), data, device=dev)
-    assert ft.N == 8192
+    assert ft.N == 8192 and len(ft.slots) == (2 if prefetch else 1)
     hist = []
     for it in range(300):
         ft.train_step()
@@ -720,10 +724,40 @@ def test_adaptive_ray_batches_follow_the_reference_rule(lib):
     assert len({r for r, _ in hist[-60:]}) > 1 and all(r != 1024 for r, _ in hist[-60:])   # the batch size moved and keeps adjusting
     assert int(ft.rays_seen) == sum(r for r, _ in hist)
     assert np.isfinite(float(ft.loss)) and torch.isfinite(ft.table).all()
-    # parked ray slots carry nothing: no samples, no image
+    # parked ray slots carry nothing: no samples, no image -- and exactly the slots behind live[0] are parked (every
+    # workgroup of the sampler used the same count)
     n_live = hist[-1][0]
     last = ft.slots[299 % len(ft.slots)]
     assert int(last.arena.rays[n_live:, 1].sum()) == 0
+    parked = (last.rays_o[:, 2] == 1e6)
+    assert int(parked.sum()) == ft.N - n_live and not bool(parked[:n_live].any())
+
+
+def test_adaptive_ray_batches_with_the_hdr_loss(lib):
+    """HDR loss + adaptive ray batches: parked ray slots carry view index -1; their exposure is written by the sampler
+    (1.0), no gather with a negative index happens, the loss stays finite and the rule still holds."""
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=1024, iters=400, adaptive_num_rays=True, num_points=2 ** 15, max_ray_batch=4096,
+                  image_mode="HDR")
+    data = SyntheticDataset(opt, dev, "train", n_views=6, H=96, W=96)
+    data.exposures = torch.tensor([0.5, 1.0, 2.0, 0.5, 1.0, 2.0], device=dev)
+    ft = FusedTrainer(opt, NeRFNetwork(opt), data, device=dev)
+    for it in range(40):
+        ft.train_step()
+    torch.cuda.synchronize()
+    slot = ft.slots[39 % len(ft.slots)]
+    n_live = int(slot.live)
+    assert 1 <= n_live < ft.N
+    view = slot.index[:, 0]
+    assert bool((view[n_live:] == -1).all()) and bool((view[:n_live] >= 0).all())
+    assert torch.equal(slot.exposure[:n_live], data.exposures[view[:n_live].long()])
+    assert bool((slot.exposure[n_live:] == 1.0).all())
+    assert np.isfinite(float(ft.loss)) and torch.isfinite(ft.table).all()
 
 
 def test_grid_kernels_at_their_boundaries_stay_inside_their_buffers(lib, orc):

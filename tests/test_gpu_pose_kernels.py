@@ -45,10 +45,13 @@ def test_step_window_matches_float16_restatement(lib, orc, iters, start, end):
         np.testing.assert_allclose(host(lw), ref, rtol=0, atol=2e-6, err_msg=f"step {s}")   # cosf vs numpy cos
         f = host(flags)
         assert f[1] == s and f[0] == int(ann < np.float16(end)), (s, f, ann)
-    # step_offset: the value the NEXT step will see
+    # step_offset 1 = what the training step sees (the reference increments global_step first, train_utils.py:887-888);
+    # flags[1] stays the count of steps already done (the pose optimiser's Adam / ExponentialLR index)
     ctr.fill_(41)
-    e.step_window(ctr, 1, iters, start, end, 16, lw, None)
-    np.testing.assert_allclose(host(lw), orc.barf_window(42, iters, start, end, 16)[0], rtol=0, atol=2e-6)
+    e.step_window(ctr, 1, iters, start, end, 16, lw, flags)
+    ref, ann = orc.barf_window(42, iters, start, end, 16)
+    np.testing.assert_allclose(host(lw), ref, rtol=0, atol=2e-6)
+    assert host(flags)[1] == 41 and host(flags)[0] == int(ann < np.float16(end))
 
 
 def test_slab_jacobian_and_ray_gradients_match_oracle(lib, orc):
