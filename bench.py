@@ -152,8 +152,8 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
                   fused_mlp=not args.torch_mlp, prefetch_march=not args.no_prefetch,
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
                   aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
-                  dp_rehearsal=args.dp_rehearsal, graph_collective=args.graph_collective, group_steps=args.group_steps,
-                  dp_mode=args.dp_mode)
+                  dp_rehearsal=args.dp_rehearsal, dp_exchange=args.dp_exchange, group_steps=args.group_steps,
+                  dp_mode=args.dp_mode, **({"loss_scale": args.loss_scale} if args.loss_scale else {}))
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
     fused = not (args.autograd or args.torch_mlp)
@@ -203,8 +203,10 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     parallel.barrier()
     torch.cuda.synchronize()
     _lib.probe_reset()
-    if fused and trainer.dp and trainer.shard is not None:
-        trainer.collective_events = []          # HIP events around the step's collectives, read after the timed region
+    if fused and trainer.xchg is not None and trainer.xchg.carrier != "none":
+        # HIP events around the collectives of the steps whose kernels are probed (the other steps replay them from inside
+        # their graphs, where nothing can be timed); read after the timed region
+        trainer.collective_events, trainer.collective_steps = [], 0
     seen0 = int(trainer.samples_seen) if fused else 0
     t0 = time.perf_counter()
     samples = 0
@@ -224,7 +226,7 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     dt = time.perf_counter() - t0
     collective_ms = None
     if fused and getattr(trainer, "collective_events", None):
-        collective_ms = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / max(args.steps, 1)
+        collective_ms = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / max(trainer.collective_steps, 1)
         trainer.collective_events = None
     probe = _lib.probe_results(symbols)
     probe_fwd = _lib.probe_results((fwd_symbol,)) if fwd_symbol in probed else (0, 0, 0.0)
@@ -303,13 +305,16 @@ def main():
     ap.add_argument("--no-fuse-adam", action="store_true",
                     help="separate Adam pass over the table (what data-parallel ranks run), on one GPU")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--loss-scale", type=float, default=0.0,
+                    help="static loss scale of the fused MLP backward's f16 deltas (0 = the Options default)")
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"],
                     help="data parallel: wire format of the table-gradient all-reduce")
     ap.add_argument("--dp-mode", default="shard", choices=["shard", "allreduce"],
                     help="data parallel: reduce_scatter -> Adam on 1/R of the table -> all_gather (shard), or gradient "
                          "all-reduce + full Adam on every rank (allreduce)")
-    ap.add_argument("--graph-collective", action="store_true",
-                    help="data parallel: capture the RCCL all-reduce inside the step graph (experimental, off by default)")
+    ap.add_argument("--dp-exchange", default=None, choices=["rccl", "torch"],
+                    help="data parallel, carrier of the collectives: rccl = bare RCCL calls captured inside the step graphs "
+                         "(default on an nccl process group), torch = torch.distributed, eager between graph segments")
     ap.add_argument("--dp-rehearsal", action="store_true",
                     help="one GPU: run the data-parallel step (separate Adam, RCCL collectives on a one-rank group)")
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
@@ -346,7 +351,8 @@ def main():
              "table_numel": int(trainer.table.numel()) if fused else 0,
              "graph": bool(fused and trainer.use_graph), "prefetch": bool(fused and trainer.prefetch),
              "device_sampler": bool(fused and trainer.device_sampler), "cap": trainer.cap if fused else 0,
-             "step": trainer.global_step}
+             "step": trainer.global_step,
+             "dp_exchange": trainer.xchg.carrier if fused and getattr(trainer, "xchg", None) is not None else None}
     del res, trainer
     # the reference's own defaults as secondary rows (main.py:31,46: --bound 2, black background): same schedule and
     # timing protocol, no probes.  The headline stays the benchmark framing (bound 1, random background).
@@ -414,7 +420,8 @@ def main():
                        "rays_per_step_per_gpu": args.rays, "samples_per_step": round(samples / max(args.steps, 1)),
                        "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
                        "parallelism": f"dp{world}", "grad_wire": args.grad_wire if (world > 1 or args.dp_rehearsal) else None,
-                       "dp_mode": args.dp_mode if (world > 1 or args.dp_rehearsal) else None, "ranks_seen": ranks_seen,
+                       "dp_mode": args.dp_mode if (world > 1 or args.dp_rehearsal) else None,
+                       "dp_exchange": tinfo["dp_exchange"], "ranks_seen": ranks_seen,
                        "collective_ms_per_step": None if collective_ms is None else round(collective_ms, 4),
                        "multi_gpu_measured": "RCCL over >1 rank has not been measured by the builder (no multi-GPU box in reach): "
                                              "this line is the first measurement" if world > 1 else None,

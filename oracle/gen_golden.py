@@ -5,7 +5,11 @@ TEST INFRASTRUCTURE.  Run as `python oracle/gen_golden.py` in the container that
 modules that are not installed are replaced by inert MagicMock entries, SURVEY.md section 8c /
 Appendix B), feeds them seeded inputs and writes inputs + outputs to tests/golden/*.npz.
 Only data is written -- no reference source text.  The reference's CUDA kernels cannot be
-built or run here, so nothing below touches `_backend`.
+built or run here.  The wrapper-level fixtures (`wrapper_grid.npz`, `wrapper_sh.npz`) run the reference's own
+`GridEncoder` / `_grid_encode` and `SHEncoder` / `_sh_encoder` Python (gridencoder/grid.py:24-99,149-174,
+shencoder/sphere_harmonics.py:14-89) on CPU with `_backend` replaced by a shim over THIS repo's CPU oracle
+(oracle/libngp_oracle.so): what they pin is the wrappers' share -- the [-bound, bound] -> [0, 1] map, flatten / permute /
+reshape, the double normalisation, which tensors get gradients and in which dtype -- not the kernels' arithmetic.
 """
 import argparse
 import os
@@ -116,6 +120,102 @@ def main():
         tabs[f"{tag}_n_params"] = np.int64(int(enc.n_params))
         tabs[f"{tag}_emb_shape"] = np.array(enc.embeddings.shape)
     np.savez(os.path.join(args.out, "grid_offsets.npz"), **tabs)
+
+    # ---------------------------------------------------------------- the encoder WRAPPERS over an oracle-backed _backend
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import oracle as orc
+
+    class OracleGridBackend:
+        """`_gridencoder` (gridencoder/src/bindings.cpp:5-9) over the CPU restatement: same positional arguments, results
+        written into the caller's tensors."""
+
+        @staticmethod
+        def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, H, dy_dx, gridtype,
+                                align_corners, interp):
+            out, jac = orc.grid_encode_forward(inputs.detach().numpy(), embeddings.detach().numpy(), offsets.numpy(), B, D, C, L,
+                                               max_level, float(S), H, dy_dx is not None, gridtype, align_corners, interp)
+            if max_level < L:       # the kernel leaves the levels it skips untouched (the wrapper zero-fills them first)
+                out[max_level:] = outputs.detach().numpy()[max_level:]
+            outputs.copy_(torch.from_numpy(out))
+            if dy_dx is not None:
+                dy_dx.copy_(torch.from_numpy(jac))
+
+        @staticmethod
+        def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S, H, dy_dx,
+                                 grad_inputs, gridtype, align_corners, interp):
+            assert grad.is_contiguous() and tuple(grad.shape) == (L, B, C)
+            ge, gi = orc.grid_encode_backward(grad.numpy(), inputs.detach().numpy(), embeddings.detach().numpy(), offsets.numpy(),
+                                              B, D, C, L, max_level, float(S), H,
+                                              None if dy_dx is None else dy_dx.numpy(), gridtype, align_corners, interp)
+            grad_embeddings.add_(torch.from_numpy(ge))          # (atomicAdd into the zero-initialised tensor)
+            if grad_inputs is not None:
+                grad_inputs.copy_(torch.from_numpy(gi))
+
+    class OracleShBackend:
+        @staticmethod
+        def sh_encode_forward(inputs, outputs, B, D, C, dy_dx):
+            out, jac = orc.sh_encode_forward(inputs.detach().numpy(), B, D, C, dy_dx is not None)
+            outputs.copy_(torch.from_numpy(out))
+            if dy_dx is not None:
+                dy_dx.copy_(torch.from_numpy(jac))
+
+        @staticmethod
+        def sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs):
+            assert grad.is_contiguous()
+            grad_inputs.add_(torch.from_numpy(orc.sh_encode_backward(grad.numpy(), inputs.detach().numpy(), B, D, C,
+                                                                     dy_dx.numpy())))
+
+    G._backend = OracleGridBackend
+    wg = {}
+    for tag, bound, kw in (("b1", 1.0, dict(num_levels=8, log2_hashmap_size=11, desired_resolution=256)),
+                           ("b2", 2.0, dict(num_levels=6, log2_hashmap_size=10, desired_resolution=512,
+                                            interpolation="smoothstep"))):
+        torch.manual_seed(41 if bound == 1.0 else 42)
+        enc = G.GridEncoder(input_dim=3, level_dim=2, base_resolution=16, **kw)
+        gen = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            enc.embeddings.copy_(torch.rand(enc.embeddings.shape, generator=gen) * 2 - 1)
+        x = (torch.rand(5, 7, 3, generator=gen) * 2 - 1) * bound
+        x[0, 0] = torch.tensor([bound, -bound, 0.0])              # on the faces of the volume
+        x[0, 1] = torch.tensor([1.01 * bound, 0.0, 0.0])          # outside: zeros, no gradient
+        x[0, 2] = torch.tensor([0.0, 0.0, 0.0])
+        gy = torch.randn(5, 7, enc.output_dim, generator=gen)
+        wg[f"{tag}_embeddings"] = enc.embeddings.detach().numpy().copy()
+        wg[f"{tag}_x"], wg[f"{tag}_gy"] = x.numpy().copy(), gy.numpy()
+        wg[f"{tag}_offsets"] = enc.offsets.numpy()
+        # (1) positions need gradients (pose refinement): outputs + both gradients
+        xr = x.clone().requires_grad_(True)
+        out = enc(xr, bound=bound)
+        gx, ge = torch.autograd.grad((out * gy).sum(), [xr, enc.embeddings])
+        wg[f"{tag}_out"], wg[f"{tag}_gx"], wg[f"{tag}_gemb"] = out.detach().numpy(), gx.numpy(), ge.numpy()
+        assert out.dtype == torch.float32 and gx.dtype == torch.float32
+        # (2) positions without gradients (the default training path): dy_dx is never formed
+        out2 = enc(x.clone(), bound=bound)
+        (ge2,) = torch.autograd.grad((out2 * gy).sum(), [enc.embeddings])
+        assert torch.equal(out2, out) and torch.equal(ge2, ge)      # same outputs, same table gradient
+        # (3) max_level: only the first levels are computed, the others read zero
+        out3 = enc(x.clone(), bound=bound, max_level=3)
+        wg[f"{tag}_out_maxlevel3"] = out3.detach().numpy()
+        # (4) double-precision positions are cast to float32 (custom_fwd(cast_inputs=torch.float32)) only under autocast;
+        #     without it the reference's op receives them as given: the wrapper's dtype contract is float32 in
+    np.savez_compressed(os.path.join(args.out, "wrapper_grid.npz"), **wg)
+
+    import shencoder.sphere_harmonics as SHM
+    SHM._backend = OracleShBackend
+    ws = {}
+    for degree in (4, 6):
+        gen = torch.Generator().manual_seed(100 + degree)
+        she = SHM.SHEncoder(input_dim=3, degree=degree)
+        d = torch.randn(3, 11, 3, generator=gen) * 2.5             # NOT unit vectors: the module normalises (:81)
+        gy = torch.randn(3, 11, degree ** 2, generator=gen)
+        dr = d.clone().requires_grad_(True)
+        out = she(dr, size=2.0)
+        (gd,) = torch.autograd.grad((out * gy).sum(), [dr])
+        out_plain = she(d.clone(), size=2.0)                       # no gradient wanted: dy_dx is not formed
+        assert torch.equal(out_plain, out.detach())
+        ws[f"d{degree}_dirs"], ws[f"d{degree}_gy"] = d.numpy(), gy.numpy()
+        ws[f"d{degree}_out"], ws[f"d{degree}_gdirs"] = out.detach().numpy(), gd.numpy()
+    np.savez(os.path.join(args.out, "wrapper_sh.npz"), size=2.0, **ws)
 
     # ---------------------------------------------------------------- checkpoint layout (state_dict keys/shapes)
     import json

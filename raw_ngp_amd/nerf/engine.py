@@ -472,7 +472,7 @@ class FusedTrainer:
         n_uni, n_occ = (cells, 0) if full else (cells // 4, cells // 4)
         total = n_uni + n_occ
         offsets = m.grid_encoder.offsets
-        if part != 1 and not (self.fuse_adam and self._image_ready):     # (the fused step keeps the f16 operand image current)
+        if part != 1 and not self._image_ready:     # (the step keeps the f16 operand image of the current weights up to date)
             self._mlp_prepare()
         for cas in range(m.cascade):
             bound = min(2 ** cas, m.bound)
@@ -496,36 +496,6 @@ class FusedTrainer:
     def mean_density(self):
         return float(self.dg_stats[1]) if self.native_refresh else float(self.model.mean_density)   # host read
 
-    def reduce_gradients(self, wire=False):
-        """Ray-batch data parallelism: average the table and MLP gradients over the ranks (RCCL over xGMI).
-        The table gradient is reduced in place (46.5 MiB, or 23 MiB in bfloat16) and the 53 KiB of MLP gradients ride in
-        the same launch (f32: one ncclGroup; bf16: appended to the wire buffer); AVG folds the division into it.
-        wire: the step path's gradient buffer (bfloat16 when grad_wire == "bf16")."""
-        if not self.dp:
-            return
-        dist = torch.distributed
-        # grad_wire "bf16": the table gradient already IS bfloat16 (the sum over ranks is formed in bf16, ~3 significant
-        # digits -- Adam normalises the magnitude anyway)
-        if wire and self.wire16:
-            # one bfloat16 buffer holds both gradients (the step path packs / unpacks the MLP part around this call)
-            if dist.get_backend() == "nccl":
-                dist.all_reduce(self._wire_flat, op=dist.ReduceOp.AVG)
-            else:
-                dist.all_reduce(self._wire_flat)
-                self._wire_flat.div_(self.world_size)
-            return
-        if dist.get_backend() == "nccl":
-            # blocking collectives (async_op=False) are enqueued on the CURRENT stream by ProcessGroupNCCL: no hop to its
-            # internal stream and back (every such event wait costs 15-20 us here); both tensors in one ncclGroup
-            with dist._coalescing_manager(device=self.device):
-                dist.all_reduce(self.table_grad, op=dist.ReduceOp.AVG)
-                dist.all_reduce(self.w_grad, op=dist.ReduceOp.AVG)
-        else:                                       # gloo (rehearsal): no AVG
-            dist.all_reduce(self.w_grad)
-            self.w_grad.div_(self.world_size)
-            dist.all_reduce(self.table_grad)
-            self.table_grad.div_(self.world_size)
-
     def _timed(self, fn):
         """Run fn() between two HIP events on the current stream when bench.py asked for collective timings."""
         if self.collective_events is None:
@@ -536,23 +506,43 @@ class FusedTrainer:
         b.record()
         self.collective_events.append((a, b))
 
-    def _sharded_exchange_and_step(self):
-        """Data parallel, "shard" mode (eager, outside the step's graphs): reduce_scatter of the table gradient and
-        all-reduce of the 53 KiB of MLP gradients, Adam on this rank's shard of the table and on the (replicated) MLP
-        weights in one launch, all_gather of the updated table rows."""
-        sh, dist = self.shard, torch.distributed
+    # ---- the exchange step's optimiser half (data parallel, or a separate optimiser pass on one GPU) ----------------
+    def _xchg_pre(self):
+        """Average the gradients over the ranks: afterwards `_xchg_grad()` is the mean gradient of what this rank updates."""
+        x = self.xchg
+        if self.collective_events is not None and not torch.cuda.is_current_stream_capturing():
+            self.collective_steps += 1
 
-        def reduce():
-            sh.reduce_scatter()
-            if dist.get_backend() == "nccl":
-                dist.all_reduce(self.w_grad, op=dist.ReduceOp.AVG)
+        def run():
+            if self.dp_mode == "shard":
+                x.reduce_scatter_avg(self.gflat)
+                if self.wire16:
+                    x.all_reduce_avg(self.w_grad)
+            elif self.wire16:
+                x.all_reduce_avg(self.gflat, self.w_grad)
             else:
-                dist.all_reduce(self.w_grad)
-                self.w_grad.div_(self.world_size)
-        self._timed(reduce)
-        eb.adam_step_dev2((sh.param_shard, sh.grad_shard, self.t_m, self.t_v, False),
-                          (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
-        self._timed(sh.all_gather)
+                x.all_reduce_avg(self.gflat)
+        if x.carrier != "none":
+            self._timed(run)
+
+    def _xchg_adam(self):
+        """ONE launch: Adam on this rank's part of the flat parameter (f32 wire: the MLP weights are part of it)."""
+        x = self.xchg
+        if self.dp_mode == "shard":
+            lo, hi = x.shard_bounds(self.flat)
+            own_p, own_g = self.flat[lo:hi], x.shard_of(self.gflat)
+        else:
+            own_p, own_g = self.flat, self.gflat
+        if self.wire16:
+            eb.adam_step_dev2((own_p, own_g, self.t_m, self.t_v, False),
+                              (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
+        else:
+            eb.adam_step_dev(own_p, own_g, self.t_m, self.t_v, self.hyper, *self.betas, self.eps)
+
+    def _xchg_post(self):
+        """Publish the updated shards (shard mode)."""
+        if self.dp_mode == "shard" and self.xchg.carrier != "none":
+            self._timed(lambda: self.xchg.all_gather(self.flat))
 
     def optimizer_step(self, device_hyper=False):
         """Adam on the table and the MLP weights.  device_hyper: learning rate and bias corrections come from
@@ -564,12 +554,15 @@ class FusedTrainer:
             self.model.grid_encoder.embeddings.grad = self.table_grad
             self.model.apply_weight_decay(self.opt.lambda_wd)
         if device_hyper:                                # (step path: the gradient is overwritten next step, no zeroing)
-            eb.adam_step_dev2((self.table, self._wire if self.wire16 else self.table_grad, self.t_m, self.t_v, False),
-                              (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
+            self._xchg_adam()
             return
-        assert self.shard is None, "data parallel 'shard' mode: only the step path (train_step) owns the optimiser"
+        assert self.xchg is None or (self.xchg.carrier == "none" and not self.wire16), \
+            "optimizer_step with host scalars: one rank, whole-table moments (data parallel: train_step owns the optimiser)"
         self._image_ready = False                       # the f16 operand image is of the weights before this update
         step, lr = self.global_step + 1, self.lr()
+        if self.xchg is not None:                       # one flat parameter: table, MLP weights, padding
+            eb.adam_step(self.flat, self.gflat, self.t_m, self.t_v, lr, *self.betas, self.eps, step, zero_grad=True)
+            return
         eb.adam_step(self.table, self.table_grad, self.t_m, self.t_v, lr, *self.betas, self.eps, step, zero_grad=True)
         eb.adam_step(self.w_flat, self.w_grad, self.w_m, self.w_v, lr, *self.betas, self.eps, step, zero_grad=False)
 
@@ -634,13 +627,14 @@ class FusedTrainer:
         # has to zero it and the accumulate's read disappears (TV / weight decay are added afterwards, in optimizer_step)
         # one GPU, plain field: the MLP's weight-gradient reduction (+ Adam on the MLP weights + their entries in the f16
         # operand image) rides along with the table backward's fill launch instead of being a kernel of its own
-        ride = split and not self.rfield and not bool(getattr(opt, "aux_stream", False)) and \
+        # (exchange step: the same passenger without Adam -- it leaves the weight gradients in the flat gradient buffer)
+        ride = not self.rfield and not bool(getattr(opt, "aux_stream", False)) and \
             os.environ.get("NGP_MLP_TAIL_RIDES", "1") != "0"
-        mlp_tail = (self.cap, opt.loss_scale, self.dws, self.ws_mlp,
-                    (self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps), self.mlp_image) if ride else None
+        mlp_adam = (self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps) if split else None
+        mlp_tail = (self.cap, opt.loss_scale, self.dws, self.ws_mlp, mlp_adam, self.mlp_image if split else None) if ride else None
         self.table_backward_symbol = "ngp_x_grid_backward_binned_apply" + ("_mlp" if ride else "")   # (what bench.py times)
         field = self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False,
-                                fused_adam=self.fuse_adam, split_weights=split, overwrite=not self.fuse_adam,
+                                fused_adam=self.fuse_adam, split_weights=True, overwrite=not self.fuse_adam,
                                 fuse_composite=True, mlp_tail=mlp_tail)
         field = self._without(field, "ngp_x_grid_backward_binned_prepare")          # folded into step_begin
         if not self.rfield and not self.pose and os.environ.get("NGP_STEP_BEGIN_RIDES", "1") != "0":
@@ -695,19 +689,20 @@ class FusedTrainer:
                 ops.append((name, op, "main"))
             ops += [(n, o, "main") for n, o in pose_tail]
             return ops
-        assert not self.rfield, "fused rfield step: single-GPU fused-Adam variant only (data parallel: use Trainer)"
+        # ---- the exchange step: gradients -> collectives -> ONE Adam launch -> collectives -> next step's operand image
         ops += [(n, o, "main") for n, o in field]
-        if self.shard is not None:
-            ops.append(("all_reduce", self._sharded_exchange_and_step, "main"))
-            return ops
-        if self.dp:
-            if self.wire16:
-                ops.append(("wire_pack", lambda: self._wire_w.copy_(self.w_grad), "main"))
-            ops.append(("all_reduce", lambda: self.reduce_gradients(wire=True), "main"))
-            if self.wire16:
-                ops.append(("wire_unpack", lambda: self.w_grad.copy_(self._wire_w), "main"))
-        ops.append(("ngp_x_adam_step_dev2", lambda: self.optimizer_step(device_hyper=True), "main"))
-        return ops                                  # (this variant prepares the weight image before its MLP forward)
+        if not ride and not self.rfield:            # (the light-conditioned backward reduces its weight gradients itself)
+            ops.append(("ngp_x_mlp_reduce_dw", lambda: self.mb.reduce_dw(self.cap, opt.loss_scale, self.dws, self.ws_mlp), "main"))
+        if self.pose:
+            # the cameras are replicated: every rank folds its rays into its own pose gradient, the ranks average them and
+            # all take the same se(3) step
+            pose_tail.insert(2, ("xchg_pose", lambda: self.xchg.all_reduce_avg(self.grad_pose.view(-1)), "main"))
+            ops += [(n, o, "main") for n, o in pose_tail if n != "xchg_pose" or self.xchg.carrier != "none"]
+        ops.append(("xchg_pre", self._xchg_pre, "main"))
+        ops.append(("ngp_x_adam_step_dev", lambda: self.optimizer_step(device_hyper=True), "main"))
+        ops.append(("xchg_post", self._xchg_post, "main"))
+        ops.append(("ngp_x_mlp_prepare", self._mlp_prepare, "main"))
+        return ops
 
     def _run_ops(self, ops, fork=True):
         """Launch a run of ops on the current stream; "aux" ops go to the aux stream (fork at the first one, join at the
@@ -747,6 +742,12 @@ class FusedTrainer:
         for part in self.graphs[key]:
             part()
 
+    def _loose_collectives(self, timed):
+        """Do this step's collectives stay outside its graph?  Yes when their carrier cannot be captured (gloo,
+        torch.distributed) and on the steps bench.py times (HIP events around them)."""
+        return self.xchg is not None and self.xchg.carrier != "none" and \
+            (not self.xchg.capturable or (timed and self.collective_events is not None))
+
     def _capture(self, slot, timed):
         """The step as hipGraphs.  Two kinds of op stay outside: the gradient all-reduce (RCCL, under DP) and, on the
         steps where bench.py times it with HIP events, the probed entry point (events inside a graph cannot be
@@ -754,9 +755,10 @@ class FusedTrainer:
         from .. import _lib
         if self.graph_pool is None:
             self.graph_pool = torch.cuda.graph_pool_handle()
-        # (graph_collective: capture the RCCL call inside the step graph -- opt-in, verified on a one-rank group only)
-        eager = {*(() if getattr(self.opt, "graph_collective", False) else ("all_reduce",)),
-                 *(_lib.probed_symbols() if timed else ())}
+        # the collectives stay outside when their carrier cannot be captured (gloo, torch.distributed) and on the steps
+        # bench.py times (HIP events around them)
+        loose = self._loose_collectives(timed)
+        eager = {*(("xchg_pre", "xchg_post", "xchg_pose") if loose else ()), *(_lib.probed_symbols() if timed else ())}
         ops = self._step_ops(slot)
         # one graph: the aux lane may fork inside it
         whole = not any(name in eager for name, _, _ in ops) and bool(getattr(self.opt, "aux_stream", False))
@@ -827,7 +829,7 @@ class FusedTrainer:
             from .. import _lib
             probed = [n for n in _lib.probed_symbols() if n in self._main_symbols]
             timed = bool(probed) and _lib.probe_next_timed()
-            key = (step % 2, timed)
+            key = (step % 2, timed, self._loose_collectives(timed))
             if key not in self.graphs:
                 self.graphs[key] = self._capture(slot, timed)
             for part in self.graphs[key]:
@@ -858,7 +860,8 @@ class FusedTrainer:
         opt = self.opt
         every = opt.update_extra_interval
         s = self.global_step
-        if not (self.use_graph and self.prefetch and self.device_sampler and self.march_mode != "index" and not self.dp
+        if not (self.use_graph and self.prefetch and self.device_sampler and self.march_mode != "index"
+                and (self.xchg is None or self.xchg.capturable)
                 and s >= 2 and s % every != 0 and self._image_ready):
             return 0
         G = min(limit, every - s % every, _lib.probe_untimed_run())
@@ -922,7 +925,8 @@ class FusedTrainer:
         the trailing prefetch) now, so that any run of regular steps between two density-grid refreshes -- or between two
         steps bench.py times -- is ONE graph launch and no capture (milliseconds) falls into a timed region.  Call after
         the first few steps (lazy initialisation done); nothing is executed.  Returns the number of graphs captured."""
-        if not (self.use_graph and self.prefetch and self.device_sampler and self.march_mode != "index" and not self.dp
+        if not (self.use_graph and self.prefetch and self.device_sampler and self.march_mode != "index"
+                and (self.xchg is None or self.xchg.capturable)
                 and self.global_step >= 2 and self._image_ready):
             return 0
         n = 0

@@ -64,7 +64,9 @@ class Options:
     loss_scale: float = 1024.0    # static loss scale of the fused MLP backward (f16 deltas)
     arena_capacity: int = 0       # > 0: sample arena (no host sync per step); 0 = reference 2-pass protocol
     native_grid_refresh: bool = True  # fused engine: density-grid refresh as device kernels (no host syncs)
-    graph_collective: bool = False  # data parallel: capture the gradient all-reduce inside the step graph (experimental)
+    dp_exchange: str = None       # data parallel, carrier of the collectives: "rccl" = bare RCCL calls on the step's stream,
+                                  # captured inside the step graphs (default on an "nccl" process group), "torch" =
+                                  # torch.distributed, eager between graph segments (gloo always takes this route)
     dp_rehearsal: bool = False    # run the data-parallel step on ONE rank (needs an initialised process group)
     grad_wire: str = "f32"        # data parallel: wire format of the gradient exchange (f32 | bf16; bf16 is an opt-in:
                                   # the cross-rank sum is then formed in bfloat16, narrower than anything the reference does)

@@ -126,49 +126,6 @@ def padded_numel(n, world=None, align=4):
     return (n + q - 1) // q * q
 
 
-class ShardedStep:
-    """The exchange of SURVEY 8e's second variant, around a rank-local optimiser:
-
-        reduce_scatter(grad, AVG)  ->  optimiser on this rank's 1/R of the flat parameter  ->  all_gather(param)
-
-    Same wire bytes as an all-reduce of the gradient (which IS a reduce-scatter followed by an all-gather), but the
-    optimiser sweep -- parameter, two moments, gradient: 28 B per element of a 12.2 M-element table -- and the moments'
-    memory shrink by the number of ranks.  `param` and `grad` are flat tensors of padded_numel() elements (grad may be
-    bfloat16: the wire format); the caller runs its optimiser on (param_shard, grad_shard) between the two calls.
-    Works over RCCL ("nccl": AVG folded into the collective, in-place gather) and gloo (CPU tests, one-GPU rehearsal)."""
-
-    def __init__(self, param, grad):
-        self.R, self.r = world_size(), rank()
-        n = param.numel()
-        assert param.dim() == 1 and grad.dim() == 1 and grad.numel() == n, "ShardedStep: flat tensors of equal length"
-        assert n % (4 * self.R) == 0, "ShardedStep: length must come from padded_numel()"
-        self.param, self.grad = param, grad
-        self.n_shard = n // self.R
-        self.lo = self.r * self.n_shard
-        self.param_shard = param[self.lo:self.lo + self.n_shard]                  # a view: updated in place
-        self.grad_shard = grad if self.R == 1 else torch.empty(self.n_shard, dtype=grad.dtype, device=grad.device)
-        self._nccl = is_dist() and dist.get_backend() == "nccl"
-        self._send = None if (self.R == 1 or self._nccl) else torch.empty_like(self.param_shard)
-
-    def reduce_scatter(self):
-        if self.R == 1:
-            return
-        if self._nccl:
-            dist.reduce_scatter_tensor(self.grad_shard, self.grad, op=dist.ReduceOp.AVG)
-        else:
-            dist.reduce_scatter_tensor(self.grad_shard, self.grad)
-            self.grad_shard.div_(self.R)
-
-    def all_gather(self):
-        if self.R == 1:
-            return
-        if self._nccl:
-            dist.all_gather_into_tensor(self.param, self.param_shard)              # in place: shard r of the output
-        else:
-            self._send.copy_(self.param_shard)
-            dist.all_gather_into_tensor(self.param, self._send)
-
-
 class Exchange:
     """The collectives of one data-parallel optimiser step on flat buffers, behind one face for three carriers:
 

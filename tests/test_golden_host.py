@@ -128,6 +128,22 @@ def test_level_windows(golden_dir, mode):
         np.testing.assert_allclose(seen[0].numpy(), g[f"{mode}_{ann}"], rtol=1e-6, atol=1e-6)
 
 
+def test_oracle_barf_window_matches_the_reference_windows(golden_dir):
+    """oracle.barf_window -- what the device step_window kernel is tested against -- reproduces the level weights the
+    reference's common_forward applied (network.py:99-109, float16 annealing of train_utils.py:488) at annealing
+    {0, 0.1, 0.33, 1}: the fixture holds features x weights for features 0.1 .. 3.2."""
+    from oracle import oracle as orc
+    g = load(golden_dir, "level_windows.npz")
+    feat = g["feat"]
+    for ann, step in ((0.0, 0), (0.1, 100), (0.33, 330), (1.0, 1000)):
+        w, a16 = orc.barf_window(step, 1000, 0.0, 0.33, 16)
+        assert a16 == np.float16(ann)
+        np.testing.assert_allclose(feat * np.repeat(w, 2)[None, :], g[f"barf_{ann}"], rtol=1e-6, atol=1e-7)
+    # (mid-window values exist in the fixture: not all weights are 0 or 1)
+    w, _ = orc.barf_window(100, 1000, 0.0, 0.33, 16)
+    assert np.any((w > 0.01) & (w < 0.99))
+
+
 def test_run_sampler_with_analytic_field(golden_dir):
     g = load(golden_dir, "run_analytic.npz")
     from raw_ngp_amd.nerf.options import Options

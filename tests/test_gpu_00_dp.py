@@ -6,7 +6,9 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -34,3 +36,49 @@ def test_two_ranks_stay_in_sync(wire, mode):
         assert res["config"]["collective_ms_per_step"] > 0
     assert res["config"]["replicas_in_sync"] is True
     assert res["value"] > 0 and res["psnr"]["value"] > 5.0
+
+
+@pytest.mark.parametrize("mode,wire", [("shard", "f32"), ("allreduce", "f32"), ("shard", "bf16")])
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mode, wire):
+    """Ray-batch data parallelism IS a bigger batch: two ranks with 2048 rays each (gloo carries the collectives between
+    the two processes on the box's one GPU) end a step with the gradient -- and, up to Adam's sign-like first step, the
+    parameters -- of one rank training on the 4096 concatenated rays.  f32 wire: 1e-3 on the gradient (summation order);
+    bfloat16 wire: 1e-2 (three significant digits per rank, by construction)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dp_equivalence_worker as W
+    env = dict(os.environ, NGP_DIST_BACKEND="gloo", NGP_LOCAL_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    port = 29850 + (os.getpid() % 100) + {"shard": 0, "allreduce": 1}[mode] + (2 if wire == "bf16" else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_equivalence_worker.py"), str(tmp_path),
+           mode, wire]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    ranks = [torch.load(os.path.join(tmp_path, f"dp{r}.pt"), weights_only=True) for r in range(2)]
+    assert torch.equal(ranks[0]["flat"], ranks[1]["flat"]) and torch.equal(ranks[0]["w"], ranks[1]["w"])   # replicas
+    # ---- one rank, the 4096 concatenated rays, separate optimiser pass (same kernels, no collectives)
+    dev = torch.device("cuda")
+    opt, data, one = W.setup(4096, dev, fuse_adam=False)
+    assert one.xchg is not None and one.xchg.carrier == "none" and not one.dp
+    parts = [W.draw(data, 2048, 100 + r, dev) for r in range(2)]
+    batch = {k: torch.cat([p[0][k] for p in parts]) for k in parts[0][0]}
+    flat0 = one.flat.clone()
+    one.train_step(batch, torch.cat([p[1] for p in parts]))
+    torch.cuda.synchronize()
+    assert int(one.arena.counter[0]) == ranks[0]["samples"] + ranks[1]["samples"]       # the same samples, split in two
+    np.testing.assert_allclose(float(one.loss), (ranks[0]["loss"] + ranks[1]["loss"]) / 2, rtol=1e-4)
+    n = one.table.numel() + (one.w_flat.numel() if wire == "f32" else 0)
+    g1 = one.gflat[:n].float().cpu()
+    g2 = torch.cat([r["grad"] for r in ranks])[:n] if mode == "shard" else ranks[0]["grad"][:n]
+    if mode == "shard":
+        assert ranks[0]["lo"] == 0 and ranks[0]["hi"] == ranks[1]["lo"]
+    rel = float((g1 - g2).norm() / g1.norm())
+    assert float(g1.norm()) > 0 and rel < (1e-2 if wire == "bf16" else 1e-3), rel
+    # parameters: Adam's first step is lr * sign(g) wherever g != 0 -- rows whose mean gradient is rounding noise may go
+    # either way, the rest agree
+    lr = one.lr0
+    d1, d2 = (one.flat[:n] - flat0[:n]).cpu(), ranks[0]["flat"][:n] - flat0[:n].cpu()
+    assert float(d1.abs().max()) > 0.5 * lr
+    differ = ((d1 - d2).abs() > 0.01 * lr).float().mean()
+    assert float(differ) < (2e-2 if wire == "bf16" else 2e-3), float(differ)

@@ -345,7 +345,9 @@ def test_fused_adam_matches_separate_adam(lib):
         t0 = eng.table.clone()
         eng.train_step()         # ONE step: later steps amplify rounding differences (Adam moves rows with a
         torch.cuda.synchronize()  # near-zero gradient by +-lr whichever sign the rounding gives it)
-        tabs.append((eng.table.clone() - t0, eng.t_m.clone(), eng.t_v.clone(), float(eng.loss)))
+        n_t = eng.table.numel()         # (separate Adam: the moments cover the flat parameter -- table, MLP weights, padding)
+        tabs.append((eng.table.clone() - t0, eng.t_m.reshape(-1)[:n_t].clone(), eng.t_v.reshape(-1)[:n_t].clone(),
+                     float(eng.loss)))
     (da, ma, va, la), (db, mb_, vb, lb) = tabs
     assert float(da.abs().max()) > 5e-3                       # the table moved (lr 1e-2)
     # The very first occupancy grid thresholds an untrained, almost constant density field at its own mean (float

@@ -6,6 +6,12 @@ container and wrote tests/golden/*.npz; the reference itself never travels):
   run_weights.npz                      per-sample weights, weights_sum, depth, image of NeRFRenderer.run()'s compositor
                                        (renderer.py:471-495)  ->  ngp_composite_rays_train_forward and the wave kernel
 
+  wrapper_grid.npz / wrapper_sh.npz    the reference's GridEncoder / _grid_encode and SHEncoder / _sh_encoder Python
+                                       (grid.py:24-99,149-174; sphere_harmonics.py:14-89) run on CPU over a `_backend`
+                                       backed by this repo's CPU oracle  ->  this repo's wrappers over the HIP library:
+                                       pins G0 / S0 (bound map, flatten / permute / reshape, double normalisation, dtype
+                                       and which inputs get gradients); the kernels' arithmetic is the oracle's either way
+
 Tolerances: the MFMA kernels round every operand to f16 (the reference's --fp16 autocast precision): 3e-2 relative on the
 activated outputs, 5e-2 in the L2 sense on gradients (a ReLU whose pre-activation is within f16 rounding of zero may
 flip).  The compositors are f32: 3e-4 relative (prefix products and __expf against exp(-cumsum))."""
@@ -85,3 +91,57 @@ def test_compositors_match_the_reference_renderer(golden_dir):
         np.testing.assert_allclose(dep.cpu().numpy(), g["depth"], err_msg=name, rtol=3e-4, atol=1e-5)
         np.testing.assert_allclose(img.cpu().numpy(), g["image"], err_msg=name, **tol)
     assert g["weights_sum"][5] == 0 and g["weights"][6, 5:].max() < 1e-30       # the fixture's empty ray and its wall
+
+
+@pytest.mark.parametrize("tag,bound,kw", [
+    ("b1", 1.0, dict(num_levels=8, log2_hashmap_size=11, desired_resolution=256)),
+    ("b2", 2.0, dict(num_levels=6, log2_hashmap_size=10, desired_resolution=512, interpolation="smoothstep"))])
+def test_grid_encoder_wrapper_matches_the_reference_wrapper(golden_dir, tag, bound, kw):
+    """G0: GridEncoder.forward + _grid_encode forward / backward as the reference's Python does them (fixture generated by
+    running that Python over an oracle-backed `_backend`), here over libngp_hip.so.  Encoders are f32: 1e-5 relative on
+    outputs (1e-6 kernel parity + the bound map's rounding), 1e-4 on gradients (atomic / binned summation order)."""
+    from raw_ngp_amd.gridencoder import GridEncoder
+    g = np.load(os.path.join(golden_dir, "wrapper_grid.npz"))
+    enc = GridEncoder(input_dim=3, level_dim=2, base_resolution=16, **kw).cuda()
+    np.testing.assert_array_equal(enc.offsets.cpu().numpy(), g[f"{tag}_offsets"])
+    with torch.no_grad():
+        enc.embeddings.copy_(dev(g[f"{tag}_embeddings"]))
+    x, gy = dev(g[f"{tag}_x"]), dev(g[f"{tag}_gy"])
+    # positions with gradients
+    xr = x.clone().requires_grad_(True)
+    out = enc(xr, bound=bound)
+    assert out.shape == (5, 7, enc.output_dim) and out.dtype == torch.float32
+    gx, ge = torch.autograd.grad((out * gy).sum(), [xr, enc.embeddings])
+    want = g[f"{tag}_out"]
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+    assert np.all(out.detach().cpu().numpy()[0, 1] == 0) and np.all(gx.cpu().numpy()[0, 1] == 0)      # outside the volume
+    assert gx.dtype == torch.float32 and gx.shape == x.shape
+    assert rel_l2(gx.cpu().numpy(), g[f"{tag}_gx"]) < 1e-4
+    assert rel_l2(ge.cpu().numpy(), g[f"{tag}_gemb"]) < 1e-4
+    # positions without gradients: same outputs, same table gradient, no position gradient
+    out2 = enc(x.clone(), bound=bound)
+    (ge2,) = torch.autograd.grad((out2 * gy).sum(), [enc.embeddings])
+    assert torch.equal(out2, out.detach())
+    assert rel_l2(ge2.cpu().numpy(), g[f"{tag}_gemb"]) < 1e-4
+    # max_level
+    out3 = enc(x.clone(), bound=bound, max_level=3)
+    want3 = g[f"{tag}_out_maxlevel3"]
+    np.testing.assert_allclose(out3.detach().cpu().numpy(), want3, rtol=1e-5, atol=1e-5 * np.abs(want3).max())
+    assert np.all(out3.detach().cpu().numpy()[..., 6:] == 0) and np.any(want3[..., :6] != 0)
+
+
+@pytest.mark.parametrize("degree", [4, 6])
+def test_sh_encoder_wrapper_matches_the_reference_wrapper(golden_dir, degree):
+    """S0: SHEncoder.forward (size division, normalisation, flatten, reshape) + _sh_encoder forward / backward: the
+    gradient reaches the UN-normalised directions through the module's normalisation.  f32: 1e-5 / 1e-4."""
+    from raw_ngp_amd.shencoder import SHEncoder
+    g = np.load(os.path.join(golden_dir, "wrapper_sh.npz"))
+    she = SHEncoder(input_dim=3, degree=degree)
+    d, gy = dev(g[f"d{degree}_dirs"]), dev(g[f"d{degree}_gy"])
+    dr = d.clone().requires_grad_(True)
+    out = she(dr, size=float(g["size"]))
+    assert out.shape == (3, 11, degree ** 2) and out.dtype == torch.float32
+    (gd,) = torch.autograd.grad((out * gy).sum(), [dr])
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"d{degree}_out"], rtol=1e-5, atol=1e-5)
+    assert rel_l2(gd.cpu().numpy(), g[f"d{degree}_gdirs"]) < 1e-4
+    assert torch.equal(she(d.clone(), size=float(g["size"])), out.detach())

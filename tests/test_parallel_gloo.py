@@ -76,23 +76,33 @@ def _shard_worker(rank, world, port, out_dir):
     param[:n] = torch.randn(n, generator=g0)                        # replicas start identical
     grad = torch.zeros(N)
     grad[:n] = torch.randn(n, generator=torch.Generator().manual_seed(50 + rank))    # every rank: its own gradient
-    step = parallel.ShardedStep(param, grad)
-    m, v = torch.zeros(step.n_shard), torch.zeros(step.n_shard)     # moments exist for this rank's shard only
+    x = parallel.Exchange("cpu")
+    assert x.carrier == "gloo" and not x.capturable and x.self_test()
+    lo, hi = x.shard_bounds(param)
+    assert (hi - lo) * world == N and lo == rank * (hi - lo)
+    m, v = torch.zeros(hi - lo), torch.zeros(hi - lo)               # moments exist for this rank's shard only
     lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-15
+    grad0 = grad.clone()
     for t in (1, 2, 3):
-        step.reduce_scatter()
-        g = step.grad_shard
+        grad.copy_(grad0)
+        g = x.reduce_scatter_avg(grad)                              # the mean of this rank's shard
+        assert g is x.shard_of(grad)
         m.mul_(b1).add_(g, alpha=1 - b1)
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
-        step.param_shard.sub_((lr / (1 - b1 ** t)) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps))
-        step.all_gather()
+        param[lo:hi].sub_((lr / (1 - b1 ** t)) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps))
+        x.all_gather(param)
+    # whole-buffer averages (the "allreduce" mode, and the 53 KiB of MLP gradients beside a bfloat16 table gradient)
+    a, b16 = grad0.clone(), grad0[:1024].to(torch.bfloat16)
+    x.all_reduce_avg(a, b16)
+    grad = grad0
+    torch.save({"avg": a, "avg16": b16.float()}, os.path.join(out_dir, f"avg{rank}.pt"))
     torch.save({"param": param.clone(), "grad": grad.clone()}, os.path.join(out_dir, f"shard{rank}.pt"))
     parallel.barrier()
     dist.destroy_process_group()
 
 
 def test_sharded_step_equals_adam_on_the_mean_gradient(tmp_path):
-    """reduce_scatter -> Adam on 1/R of the rows -> all_gather leaves every replica with what a single process gets from
+    """parallel.Exchange over gloo: reduce_scatter -> Adam on 1/R of the rows -> all_gather leaves every replica with what a single process gets from
     torch.optim.Adam on the mean of the ranks' gradients."""
     world = 2
     mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
@@ -107,3 +117,8 @@ def test_sharded_step_equals_adam_on_the_mean_gradient(tmp_path):
         p.grad = (outs[0]["grad"] + outs[1]["grad"]) / 2
         opt.step()
     np.testing.assert_allclose(outs[0]["param"].numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-7)
+    avgs = [torch.load(os.path.join(tmp_path, f"avg{r}.pt"), weights_only=True) for r in range(world)]
+    mean = (outs[0]["grad"] + outs[1]["grad"]) / 2
+    for r in range(world):
+        np.testing.assert_allclose(avgs[r]["avg"].numpy(), mean.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(avgs[r]["avg16"].numpy(), mean[:1024].numpy(), rtol=2e-2, atol=2e-2)
