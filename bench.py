@@ -170,13 +170,17 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     symbols = (args.roofline_kernel,)
     if args.roofline_kernel == "ngp_x_grid_backward_binned":
         # (one GPU, plain field: the apply call that also carries the MLP's weight-gradient reduction along)
-        ride = fused and trainer.fuse_adam and not trainer.rfield and not getattr(opt, "aux_stream", False) and \
-            os.environ.get("NGP_MLP_TAIL_RIDES", "1") != "0"
+        ride = fused and trainer.rides_mlp_tail()
         symbols = ("ngp_x_grid_backward_binned_apply" + ("_mlp" if ride else ""), "ngp_x_grid_backward_binned_prepare")
     # the north star also names the encoder's forward: timed the same way, reported as roofline_forward
     fwd_symbol = "ngp_x_grid_encode_forward_slab"
     probed = symbols + ((fwd_symbol,) if fused and fwd_symbol not in symbols else ())
     _lib.set_probe(None if (args.no_probe or not probe_on) else probed, arg_idx, every=args.probe_every)
+    if fused and trainer.xchg is not None and trainer.xchg.carrier != "none" and not args.no_probe and probe_on:
+        # HIP events around the collectives of the steps whose kernels are probed (the other steps replay them from inside
+        # their graphs, where nothing can be timed); switched on BEFORE the burn-in, so that the step variant with its
+        # collectives outside the graph is captured there and not inside the timed region
+        trainer.collective_events, trainer.collective_steps = [], 0
     # The fused engine replays runs of consecutive steps from hipGraphs whose shape depends on where a run starts inside the
     # 16-step density-grid cycle, on its length and on which steps are probed; a variant that is first needed inside the
     # timed region would be CAPTURED there (milliseconds of host time: the driver's 20-step region is 7 ms long).  So the
@@ -203,10 +207,8 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     parallel.barrier()
     torch.cuda.synchronize()
     _lib.probe_reset()
-    if fused and trainer.xchg is not None and trainer.xchg.carrier != "none":
-        # HIP events around the collectives of the steps whose kernels are probed (the other steps replay them from inside
-        # their graphs, where nothing can be timed); read after the timed region
-        trainer.collective_events, trainer.collective_steps = [], 0
+    if fused and trainer.collective_events is not None:
+        trainer.collective_events, trainer.collective_steps = [], 0      # (forget the burn-in's measurements)
     seen0 = int(trainer.samples_seen) if fused else 0
     t0 = time.perf_counter()
     samples = 0
@@ -265,6 +267,49 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
                 untrained_cells=untrained_cells, overflow=bool(fused and overflow), model=model)
 
 
+def run_config4(args, dev):
+    """BASELINE configs[3] as far as it can be run without its (private) data: the light-conditioned field (rfield:
+    47 -> 80 -> 80 -> 3 view MLP over [features, SH(view), SH(light)]), BARF pose refinement from perturbed cameras, the HDR
+    loss with per-view exposures, bound 2 as `--lightstage` sets it (main.py:129-143), on the procedural scene with synthetic
+    light directions / exposures (SURVEY 8d "Config 4").  One fused step per iteration (raw_ngp_amd.nerf.engine with
+    rfield + pose_opt + image_mode HDR); timed like the headline: K steps between synchronisations after a burn-in."""
+    from raw_ngp_amd.nerf import pose as P
+    torch.manual_seed(0)
+    iters = 3000
+    opt = Options(bound=2.0, num_rays=args.rays, iters=iters, rfield=True, pose_opt="barf", noise=0.03, image_mode="HDR",
+                  background="black")
+    views, res = 40, 200
+    data = SyntheticDataset(opt, dev, "train", n_views=views, H=res, W=res)
+    data.ldirs = torch.from_numpy(P.synthetic_light_dirs(views)).to(dev)
+    data.exposures = torch.from_numpy(np.random.default_rng(5).choice([0.5, 1.0, 2.0], views).astype(np.float32)).to(dev)
+    # what a camera with that exposure records of the same radiance: colour x exposure, clipped at white
+    data.images[..., :3] = (data.images[..., :3].float() * data.exposures.view(-1, 1, 1, 1)).clamp(max=255).to(torch.uint8)
+    trainer = FusedTrainer(opt, NeRFNetwork(opt), data, device=dev, seed=args.seed)
+    co = trainer.pose_optimizer
+    err0 = P.pose_error(co.get_refined_poses(data.poses), data.poses)
+    moving = int(opt.end_annealing * iters)             # the cameras move while annealing < end_annealing
+    out = {}
+    for tag, upto in (("cameras_moving", moving // 2), ("cameras_frozen", iters - args.steps)):
+        trainer.train(upto - trainer.global_step - args.warmup)
+        trainer.train(args.warmup)
+        torch.cuda.synchronize()
+        seen0 = int(trainer.samples_seen)
+        t0 = time.perf_counter()
+        trainer.train(args.steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[tag] = {"at_step": upto, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                    "value": round(args.rays * args.steps / dt, 1), "unit": "rays/s",
+                    "samples_per_step": round((int(trainer.samples_seen) - seen0) / args.steps)}
+    err1 = P.pose_error(co.get_refined_poses(data.poses), data.poses)
+    out.update({"workload": f"configs[3] stand-in: rfield + barf + HDR loss, bound 2, {args.rays} rays/batch, {views} views of "
+                            f"{res}x{res} (synthetic light directions, exposures, 0.03 se(3) noise), {iters} iterations",
+                "pose_error_deg_dist_start": [round(float(v), 4) for v in err0],
+                "pose_error_deg_dist_end": [round(float(v), 4) for v in err1],
+                "loss": round(float(trainer.loss), 6), "arena_overflow": int(trainer.arena.counter[1]) > trainer.cap})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,7 +365,7 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
     ap.add_argument("--autograd", action="store_true", help="per-op autograd path (Trainer) instead of the fused step")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the two secondary rows (reference defaults: black background; bound 2 + black)")
+                    help="skip the secondary rows (reference defaults: black background; bound 2 + black; the configs[3] stand-in)")
     args = ap.parse_args()
     if args.burnin < 0:
         args.burnin = max((args.psnr_iters or 5000) - args.warmup - args.steps, 300)
@@ -370,6 +415,9 @@ def main():
                                "psnr": None if r2["psnr"] is None else round(float(r2["psnr"]), 3),
                                "arena_overflow": r2["overflow"], "untrained_cells": r2["untrained_cells"]}
             del r2
+        if world == 1 and not (args.autograd or args.torch_mlp):
+            torch.cuda.empty_cache()
+            secondary["config4"] = run_config4(args, dev)
     if rank == 0:
         launches, units, ksec = probe
         roof = None

@@ -628,8 +628,7 @@ class FusedTrainer:
         # one GPU, plain field: the MLP's weight-gradient reduction (+ Adam on the MLP weights + their entries in the f16
         # operand image) rides along with the table backward's fill launch instead of being a kernel of its own
         # (exchange step: the same passenger without Adam -- it leaves the weight gradients in the flat gradient buffer)
-        ride = not self.rfield and not bool(getattr(opt, "aux_stream", False)) and \
-            os.environ.get("NGP_MLP_TAIL_RIDES", "1") != "0"
+        ride = self.rides_mlp_tail()
         mlp_adam = (self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps) if split else None
         mlp_tail = (self.cap, opt.loss_scale, self.dws, self.ws_mlp, mlp_adam, self.mlp_image if split else None) if ride else None
         self.table_backward_symbol = "ngp_x_grid_backward_binned_apply" + ("_mlp" if ride else "")   # (what bench.py times)
@@ -742,6 +741,11 @@ class FusedTrainer:
         for part in self.graphs[key]:
             part()
 
+    def rides_mlp_tail(self):
+        """Does the MLP's weight-gradient reduction ride on the table backward's fill launch (ngp_x_..._apply_mlp)?"""
+        return not self.rfield and not bool(getattr(self.opt, "aux_stream", False)) and \
+            os.environ.get("NGP_MLP_TAIL_RIDES", "1") != "0"
+
     def _loose_collectives(self, timed):
         """Do this step's collectives stay outside its graph?  Yes when their carrier cannot be captured (gloo,
         torch.distributed) and on the steps bench.py times (HIP events around them)."""
@@ -765,6 +769,10 @@ class FusedTrainer:
         parts, run = [], []
 
         def flush():
+            if run and len(run) <= 2 and all(lane == "main" for _, _, lane in run):
+                # (one or two launches between two eager ops: launched directly -- a graph launch costs more than it saves)
+                parts.extend(op for _, op, _ in run)
+                run.clear()
             if run:
                 g, seg = torch.cuda.CUDAGraph(), list(run)
                 with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):

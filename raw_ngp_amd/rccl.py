@@ -87,8 +87,16 @@ class Communicator:
         n = buf.numel() // self.world
         return n, buf.data_ptr(), buf.data_ptr() + self.rank * n * buf.element_size()
 
+    def _op(self, op):
+        # one rank: the average of one contribution is the contribution.  RCCL implements ncclAvg as a pre-multiplied sum,
+        # which on a one-rank communicator is a pass of its own over the buffer (oneRankReduce<FuncPreMulSum>: 50 us for the
+        # 48.8 MB table gradient) -- work that exists on no multi-rank communicator, where the factor is folded into the
+        # reduction's first load.  ncclSum in place is the identity and launches nothing.
+        return ncclSum if (op == ncclAvg and self.world == 1) else op
+
     def reduce_scatter_(self, buf, op=ncclAvg):
         """In place: afterwards buf[rank * n : (rank + 1) * n] holds the reduction of that shard over all ranks."""
+        op = self._op(op)
         n, base, mine = self._shard(buf)
         with torch.cuda.device(self.device):
             _check(lib().ncclReduceScatter(base, mine, n, _DTYPES[buf.dtype], op, self.comm, self._stream()), "ncclReduceScatter")
@@ -102,6 +110,7 @@ class Communicator:
     def all_reduce_(self, *bufs, op=ncclAvg):
         """In place; several buffers go out as one group (one launch)."""
         L = lib()
+        op = self._op(op)
         with torch.cuda.device(self.device):
             if len(bufs) > 1:
                 _check(L.ncclGroupStart(), "ncclGroupStart")
