@@ -205,8 +205,15 @@ int ngp_x_build_occupancy_index(const uint8_t *grid, uint32_t C, uint32_t H, uin
  *   but a value SMALLER than the truth is an error the kernels cannot detect).
  * grad is [L][grad_stride][2] (grad_stride = B for the reference layout); B_dev: optional device int32 with
  * the number of live points (clamped to B; launch geometry and workspace are sized by B).
- * Does not compute grad_inputs (ngp_x_grid_input_backward does). */
+ * Does not compute grad_inputs (ngp_x_grid_input_backward does).
+ * Two record layouts exist behind the same calls.  Tile-local (the default; up to 2048 x 512 samples and 128 chunks per
+ * level): every fill workgroup writes its records, sorted by chunk, into a region of its own and leaves a directory; nothing
+ * is counted, scanned or reserved across workgroups.  Global bins (NGP_BINNED_LOCAL=0, or beyond those limits): one record
+ * stream per chunk, sized by a counting pass + scan, filled through per-chunk cursors.  ngp_x_grid_backward_binned_counts
+ * tells which one a call of this shape takes: 1 = the apply half needs the counts (prepare stage 0, or stage 1 + a
+ * counting forward + stage 2), 0 = it only needs the header reset of prepare stage 1 (counting and scanning are wasted). */
 size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, uint32_t n_rows_total);
+int ngp_x_grid_backward_binned_counts(uint32_t B, uint32_t L, uint32_t n_rows_total, uint32_t max_level_rows);
 int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,
                                       float *grad_embeddings, const int32_t *B_dev, uint32_t B,
                                       uint32_t grad_stride, uint32_t L, uint32_t max_level,

@@ -115,6 +115,8 @@ def load():
         lib.ngp_abi_version.restype = ctypes.c_int
         lib.ngp_x_grid_backward_workspace_bytes.argtypes = [_u, _u, _u]
         lib.ngp_x_grid_backward_workspace_bytes.restype = ctypes.c_size_t
+        lib.ngp_x_grid_backward_binned_counts.argtypes = [_u, _u, _u, _u]
+        lib.ngp_x_grid_backward_binned_counts.restype = ctypes.c_int
         lib.ngp_x_occupancy_index_bytes.argtypes = [_u, _u]
         lib.ngp_x_occupancy_index_bytes.restype = ctypes.c_size_t
         lib.ngp_x_density_grid_workspace_bytes.argtypes = [_u]
@@ -136,7 +138,7 @@ def load():
 
 
 def declared_symbols():
-    return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes",
+    return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes", "ngp_x_grid_backward_binned_counts",
             "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes", "ngp_x_mlp_rf_image_bytes",
             "ngp_x_mlp_rf_backward_workspace_bytes", "ngp_x_occupancy_index_bytes",
             "ngp_x_density_grid_workspace_bytes"] + list(_SIGNATURES)
@@ -380,6 +382,15 @@ class _GridBackend:
     @staticmethod
     def backward_workspace_bytes(B, L, rows):
         return int(load().ngp_x_grid_backward_workspace_bytes(B, L, rows))
+
+    @staticmethod
+    def backward_needs_counts(B, L, offsets):
+        """Does grid_backward_binned_apply on a workspace of this shape need the per-chunk record counts (global-bins
+        layout: a counting forward pass + scan), or only prepare's header reset (tile-local layout)?"""
+        rows = int(offsets[-1]) if not torch.is_tensor(offsets) else None
+        if rows is None:
+            rows = int(offsets[-1].item())
+        return bool(load().ngp_x_grid_backward_binned_counts(B, L, rows, _GridBackend._max_level_rows(offsets)))
 
     @staticmethod
     def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):

@@ -54,10 +54,34 @@ __host__ __device__ inline WsLayout ws_layout(void *ws, uint32_t n_chunks_max, s
     return w;
 }
 
+// ---- tile-local layout of the records (bin_fill_local_kernel / bin_reduce_local_kernel) --------------------------------
+// A fill workgroup (kFillTile samples of one level) owns a fixed region of kRegion record slots, writes its records
+// there sorted by chunk -- every chunk's run starts at a multiple of four slots and is padded to one with null records (key 0,
+// value 0), so that the reduce reads whole quads with 16-byte loads -- and leaves one directory word per chunk:
+// dir[chunk][tile] = first slot | count << 16.  Nothing is
+// coordinated across workgroups (no cursors, no counting pass, no scan); the reduce workgroup of a chunk collects its runs
+// from every tile through the directory column of that chunk.
+constexpr uint32_t kMaxTiles = 2048;     // fill tiles per call the tile-local reduce can index (B <= 1 Mi samples)
+__host__ __device__ inline uint32_t ws_tiles(uint32_t B) { return (B + kFillTile - 1) / kFillTile; }
+constexpr uint32_t kLocalBins = 128;                          // chunks per level the tile-local layout is sized for
+constexpr uint32_t kRegion = kFillTile * 8 + 4 * kLocalBins;  // 8 records per sample + up to 3 slots of padding per chunk
+__host__ __device__ inline size_t ws_rec_cap_local(uint32_t B, uint32_t L) { return (size_t)ws_tiles(B) * L * kRegion; }
+// the directory sits behind the key stream (4-byte aligned: the key stream has an even number of entries)
+__host__ __device__ inline uint32_t *ws_dir(const WsLayout &w, size_t rec_cap)
+{
+    return reinterpret_cast<uint32_t *>(const_cast<uint16_t *>(w.keys) + ((rec_cap + 1) & ~(size_t)1));
+}
+
 static inline size_t ws_bytes(uint32_t B, uint32_t L, uint32_t n_chunks_max)
 {
     const size_t head = (size_t)(kMaxLevels + 4 + 4 * (size_t)n_chunks_max + 2 + 4) * 4;
-    return head + ws_rec_cap(B, L, n_chunks_max) * 12 + 64;   // (10 bytes per record are used: float2 + uint16)
+    const size_t rec = ws_rec_cap(B, L, n_chunks_max) > ws_rec_cap_local(B, L) ? ws_rec_cap(B, L, n_chunks_max)
+                                                                               : ws_rec_cap_local(B, L);
+    // (10 bytes per record are used: float2 + uint16; the slack holds the tile-local layout's directory)
+    const size_t dir = (size_t)n_chunks_max * ws_tiles(B) * 4;
+    const size_t need_local = ws_rec_cap_local(B, L) * 10 + dir + 16;
+    const size_t need = rec * 12 > need_local ? rec * 12 : need_local;
+    return head + need + 64;
 }
 
 template <int CTRL>

@@ -22,6 +22,8 @@
 //
 // Result: the reference's sums, each rounded once (resolution 2^-37 of the largest contribution) instead of
 // once per atomic in hardware order; bitwise reproducible except for the few multi-segment chunks.
+#include <type_traits>
+
 #include "binned_common.hpp"
 #include "mlp_common.hpp"
 
@@ -152,6 +154,26 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t L, WsLayout w, 
     bin_scan_block(L, w, single_segment);
 }
 
+// Diagnostic build only (-DNGP_STAMP_FILL, never shipped; tools/fill_stamps.py): s_memtime at the phase boundaries of the
+// fill kernel as seen by thread 0 (wave 0, the wave that scans), summed per level.  No stamp executes in the product build.
+#ifdef NGP_STAMP_FILL
+__device__ unsigned long long ngp_dbg_fill_stamps[kMaxLevels][8];
+#define NGP_FILL_STAMP_DECL unsigned long long st_prev = 0
+#define NGP_FILL_STAMP(i)                                                                                  \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        unsigned long long st_now;                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); \
+        if (threadIdx.x == 0 && (i) > 0) atomicAdd(&ngp_dbg_fill_stamps[level][(i)], st_now - st_prev);    \
+        if (threadIdx.x == 0 && (i) == 0) atomicAdd(&ngp_dbg_fill_stamps[level][0], 1ull);                 \
+        st_prev = st_now;                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
+#else
+#define NGP_FILL_STAMP_DECL
+#define NGP_FILL_STAMP(i)
+#endif
+
 // ------------------------------------------------------------------ fill
 // One workgroup = 512 samples of one level.  Records (row-in-chunk, w * g.x, w * g.y) are sorted by chunk inside the
 // workgroup (LDS) and leave it as two contiguous streams per chunk: float2 payloads and uint16 keys (10 bytes a record).
@@ -185,11 +207,14 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     const uint32_t level = item / ntiles;
     const uint32_t b0 = (item - level * ntiles) * kFillTile;
     if (b0 >= B) return;
+    NGP_FILL_STAMP_DECL;
+    NGP_FILL_STAMP(0);
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
     const uint32_t first = w.chunk_base[level];
     const uint32_t nbins = w.chunk_base[level + 1] - first;
     for (uint32_t i = threadIdx.x; i < nbins; i += kFillBlock) hist[i] = 0;
     __syncthreads();
+    NGP_FILL_STAMP(1);   // header words + histogram zeroed
 
     static_assert(kFillTile == kFillBlock, "one sample per lane");
     const uint32_t b = b0 + threadIdx.x;
@@ -205,6 +230,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     }
     float2 gr = make_float2(0.0f, 0.0f);
     if (live) gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * gstride + b];
+    NGP_FILL_STAMP(2);   // position and gradient have arrived
     const bool nan = !(gr.x == gr.x && gr.y == gr.y);
     // a sample whose gradient is exactly zero at this level (behind the compositor's early stop: a third of the samples
     // late in training) contributes nothing: no weights, and no records unless its run has a non-zero member
@@ -248,7 +274,9 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
             pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
         }
     }
+    NGP_FILL_STAMP(3);   // weights, run sums, hashes, histogram atomics (wave 0)
     __syncthreads();
+    NGP_FILL_STAMP(4);   // ... until the last wave is there
 
     // wave 0: exclusive scan of hist -> staging offsets (lbase); reserve the global ranges with one atomic per non-empty
     // bin -- issued here, consumed after the next barrier, so their round trip overlaps the other waves' staging
@@ -292,7 +320,18 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
             if (lane == 63u) s_total = inc;
         }
     }
+#ifndef NGP_STAMP_FILL
     __syncthreads();
+#else
+    {   // (the stamp's vmcnt(0) would wait for the cursor atomics here: stamp without it)
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long st_now;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory");
+        if (threadIdx.x == 0) atomicAdd(&ngp_dbg_fill_stamps[level][5], st_now - st_prev);   // scan + cursor atomics issued
+        st_prev = st_now;
+        __syncthreads();
+    }
+#endif
     if (threadIdx.x < 64u && fast) {
         const uint32_t i0 = 2u * lane, i1 = i0 + 1u;
         if (i0 < nbins) delta[i0] = g0 - run0;
@@ -318,6 +357,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
     if ((threadIdx.x & 63u) == 0 && __float_as_uint(gmax) > __builtin_nontemporal_load(&w.chunk_base[kMaxLevels + 1]))
         atomicMax(&w.chunk_base[kMaxLevels + 1], __float_as_uint(gmax));
     __syncthreads();
+    NGP_FILL_STAMP(6);   // cursor round trip + staging, until the last wave is there
     // consecutive lanes -> consecutive records of one chunk (until the chunk changes): contiguous 8-byte and 2-byte stores
     const uint32_t total = s_total;
     for (uint32_t j = threadIdx.x; j < total; j += kFillBlock) {
@@ -326,6 +366,179 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
         w.vals[dst] = stage_val[j];
         w.keys[dst] = (uint16_t)(key & (kChunkRows - 1u));
     }
+    NGP_FILL_STAMP(7);   // stream-out (stores retired)
+}
+
+// ------------------------------------------------------------------ fill, tile-local layout
+// The same traversal, staging and record format -- but the workgroup writes into a region of its own (slot j of the
+// staging area goes to slot j of the region: the stream-out is a plain copy) and publishes one directory word per chunk.
+// No cursor atomics (their issue and round trip were half of a workgroup's life: tools/fill_stamps.py), no counting pass in
+// the encoder's forward, no scan; zero-gradient runs still emit nothing.
+// LDS: hist[nbins] | lbase[nbins] | stage_val[kRegion] float2 | stage_key[kRegion] u16
+__global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
+    const float *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ B_dev, uint32_t B_cap, uint32_t gstride, uint32_t ntiles, uint32_t nbins_cap, LevelRes lv,
+    uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w, uint32_t *__restrict__ dir, uint32_t n_tail,
+    MlpDwReduce tail)
+{
+    extern __shared__ uint32_t lds[];
+    if (blockIdx.x < n_tail) {   // passengers: the tiny MLPs' weight-gradient reduction (see bin_fill_kernel)
+        float(*part)[64] = reinterpret_cast<float(*)[64]>(lds) + 4 * (threadIdx.x >> 8);
+        mlp_reduce_dw_group(tail, blockIdx.x * 2u + (threadIdx.x >> 8), threadIdx.x & 255u, part);
+        return;
+    }
+    uint32_t *hist = lds, *lbase = lds + nbins_cap;
+    float2 *stage_val = reinterpret_cast<float2 *>(lds + 2 * nbins_cap);            // 8-byte aligned: nbins_cap % 4 == 0
+    uint16_t *stage_key = reinterpret_cast<uint16_t *>(stage_val + kRegion);
+    __shared__ uint32_t s_total;
+    __shared__ float s_wmax[kFillBlock / 64];
+
+    const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
+    const uint32_t item = xcd_remap(blockIdx.x - n_tail, gridDim.x - n_tail);
+    const uint32_t level = item / ntiles, tile = item - level * ntiles;
+    const uint32_t b0 = tile * kFillTile;
+    if (b0 >= B) return;
+    const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
+    // the level's chunks: the table's geometry, no workspace header involved
+    uint32_t first = 0;
+    for (uint32_t l = 0; l < level; l++) first += ((uint32_t)(offsets[l + 1] - offsets[l]) + kChunkRows - 1) >> kChunkShift;
+    const uint32_t nbins = (g.T + kChunkRows - 1) >> kChunkShift;
+    NGP_FILL_STAMP_DECL;
+    NGP_FILL_STAMP(0);
+    const uint32_t b = b0 + threadIdx.x;
+    // position and gradient do not depend on each other: both requests leave before anything waits
+    float x[3] = {0.f, 0.f, 0.f};
+    float2 gr = make_float2(0.0f, 0.0f);
+    if (b < B) {
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) x[d] = inputs[(size_t)b * 3 + d];
+        gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * gstride + b];
+    }
+    for (uint32_t i = threadIdx.x; i < nbins; i += kFillBlock) hist[i] = 0;
+    __syncthreads();
+    NGP_FILL_STAMP(1);   // (diagnostic build: the stamp waits for the loads -> phase 1 = header + loads)
+
+    uint32_t rows[8], pos[8];
+    float vx[8], vy[8];
+    Cell<3> cl = {};
+    const bool live = b < B && locate<3>(x, g.res, align_corners, interp, cl);
+    if (!live) gr = make_float2(0.0f, 0.0f);
+    const bool nan = !(gr.x == gr.x && gr.y == gr.y);
+    const bool active = live && (gr.x != 0.0f || gr.y != 0.0f);
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; corner++) vx[corner] = vy[corner] = 0.0f;
+    if (active) {
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; corner++) {
+            float wgt = 1.0f;
+#pragma unroll
+            for (uint32_t d = 0; d < 3; d++) wgt *= (corner & (1u << d)) ? cl.f[d] : 1.0f - cl.f[d];
+            vx[corner] = wgt * gr.x;
+            vy[corner] = wgt * gr.y;
+        }
+    }
+    bool emit = active;
+    if (mergeable(g, w)) {   // run merging, as in bin_fill_kernel
+        uint32_t dist;
+        const bool tail_lane = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
+        const RunFlags flags = run_flags(dist);
+        const float active_in_run = run_sum(active ? 1.0f : 0.0f, flags);
+        emit = tail_lane && active_in_run > 0.0f;
+        if (__ballot(active) != 0ull) {
+#pragma unroll
+            for (uint32_t corner = 0; corner < 8; corner++) {
+                vx[corner] = run_sum(vx[corner], flags);
+                vy[corner] = run_sum(vy[corner], flags);
+            }
+        }
+    }
+    if (emit) {
+        const AxisTerms<3> terms = axis_terms<3>(g, cl);
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; corner++) {
+            rows[corner] = row_from_terms<3>(g, terms, corner);
+            pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
+        }
+    }
+    NGP_FILL_STAMP(3);
+    __syncthreads();
+    NGP_FILL_STAMP(4);
+
+    // exclusive scan of the histogram (each chunk's count rounded up to a quad) -> staging offsets = offsets inside the
+    // tile's region; the directory words leave right here (plain stores, nothing waits for them) and the up to three
+    // slots of padding behind each run become null records.  Wave 0 scans the level's <= 128 bins, two per lane.
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint32_t *dcol = dir + (size_t)first * ntiles + tile;   // dir[chunk][tile]
+    if (wid == 0) {
+        const uint32_t i0 = 2u * lane, i1 = i0 + 1u;
+        const uint32_t n0 = i0 < nbins ? hist[i0] : 0u, n1 = i1 < nbins ? hist[i1] : 0u;
+        const uint32_t q0 = (n0 + 3u) & ~3u, q1 = (n1 + 3u) & ~3u;
+        uint32_t inc = q0 + q1;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        const uint32_t run0 = inc - (q0 + q1), run1 = run0 + q0;
+        if (i0 < nbins) {
+            lbase[i0] = run0;
+            dcol[(size_t)i0 * ntiles] = run0 | (n0 << 16);
+            for (uint32_t k = n0; k < q0; k++) {
+                stage_key[run0 + k] = 0;
+                stage_val[run0 + k] = make_float2(0.f, 0.f);
+            }
+        }
+        if (i1 < nbins) {
+            lbase[i1] = run1;
+            dcol[(size_t)i1 * ntiles] = run1 | (n1 << 16);
+            for (uint32_t k = n1; k < q1; k++) {
+                stage_key[run1 + k] = 0;
+                stage_val[run1 + k] = make_float2(0.f, 0.f);
+            }
+        }
+        if (lane == 63u) s_total = inc;
+    }
+    NGP_FILL_STAMP(5);   // scan + directory stores (retired)
+    __syncthreads();
+
+    float gmax = nan ? __uint_as_float(0x7f800000u) : 0.0f;   // NaN -> inf
+    if (emit) {
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; corner++) {
+            gmax = fmaxf(gmax, fmaxf(fabsf(vx[corner]), fabsf(vy[corner])));
+            const uint32_t slot = lbase[rows[corner] >> kChunkShift] + pos[corner];
+            stage_key[slot] = (uint16_t)(rows[corner] & (kChunkRows - 1u));
+            stage_val[slot] = make_float2(vx[corner], vy[corner]);
+        }
+    }
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, d, 64));
+    if (lane == 0) s_wmax[wid] = gmax;
+    __syncthreads();
+    // largest |gradient| of the call -> fixed-point scale of the reduce kernel: one word for the whole grid, touched by one
+    // lane per workgroup and only when the workgroup would raise it.  The current value is read with a device-scope atomic
+    // load: a plain (or "non-temporal") load of this uniform address becomes a scalar load, and the scalar cache never
+    // sees the other workgroups' atomics -- every wave then believes the word is still zero and the kernel degenerates
+    // into 50 000 serialised same-address atomics (600 us instead of 100).
+    if (threadIdx.x == 0) {
+        float m = s_wmax[0];
+#pragma unroll
+        for (uint32_t k = 1; k < kFillBlock / 64; k++) m = fmaxf(m, s_wmax[k]);
+        uint32_t *word = &w.chunk_base[kMaxLevels + 1];
+        if (__float_as_uint(m) > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(word, __float_as_uint(m));
+    }
+    NGP_FILL_STAMP(6);
+    // the region is the staging area, slot for slot: 16-byte stores of two payloads, 8-byte stores of four keys
+    const uint32_t total = s_total;
+    const size_t region = ((size_t)level * ntiles + tile) * kRegion;   // (kRegion: a multiple of 4 records)
+    float4 *dv = reinterpret_cast<float4 *>(w.vals + region);
+    const float4 *sv = reinterpret_cast<const float4 *>(stage_val);
+    for (uint32_t j = threadIdx.x; j < total / 2u; j += kFillBlock) dv[j] = sv[j];      // (total is a multiple of 4)
+    uint2 *dk = reinterpret_cast<uint2 *>(w.keys + region);
+    const uint2 *sk = reinterpret_cast<const uint2 *>(stage_key);
+    for (uint32_t j = threadIdx.x; j < total / 4u; j += kFillBlock) dk[j] = sk[j];
+    NGP_FILL_STAMP(7);
 }
 
 // ------------------------------------------------------------------ reduce
@@ -340,18 +553,39 @@ struct AdamArgs {
 // MODE 0: grad[chunk] += sums   1: Adam on the chunk's rows (no gradient written)   2: grad[chunk] = sums, zeros included
 // MODE 3: as 2, but the gradient is stored as bfloat16 (round to nearest even): the data-parallel wire format
 // (modes 1 and 2 need one segment per chunk and visit every chunk, also the ones without records)
-template <int MODE>
-__global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
+// LOCAL: the records live in per-tile regions (bin_fill_local_kernel); the chunk's runs are found through its directory
+// column.  One workgroup per chunk in every mode (the += of mode 0 needs no atomics then).
+struct LocalRecords {
+    const uint32_t *dir = nullptr;    // [n_chunks][ntiles]: first slot | count << 16
+    const int32_t *B_dev = nullptr;
+    uint32_t B_cap = 0, ntiles = 0;
+};
+
+template <int MODE, bool LOCAL = false>
+__global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
                                                                  float *__restrict__ grad_table, uint32_t L, WsLayout w,
-                                                                 AdamArgs opt)
+                                                                 AdamArgs opt, LocalRecords loc = LocalRecords{})
 {
-    constexpr bool ADAM = MODE == 1, ALL = MODE != 0;
+    constexpr bool ADAM = MODE == 1, ALL = MODE != 0 || LOCAL;
     __shared__ unsigned long long acc[kChunkRows * 2];   // 64 KiB: int64 fixed-point sums, [row][channel]
     __shared__ uint32_t s_chunk, s_level;
     __shared__ uint32_t s_base[kMaxLevels + 1];
+    __shared__ uint32_t s_pref[LOCAL ? kMaxTiles + 1 : 1], s_wsum[kReduceBlock / 64];
+    __shared__ uint16_t s_start[LOCAL ? kMaxTiles : 1];
     // header words the whole workgroup needs: fetched once, side by side (chains of dependent global loads -- a binary
     // search, a level walk -- cost more than the chunk's arithmetic)
-    if (threadIdx.x <= L) s_base[threadIdx.x] = w.chunk_base[threadIdx.x];
+    if (LOCAL) {   // the chunks of each level follow from the table's geometry
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (uint32_t l = 0; l < L; l++) {
+                s_base[l] = run;
+                run += ((uint32_t)(offsets[l + 1] - offsets[l]) + kChunkRows - 1) >> kChunkShift;
+            }
+            s_base[L] = run;
+        }
+    } else if (threadIdx.x <= L) {
+        s_base[threadIdx.x] = w.chunk_base[threadIdx.x];
+    }
     for (uint32_t i = threadIdx.x; i < kChunkRows * 2; i += kReduceBlock) acc[i] = 0ull;
     __syncthreads();
     const uint32_t n_chunks = s_base[L];
@@ -381,14 +615,17 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     }
     __syncthreads();
     const uint32_t chunk = s_chunk;
-    const uint32_t reserved = w.count[chunk];   // records counted for the chunk (what the segments were cut from)
-    const uint32_t cnt = w.cursor[chunk];       // records the fill kernel really wrote (zero-gradient runs emit none)
-    const uint32_t n_seg = w.seg_base[chunk + 1] - w.seg_base[chunk];
-    const uint32_t seg_len = n_seg == 1 ? max(reserved, 1u) : (reserved > kSegBig ? kSegBig : kSeg);
-    const uint32_t seg = item - w.seg_base[chunk];
-    const uint32_t beg = w.offset[chunk] + seg * seg_len;                  // multiple of 4 records
-    const uint32_t end = min(w.offset[chunk] + cnt, beg + seg_len);
-    if (!ALL && beg >= end) return;   // empty chunk: nothing to add (modes 1 and 2 still have rows to write)
+    uint32_t n_seg = 1, beg = 0, end = 0;
+    if constexpr (!LOCAL) {
+        const uint32_t reserved = w.count[chunk];   // records counted for the chunk (what the segments were cut from)
+        const uint32_t cnt = w.cursor[chunk];       // records the fill kernel really wrote (zero-gradient runs emit none)
+        n_seg = w.seg_base[chunk + 1] - w.seg_base[chunk];
+        const uint32_t seg_len = n_seg == 1 ? max(reserved, 1u) : (reserved > kSegBig ? kSegBig : kSeg);
+        const uint32_t seg = item - w.seg_base[chunk];
+        beg = w.offset[chunk] + seg * seg_len;                  // multiple of 4 records
+        end = min(w.offset[chunk] + cnt, beg + seg_len);
+        if (!ALL && beg >= end) return;   // empty chunk: nothing to add (modes 1 and 2 still have rows to write)
+    }
 
     // which level does this chunk belong to, and where does it start in the table
     const uint32_t level = s_level;
@@ -397,6 +634,21 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
     const uint32_t rows_here = min(kChunkRows, T - row0);
     // fused variant: the optimiser state of this lane's rows is requested now, so that its latency hides behind the
     // record streaming (it does not depend on the gradient)
+    // tile-local records: the chunk's directory column is requested first -- in front of the optimiser state, whose 96 KiB
+    // per workgroup would otherwise have to arrive before the (in-order) directory words count as returned
+    constexpr uint32_t kDirPerLane = LOCAL ? kMaxTiles / kReduceBlock : 1;
+    uint32_t dirw[kDirPerLane];
+    uint32_t tiles = 0;
+    if constexpr (LOCAL) {
+        const uint32_t Bn = loc.B_dev ? min((uint32_t)max(loc.B_dev[0], 0), loc.B_cap) : loc.B_cap;
+        tiles = (Bn + kFillTile - 1) / kFillTile;
+        const uint32_t *dcol = loc.dir + (size_t)chunk * loc.ntiles;
+#pragma unroll
+        for (uint32_t q = 0; q < kDirPerLane; q++) {
+            const uint32_t t = threadIdx.x * kDirPerLane + q;
+            dirw[q] = t < tiles ? dcol[t] : 0u;
+        }
+    }
     constexpr uint32_t kPer = kChunkRows / kReduceBlock;
     float2 pp[kPer], mm[kPer], vv[kPer];
     const size_t adam_base = (size_t)(uint32_t)offsets[level] + row0;
@@ -437,6 +689,102 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
         atomicAdd(&acc[row * 2], (unsigned long long)qx);
         atomicAdd(&acc[row * 2 + 1], (unsigned long long)qy);
     };
+    if constexpr (LOCAL) {
+        // The chunk's records: one run per tile, found through the directory column dir[chunk][0 .. tiles) -- fetched above
+        // (one round trip), kept in LDS as a prefix of run lengths (in quads) + the runs' first slots; after that every load
+        // is independent of every other.  Runs start at multiples of four slots and are padded with null records: a quad
+        // is one 8-byte load of keys and two 16-byte loads of payloads, like the streams of the global-bins layout.
+        const size_t level_region = (size_t)level * loc.ntiles * kRegion;
+        constexpr uint32_t kPerLane = kDirPerLane;   // consecutive tiles per lane in the scan
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kPerLane; q++) sum += ((dirw[q] >> 16) + 3u) >> 2;
+        const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        uint32_t inc = sum;
+#pragma unroll
+        for (uint32_t dd = 1; dd < 64u; dd <<= 1) {
+            const uint32_t up = __shfl_up(inc, dd, 64);
+            if (ln >= dd) inc += up;
+        }
+        if (ln == 63u) s_wsum[wv] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (uint32_t k = 0; k < wv; k++) run += s_wsum[k];
+#pragma unroll
+        for (uint32_t q = 0; q < kPerLane; q++) {
+            const uint32_t t = threadIdx.x * kPerLane + q;
+            s_pref[t] = run;
+            s_start[t] = (uint16_t)(dirw[q] & 0xffffu);
+            run += ((dirw[q] >> 16) + 3u) >> 2;
+        }
+        if (threadIdx.x == kReduceBlock - 1) s_pref[kMaxTiles] = run;
+        __syncthreads();
+        const uint32_t Q = s_pref[kMaxTiles];   // quads of the chunk
+        const uint2 *kq = reinterpret_cast<const uint2 *>(w.keys);       // 4 keys per uint2
+        const float4 *vq = reinterpret_cast<const float4 *>(w.vals);     // 2 payloads per float4
+        auto apply_quad = [&](const uint2 &k4, const float4 &a0, const float4 &a1) {   // (null records add zero to row 0)
+            apply(k4.x & 0xffffu, a0.x, a0.y);
+            apply(k4.x >> 16, a0.z, a0.w);
+            apply(k4.y & 0xffffu, a1.x, a1.y);
+            apply(k4.y >> 16, a1.z, a1.w);
+        };
+        if (Q > 12u * tiles) {
+            // a heavy chunk (the few chunks of the coarse levels collect hundreds of records from every tile): a wave streams
+            // a run -- 256 records per load round -- two runs per turn.  (Sharing such a chunk among several workgroups was
+            // tried -- parked 64-bit sums, a ticket, the last one finishes -- and is slower: the device-scope release /
+            // acquire fences write back and invalidate a whole L2 in the middle of a kernel that streams the optimiser state.)
+            for (uint32_t t0 = wv; t0 < tiles; t0 += 2u * (kReduceBlock / 64u)) {
+                uint32_t nq[2];
+                size_t rq[2];   // first quad of the run
+                uint2 k4[2];
+                float4 a0[2], a1[2];
+#pragma unroll
+                for (uint32_t u = 0; u < 2; u++) {
+                    const uint32_t t = min(t0 + u * (kReduceBlock / 64u), kMaxTiles - 1u);
+                    nq[u] = s_pref[t + 1] - s_pref[t];
+                    rq[u] = (level_region + (size_t)t * kRegion + s_start[t]) >> 2;
+                    k4[u] = make_uint2(0, 0);
+                    a0[u] = a1[u] = make_float4(0, 0, 0, 0);
+                    if (ln < nq[u]) {
+                        k4[u] = kq[rq[u] + ln];
+                        a0[u] = vq[(rq[u] + ln) * 2];
+                        a1[u] = vq[(rq[u] + ln) * 2 + 1];
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 2; u++) {
+                    if (ln < nq[u]) apply_quad(k4[u], a0[u], a1[u]);
+                    for (uint32_t j = ln + 64u; j < nq[u]; j += 64u)   // runs longer than 256 records
+                        apply_quad(kq[rq[u] + j], vq[(rq[u] + j) * 2], vq[(rq[u] + j) * 2 + 1]);
+                }
+            }
+        } else {
+            // light chunks (the hashed levels: 10-30 records per run): a flat index over the quads of the concatenated runs,
+            // two independent quads per lane and turn; a binary search over the LDS prefix maps a quad to its tile
+            const uint32_t top = 1u << (32 - __clz(max(tiles, 2u) - 1u));   // power of two >= tiles (<= kMaxTiles)
+            auto locate_quad = [&](uint32_t v) -> size_t {   // tile = largest t with s_pref[t] <= v
+                uint32_t lo = 0;
+                for (uint32_t step = top >> 1; step >= 1; step >>= 1)
+                    if (s_pref[lo + step] <= v) lo += step;
+                return ((level_region + (size_t)lo * kRegion + s_start[lo]) >> 2) + (v - s_pref[lo]);
+            };
+            for (uint32_t v0 = threadIdx.x; v0 < Q; v0 += 2u * kReduceBlock) {
+                const uint32_t v1 = v0 + kReduceBlock;
+                const size_t qa = locate_quad(v0), qb = v1 < Q ? locate_quad(v1) : qa;
+                const uint2 ka = kq[qa];
+                const float4 a0 = vq[qa * 2], a1 = vq[qa * 2 + 1];
+                uint2 kb = make_uint2(0, 0);
+                float4 b0 = make_float4(0, 0, 0, 0), b1 = b0;
+                if (v1 < Q) {
+                    kb = kq[qb];
+                    b0 = vq[qb * 2];
+                    b1 = vq[qb * 2 + 1];
+                }
+                apply_quad(ka, a0, a1);
+                if (v1 < Q) apply_quad(kb, b0, b1);
+            }
+        }
+    }
     const uint2 *key4 = reinterpret_cast<const uint2 *>(w.keys);       // 4 keys per uint2
     const float4 *val2 = reinterpret_cast<const float4 *>(w.vals);     // 2 payloads per float4
     for (uint32_t i0 = beg + threadIdx.x * 4; i0 < end; i0 += kReduceBlock * 8) {
@@ -460,7 +808,6 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
         if (i1 + 3 < end) apply(kb.y >> 16, b1.z, b1.w);
     }
     __syncthreads();
-
     float *dst = grad_table + ((size_t)(uint32_t)offsets[level] + row0) * 2;
     auto to_float = [&](unsigned long long q) { return (float)scalbn((double)(long long)q, -k); };
     if (ADAM) {
@@ -516,6 +863,16 @@ __global__ __launch_bounds__(kReduceBlock) void bin_reduce_kernel(const int32_t 
 
 using namespace ngp;
 
+#ifdef NGP_STAMP_FILL
+extern "C" int ngp_dbg_read_fill_stamps(unsigned long long *out, int reset)
+{
+    static unsigned long long zero[kMaxLevels * 8] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ngp_dbg_fill_stamps), sizeof(zero)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ngp_dbg_fill_stamps), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 extern "C" size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, uint32_t n_rows_total)
 {
     const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
@@ -523,6 +880,17 @@ extern "C" size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, ui
 }
 
 namespace {
+// record layout: tile-local regions + directory (default) or global bins with counts, scan and cursors (NGP_BINNED_LOCAL=0,
+// more than kMaxTiles fill tiles, or a level with more than kLocalBins chunks)
+bool binned_local(uint32_t B, uint32_t nbins_cap)
+{
+    static const bool enabled = [] {
+        const char *e = getenv("NGP_BINNED_LOCAL");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && ceil_div(B, kFillTile) <= kMaxTiles && nbins_cap <= kLocalBins;
+}
+
 struct BinnedCall {
     LevelRes lv;
     WsLayout w;
@@ -551,6 +919,13 @@ int binned_setup(BinnedCall &c, const char *who, const int32_t *offsets, uint32_
     return NGP_OK;
 }
 }  // namespace
+
+extern "C" int ngp_x_grid_backward_binned_counts(uint32_t B, uint32_t L, uint32_t n_rows_total, uint32_t max_level_rows)
+{
+    const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
+    const uint32_t level_chunks = max_level_rows ? ceil_div(max_level_rows, kChunkRows) : n_chunks_max;
+    return binned_local(B, (level_chunks + 3u) & ~3u) ? 0 : 1;
+}
 
 // positions only: plan + count + scan.  in_bound > 0: `inputs` are world positions (the encoder's [0,1] mapping is
 // applied here), so this half can run as soon as the samples exist -- e.g. on another stream, before the forward pass
@@ -614,11 +989,39 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const float *g
     hipStream_t st = as_stream(stream);
     const uint32_t ft = ceil_div(B, kFillTile);
     const uint32_t n_tail = tail ? kDwGroups / 2u : 0u;   // two groups of 64 outputs per 512-lane workgroup
+    const AdamArgs opt{adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps};
+    if (binned_local(B, c.nbins_cap)) {   // (else: the global-bins layout below)
+        const size_t rec_cap = ws_rec_cap_local(B, L);
+        const WsLayout wl = ws_layout(workspace, c.n_chunks_max, rec_cap);
+        uint32_t *dir = ws_dir(wl, rec_cap);
+        const size_t lds = (size_t)c.nbins_cap * 8 + (size_t)kRegion * 10;
+        bin_fill_local_kernel<<<ft * max_level + n_tail, kFillBlock, lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft,
+                                                                              c.nbins_cap, c.lv, gridtype, align_corners != 0,
+                                                                              interp, wl, dir, n_tail,
+                                                                              tail ? *tail : MlpDwReduce{});
+        LocalRecords loc;
+        loc.dir = dir;
+        loc.B_dev = B_dev;
+        loc.B_cap = B;
+        loc.ntiles = ft;
+        // (levels >= max_level have no records: their directory columns are not read -- the reduce walks L levels only when
+        // every level was filled, otherwise max_level of them)
+        const uint32_t Lr = max_level;
+        if (fused)
+            bin_reduce_kernel<1, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+        else if (overwrite == 2)
+            bin_reduce_kernel<3, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+        else if (overwrite)
+            bin_reduce_kernel<2, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+        else
+            bin_reduce_kernel<0, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+        NGP_CHECK_LAUNCH("grid_backward_binned_apply");
+        return NGP_OK;
+    }
     bin_fill_kernel<<<ft * max_level + n_tail, kFillBlock, c.fill_lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft,
                                                                             c.nbins_cap, c.lv, gridtype, align_corners != 0,
                                                                             interp, c.w, n_tail, tail ? *tail : MlpDwReduce{});
     const uint32_t n_items_max = c.n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
-    const AdamArgs opt{adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps};
     if (fused)   // prepared with single_segment: one workgroup owns each chunk's rows
         bin_reduce_kernel<1><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
     else if (overwrite == 2)
@@ -678,8 +1081,10 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
                                                  uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
                                                  void *workspace, size_t workspace_bytes, ngp_stream_t stream)
 {
+    // (the tile-local layout needs the header reset only: stage 1)
+    const int stage = ngp_x_grid_backward_binned_counts(B, L, n_rows_total, max_level_rows) ? 0 : 1;
     const int rc = ngp_x_grid_backward_binned_prepare(inputs, 0.0f, offsets, B_dev, B, L, max_level, S, H, gridtype,
-                                                      align_corners, interp, n_rows_total, max_level_rows, 0, 0, 0, workspace,
+                                                      align_corners, interp, n_rows_total, max_level_rows, 0, 0, stage, workspace,
                                                       workspace_bytes, stream);
     if (rc != NGP_OK) return rc;
     return ngp_x_grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L, max_level, S, H,

@@ -274,6 +274,8 @@ class FusedTrainer:
         self.ws_mlp = torch.empty(mb.backward_workspace_bytes(cap), dtype=torch.uint8, device=dev)
         for slot in self.slots:         # the binned backward's bookkeeping is per ray batch (prepared with the march)
             slot.ws_grid = torch.empty(gb.backward_workspace_bytes(cap, self.L, self.rows), dtype=torch.uint8, device=dev)
+        # record layout of the binned table backward at this capacity: does it want the encoder's forward to count records?
+        self.binned_counts = gb.backward_needs_counts(cap, self.L, model.grid_encoder.offsets)
         self._image_ready = False                      # the step path expects the f16 weight image of the current weights
         self.global_step = 0
         self._groups_precaptured = False
@@ -390,7 +392,7 @@ class FusedTrainer:
         ops = [
             ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
                 ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt, cap, cap, self.L, self.L, self.S, self.H,
-                binned_workspace=slot.ws_grid, dydx=self.dydx if self.pose else None)),
+                binned_workspace=slot.ws_grid if self.binned_counts else None, dydx=self.dydx if self.pose else None)),
             ("ngp_x_grid_backward_binned_prepare", lambda: gb.grid_backward_binned_prepare(
                 None, 0.0, offsets, self.rows, cnt, cap, self.L, self.L, self.S, self.H, slot.ws_grid,
                 single_segment=fused_adam or overwrite, stage=2)),
@@ -621,7 +623,8 @@ class FusedTrainer:
         # offsets of the binned backward (the scan after the encoder's counting pass): one launch, right after the forward
         begin = ("ngp_x_step_begin", lambda: eb.step_begin(
             self.step_ctr, self.hyper, self.lr0, float(opt.iters), *self.betas, self.loss, self.samples_seen,
-            slot.arena.counter, binned_workspace=slot.ws_grid, L=self.L, n_rows_total=self.rows, single_segment=True))
+            slot.arena.counter, binned_workspace=slot.ws_grid if self.binned_counts else None, L=self.L,
+            n_rows_total=self.rows, single_segment=True))
         ops = []
         # separate Adam (data parallel, or fuse_adam off): the reduction writes every row of the gradient, so nothing
         # has to zero it and the accumulate's read disappears (TV / weight decay are added afterwards, in optimizer_step)
@@ -641,7 +644,7 @@ class FusedTrainer:
             # compositor): one kernel and one dependent-launch gap fewer on the critical path
             ar, cap = slot.arena, self.cap
             sb = (self.step_ctr, self.hyper, self.lr0, float(opt.iters), *self.betas, self.loss, self.samples_seen,
-                  ar.counter, slot.ws_grid, self.L, self.rows, True)
+                  ar.counter, slot.ws_grid if self.binned_counts else None, self.L, self.rows, True)
             field = [("ngp_x_mlp_forward_step_begin", lambda: self._mlp_forward(cap, ar.dirs, ar.ldirs, ar.counter, cap, self.sigma,
                                                                                self.rgb, step_begin=sb))
                      if o[0] == "ngp_x_mlp_forward" else o for o in field]

@@ -420,10 +420,23 @@ def test_binned_backward_with_zero_gradient_tails(lib, orc):
     cnt = torch.tensor([B, B, 0, 0], dtype=torch.int32, device="cuda")
     gb.grid_backward_binned(dev(grad), dev(x01), dev(offsets), out, cnt, B, B, L, L, S, H, ws)
     np.testing.assert_allclose(host(out), ref, rtol=2e-5, atol=2e-6)
-    # fewer records were written than reserved
+    # fewer records were written than the samples would have emitted with gradients everywhere
     n_chunks_max = rows // 4096 + L + 1
-    head = host(ws[:(68 + 2 * n_chunks_max) * 4]).view(np.uint32)
-    reserved, written = head[68:68 + n_chunks_max].sum(), head[68 + n_chunks_max:68 + 2 * n_chunks_max].sum()
+    if gb.backward_needs_counts(B, L, dev(offsets)):     # global-bins layout: per-chunk counts (reserved) and cursors (written)
+        head = host(ws[:(68 + 2 * n_chunks_max) * 4]).view(np.uint32)
+        reserved, written = head[68:68 + n_chunks_max].sum(), head[68 + n_chunks_max:68 + 2 * n_chunks_max].sum()
+    else:                                                # tile-local layout: the directory words carry the run lengths
+        def records(g):
+            out_ = torch.zeros(rows, 2, device="cuda")
+            ws_ = torch.zeros(gb.backward_workspace_bytes(B, L, rows), dtype=torch.uint8, device="cuda")
+            gb.grid_backward_binned(dev(g), dev(x01), dev(offsets), out_, cnt, B, B, L, L, S, H, ws_)
+            tiles, region = (B + 511) // 512, 512 * 8 + 4 * 128
+            head_bytes = (68 + 4 * n_chunks_max + 2) * 4
+            head_bytes += (4 - (head_bytes // 4) % 4) % 4 * 4
+            at = head_bytes + tiles * L * region * 10
+            d = host(ws_[at:at + n_chunks_max * tiles * 4]).view(np.uint32)
+            return int((d >> 16).sum())
+        written, reserved = records(grad), records(np.ones_like(grad))
     assert 0 < written < 0.85 * reserved
 
 
