@@ -56,6 +56,12 @@ PMC_TRAFFIC_BYTES_PER_SAMPLE = {"ngp_x_grid_backward_binned": 2290.0}
 PMC_FUSED_TRAFFIC_BYTES_PER_SAMPLE = 723.0
 PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 467.0
 FWD_BYTES_PER_SAMPLE = 12 + 16 * (64 + 8)      # 1164 B/sample, SURVEY.md section 8d
+# What the forward's ADDRESS STREAM can reach with the arithmetic taken away: tools/ubench/gather_lines.hip issues exactly the
+# slab forward's loads (same table, same ray-ordered samples, same level -> XCD placement) and nothing else.  Best variant
+# (8-byte gathers, 8 in flight per lane) on 139 264 samples: 54.9 us = 2.54 G samples/s, i.e. 2 953 GB/s in the forward's
+# algorithmic bytes (profiles/r03_ubench_gather_lines.txt; 3 060 GB/s at 204 800 samples).  The table is cache-resident: this,
+# not the 8 TB/s of HBM, is the kernel's ceiling -- `frac_of_line_rate` is measured against it.
+FWD_LINE_RATE_CEILING_GBPS = 2953.0
 
 # entry point(s) timed with HIP events -> (index of the samples-per-launch argument, algorithmic bytes per sample)
 ROOFLINE_KERNELS = {
@@ -450,6 +456,8 @@ def main():
             ach = per_launch * FWD_BYTES_PER_SAMPLE * probe_fwd[0] / probe_fwd[2] / 1e9
             roof_fwd = {"bound": "hbm", "kernel": fwd_symbol, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                        "line_rate_ceiling": FWD_LINE_RATE_CEILING_GBPS,
+                        "frac_of_line_rate": round(ach / FWD_LINE_RATE_CEILING_GBPS, 4),
                         "traffic": round(PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE * per_launch),
                         "launches": probe_fwd[0], "avg_us": round(probe_fwd[2] / probe_fwd[0] * 1e6, 2),
                         "bytes_per_sample": FWD_BYTES_PER_SAMPLE, "samples_per_launch": round(per_launch)}

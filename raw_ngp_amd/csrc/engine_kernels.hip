@@ -24,7 +24,7 @@ namespace ngp {
 // rides along for free and the backward needs no counting pass of its own.
 // JAC: also write d out / d x01 (gridencoder.cu:205-247) as a level-major slab dydx[level][stride][3][2] -- what the ray
 // gradients of pose refinement contract with d enc (pose_kernels.hip: ray_gradients)
-template <bool COUNT, bool JAC = false>
+template <bool COUNT, bool JAC = false, bool PAIR = true>
 __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     const float *__restrict__ xyzs, float bound, const float *__restrict__ table, const int32_t *__restrict__ offsets,
     float *__restrict__ out, float *__restrict__ inputs01, const int32_t *__restrict__ B_dev, uint32_t B_cap,
@@ -63,6 +63,8 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     // The gathers are bound by the address pipeline (one lane per clock), not by bytes: fetch the two x-neighbours of a
     // corner pair with ONE 16-byte load whenever their rows are adjacent -- always on dense levels (stride 1 along x),
     // and on hashed levels when the cell's x is even (prime_x = 1, so the two hashes differ in bit 0 only).
+    // (PAIR = false, plain 8-byte gathers: 66 us against 60 in the step -- although in tools/ubench/gather_lines.hip, where
+    // nothing but the loads is left, the unpaired stream is the faster one: 55 us against 69.)
     uint32_t row_id[8];
     float ax = 0.f, ay = 0.f;
     if (live) {
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
             wts[cb] = wb;
             row_id[ca] = ra;
             row_id[cb] = rb;
-            if (rb == ra + 1u || ra == rb + 1u) {
+            if (PAIR && (rb == ra + 1u || ra == rb + 1u)) {
                 const uint32_t lo = min(ra, rb);
                 const float4 v = *reinterpret_cast<const float4 *>(tab + (size_t)lo * 2);
                 const bool a_first = ra < rb;

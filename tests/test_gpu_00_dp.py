@@ -81,7 +81,8 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mode, wire
     d1, d2 = (one.flat[:n] - flat0[:n]).cpu(), ranks[0]["flat"][:n] - flat0[:n].cpu()
     assert float(d1.abs().max()) > 0.5 * lr
     differ = (d1 - d2).abs() > 0.01 * lr
-    clear = g1.abs() > 1e-4 * g1.abs().max()            # gradients well above the summation noise: the sign is not in doubt
-    assert float(clear.float().mean()) > 0.05
+    nz = g1[g1 != 0].abs()
+    clear = g1.abs() > 1e-2 * nz.median()                # gradients well above the summation noise: the sign is not in doubt
+    assert int(clear.sum()) > 0.3 * nz.numel() > 1000
     assert float(differ[clear].float().mean()) < (2e-2 if wire == "bf16" else 2e-3), float(differ[clear].float().mean())
     assert float(differ.float().mean()) < 0.05, float(differ.float().mean())
