@@ -474,12 +474,14 @@ int ngp_x_sample_rays_adaptive(const uint8_t *images, uint32_t V, uint32_t H, ui
                                const int32_t *prev_live, int32_t *live, uint32_t num_points, const float *view_exposure,
                                float *exposure, ngp_stream_t stream);
 /* ngp_x_composite_mse_train (exposure == NULL) / ngp_x_composite_hdr_train with the loss taken over the first n_live[0]
- * of the N ray slots only (mean over those rays; n_live == NULL: all N). */
+ * of the N ray slots only (mean over those rays; n_live == NULL: all N), plus the entropy term of train_utils.py:554-557
+ * when lambda_entropy > 0: loss += lambda_entropy * mean_rays(H(clamp(weights_sum, 1e-5, 1 - 1e-5))),
+ * H(w) = -w log2 w - (1 - w) log2(1 - w), with its gradient through weights_sum. */
 int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
-                               const float *weight, float inv_norm, const int32_t *n_live, const float *sigmas,
-                               const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
-                               float T_thresh, float *weights_sum, float *depth, float *image, float *grad_sigmas,
-                               float *grad_rgbs, float *loss_out, ngp_stream_t stream);
+                               const float *weight, float inv_norm, const int32_t *n_live, float lambda_entropy,
+                               const float *sigmas, const float *rgbs, const float *ts, const int32_t *rays, uint32_t M,
+                               uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,
+                               float *grad_sigmas, float *grad_rgbs, float *loss_out, ngp_stream_t stream);
 
 /* ---- pose refinement around the fused step (csrc/pose_kernels.hip) -----------------------------------------------
  * ngp_x_step_window   annealing = float16((step_counter[0] + step_offset) / iters) (train_utils.py:488) -> the BARF level
@@ -497,6 +499,13 @@ int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_rgb, float 
  *                     grad_xi (optional) receives that gradient */
 int ngp_x_step_window(const uint32_t *step_counter, uint32_t step_offset, double iters, float start_annealing,
                       float end_annealing, uint32_t L, float *level_w, int32_t *flags, ngp_stream_t stream);
+/* ... the BAA-NGP window (network.py:77-97): level 0 always counts, level j >= 1 ramps in like the (j - 1)-th of L - 1 levels;
+ * ngp_x_slab_window applies it to the level-major encoder slab [L][stride][2] in place: with c = the finest level whose
+ * weight is > 0, f'_l = w_l f_l + (1 - w_l) f_c (backward != 0: the adjoint, in place on the slab of feature gradients). */
+int ngp_x_step_window_baa(const uint32_t *step_counter, uint32_t step_offset, double iters, float start_annealing,
+                          float end_annealing, uint32_t L, float *level_w, int32_t *flags, ngp_stream_t stream);
+int ngp_x_slab_window(float *slab, uint32_t stride, uint32_t L, const float *level_w, const int32_t *M_dev, uint32_t M,
+                      int backward, ngp_stream_t stream);
 int ngp_x_ray_gradients(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound, const float *ddirs,
                         const float *ts, const int32_t *rays, uint32_t N, uint32_t M, float *grad_rays_o,
                         float *grad_rays_d, ngp_stream_t stream);

@@ -68,8 +68,10 @@ _SIGNATURES = {
                               _p, _p],
     "ngp_x_sample_rays_adaptive": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p,
                                    _p, _p, _p, _p, _p, _p, _u, _p, _p],
-    "ngp_x_composite_train_live": [_p, _p, _f, _p, _p, _f, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
+    "ngp_x_composite_train_live": [_p, _p, _f, _p, _p, _f, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
     "ngp_x_step_window": [_p, _u, _d, _f, _f, _u, _p, _p],
+    "ngp_x_step_window_baa": [_p, _u, _d, _f, _f, _u, _p, _p],
+    "ngp_x_slab_window": [_p, _u, _u, _p, _p, _u, _i],
     "ngp_x_ray_gradients": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_pose_gradient": [_p, _p, _p, _u, _u, _u, _f, _f, _f, _f, _p],
     "ngp_x_pose_update": [_p, _p, _p, _u, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p],
@@ -716,20 +718,29 @@ class _EngineBackend:
 
     @staticmethod
     def composite_train_live(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, n_live, sigmas, rgbs, ts, rays, M, N,
-                             T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out):
-        """composite_mse_train (exposure None) / composite_hdr_train over the first n_live[0] ray slots."""
+                             T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out, lambda_entropy=0.0):
+        """composite_mse_train (exposure None) / composite_hdr_train over the first n_live[0] ray slots (None: all), plus
+        lambda_entropy * mean entropy of the rays' accumulated opacity (train_utils.py:554-557)."""
         _call("ngp_x_composite_train_live", rays, _ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
               float(bg_const), _ptr(exposure, "f", "exposure", True), _ptr(weight, "f", "weight", True), float(inv_norm),
-              _ptr(n_live, "i", "n_live", True), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"),
+              _ptr(n_live, "i", "n_live", True), float(lambda_entropy), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"),
+              _ptr(ts, "f", "ts"),
               _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
               _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
               _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
 
     @staticmethod
-    def step_window(step_counter, step_offset, iters, start_annealing, end_annealing, L, level_w, flags=None):
-        _call("ngp_x_step_window", level_w, _ptr(step_counter, "u", "step_counter"), int(step_offset), float(iters),
-              float(start_annealing), float(end_annealing), int(L), _ptr(level_w, "f", "level_w"),
-              _ptr(flags, "i", "flags", True))
+    def step_window(step_counter, step_offset, iters, start_annealing, end_annealing, L, level_w, flags=None, baa=False):
+        """baa: the BAA-NGP weights (network.py:77-97) instead of BARF's (:99-109)."""
+        _call("ngp_x_step_window_baa" if baa else "ngp_x_step_window", level_w, _ptr(step_counter, "u", "step_counter"),
+              int(step_offset), float(iters), float(start_annealing), float(end_annealing), int(L),
+              _ptr(level_w, "f", "level_w"), _ptr(flags, "i", "flags", True))
+
+    @staticmethod
+    def slab_window(slab, stride, L, level_w, M_dev, M, backward=False):
+        """BAA-NGP blend on the level-major encoder slab, in place (backward: its adjoint on the gradient slab)."""
+        _call("ngp_x_slab_window", slab, _ptr(slab, "f", "slab"), int(stride), int(L), _ptr(level_w, "f", "level_w"),
+              _ptr(M_dev, "i", "M_dev", True), int(M), int(bool(backward)))
 
     @staticmethod
     def ray_gradients(denc, dydx, stride, L, bound, ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d):

@@ -259,6 +259,9 @@ struct HdrLoss {
     // adaptive ray batches (train_utils.py:563-564): only the first n_live[0] of the N ray slots carry rays; the loss is
     // the mean over those (NULL: all N)
     const int32_t *n_live = nullptr;
+    // entropy of the accumulated opacity (train_utils.py:554-557): loss += lambda * mean_rays(H(clamp(ws, 1e-5, 1 - 1e-5))),
+    // H(w) = -w log2 w - (1 - w) log2(1 - w); its gradient joins d loss / d weights_sum
+    float lambda_entropy = 0.0f;
 };
 
 template <int MODE>
@@ -360,6 +363,12 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
         }
         gws = -(gr * b0 + gg * b1 + gb * b2);
         gd = 0.0f;
+        if (hdr.lambda_entropy > 0.0f) {
+            const float wcl = fminf(fmaxf(wsF, 1e-5f), 1.0f - 1e-5f), kk = hdr.lambda_entropy / (float)n_rays;
+            ray_loss += kk * (-wcl * log2f(wcl) - (1.0f - wcl) * log2f(1.0f - wcl));
+            // (torch.clamp passes the gradient on [min, max], ends included)
+            if (wsF >= 1e-5f && wsF <= 1.0f - 1e-5f) gws += kk * (log2f(1.0f - wcl) - log2f(wcl));
+        }
         if (lane == 0 && in_range) ray_err[threadIdx.x >> 6] = ray_loss;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -781,15 +790,16 @@ extern "C" int ngp_x_composite_hdr_train(const float *gt_rgba, const float *bg_r
                                          float *grad_rgbs, float *loss_out, ngp_stream_t stream)
 {
     NGP_REQUIRE(exposure, "composite_hdr_train: null tensor");
-    return ngp_x_composite_train_live(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, nullptr, sigmas, rgbs, ts, rays, M,
-                                      N, T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out, stream);
+    return ngp_x_composite_train_live(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, nullptr, 0.0f, sigmas, rgbs, ts,
+                                      rays, M, N, T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out, stream);
 }
 
 extern "C" int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
-                                          const float *weight, float inv_norm, const int32_t *n_live, const float *sigmas,
-                                          const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
-                                          float T_thresh, float *weights_sum, float *depth, float *image,
-                                          float *grad_sigmas, float *grad_rgbs, float *loss_out, ngp_stream_t stream)
+                                          const float *weight, float inv_norm, const int32_t *n_live, float lambda_entropy,
+                                          const float *sigmas, const float *rgbs, const float *ts, const int32_t *rays,
+                                          uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth,
+                                          float *image, float *grad_sigmas, float *grad_rgbs, float *loss_out,
+                                          ngp_stream_t stream)
 {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(gt_rgba && rays && weights_sum && depth && image && loss_out, "composite_train_live: null tensor");
@@ -802,6 +812,8 @@ extern "C" int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_
     hdr.weight = weight;
     hdr.inv_norm = inv_norm;
     hdr.n_live = n_live;
+    NGP_REQUIRE(lambda_entropy >= 0.0f, "composite_train_live: lambda_entropy must not be negative");
+    hdr.lambda_entropy = lambda_entropy;
     composite_backward_wave_kernel<2><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
         nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, nullptr, nullptr, nullptr, M,
         N, T_thresh, grad_sigmas, grad_rgbs, loss_out, weights_sum, depth, image, hdr);

@@ -25,6 +25,9 @@ namespace ngp {
 // forms annealing from the incremented value (:488): the training step with s steps behind it sees (s + 1) / iters --
 // step_offset = 1 -- while the density-grid refresh in front of it still sees the previous step's window (s / iters; 0.0
 // before the first step, :411).
+// BAA: the BAA-NGP window (network.py:77-97): level 0 always counts, level j >= 1 ramps in like the (j - 1)-th of L - 1 levels
+// (alpha is scaled by L - 1 = grid_mlp.dim_out - 1, :78-83); what the window does to the features is slab_window_kernel's job
+template <bool BAA>
 __global__ void step_window_kernel(const uint32_t *__restrict__ step_counter, uint32_t step_offset, double iters,
                                    float start, float end, uint32_t L, float *__restrict__ level_w,
                                    int32_t *__restrict__ flags)
@@ -35,17 +38,60 @@ __global__ void step_window_kernel(const uint32_t *__restrict__ step_counter, ui
     // `if end == 0: end = 1e-12` (network.py:103-104); end - start is python float arithmetic, cast to float16 as a whole
     const double span = (end == 0.0f ? 1e-12 : (double)end) - (double)start;
     const _Float16 e16 = (_Float16)(double)end;                     // the pose-step test uses opt.end_annealing as given
-    float alpha = (float)(((ann - (_Float16)(double)start) / (_Float16)span) * (_Float16)(float)L);
+    const uint32_t Lw = BAA ? L - 1u : L;
+    float alpha = (float)(((ann - (_Float16)(double)start) / (_Float16)span) * (_Float16)(float)Lw);
     // end == 0 ("no annealing"): the 1e-12 guard underflows to 0 in float16; what the guard is there for -- and what
     // float64 arithmetic (NumPy 1.x scalar promotion) gives -- is a window that is fully open from the first step on
-    if (end == 0.0f) alpha = (float)(((double)(float)ann - (double)start) / span * (double)L);
+    if (end == 0.0f) alpha = (float)(((double)(float)ann - (double)start) / span * (double)Lw);
     if (k < L) {
-        const float x = fminf(fmaxf(alpha - (float)k, 0.0f), 1.0f);
+        const float x = fminf(fmaxf(alpha - (float)(BAA ? k - 1u : k), 0.0f), 1.0f);
         level_w[k] = k == 0 ? 1.0f : (1.0f - cosf(x * 3.14159265358979323846f)) / 2.0f;
     }
     if (k == 0 && flags) {
         flags[0] = ann < e16 ? 1 : 0;
         flags[1] = (int32_t)step_counter[0];
+    }
+}
+
+// ------------------------------------------------------------------ BAA-NGP window on the encoder slab
+// network.py:84-97: with c = the finest level whose weight is > 0 (its two features are `coarse_features`),
+//   f'_l = w_l f_l + (1 - w_l) f_c          for every level l (f'_c = f_c)
+// applied in place to the level-major slab enc[L][stride][2] before the field reads it.  BWD: the adjoint, in place on
+// d enc:  d f_l = w_l d f'_l  (l != c),   d f_c = d f'_c + sum_{l != c} (1 - w_l) d f'_l.   One lane per sample.
+template <bool BWD>
+__global__ __launch_bounds__(256) void slab_window_kernel(float2 *__restrict__ slab, uint32_t stride, uint32_t L,
+                                                          const float *__restrict__ level_w,
+                                                          const int32_t *__restrict__ M_dev, uint32_t M)
+{
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n = M_dev ? min((uint32_t)max(M_dev[0], 0), M) : M;
+    if (b >= n) return;
+    uint32_t c = 0;
+    for (uint32_t l = 0; l < L; l++)
+        if (level_w[l] > 0.0f) c = l;
+    if (!BWD) {
+        const float2 fc = slab[(size_t)c * stride + b];
+        for (uint32_t l = 0; l < L; l++) {
+            if (l == c) continue;
+            const float w = level_w[l];
+            float2 f = slab[(size_t)l * stride + b];
+            f.x = f.x * w + fc.x * (1.0f - w);
+            f.y = f.y * w + fc.y * (1.0f - w);
+            slab[(size_t)l * stride + b] = f;
+        }
+    } else {
+        float2 gc = slab[(size_t)c * stride + b];
+        for (uint32_t l = 0; l < L; l++) {
+            if (l == c) continue;
+            const float w = level_w[l];
+            float2 g = slab[(size_t)l * stride + b];
+            gc.x += (1.0f - w) * g.x;
+            gc.y += (1.0f - w) * g.y;
+            g.x *= w;
+            g.y *= w;
+            slab[(size_t)l * stride + b] = g;
+        }
+        slab[(size_t)c * stride + b] = gc;
     }
 }
 
@@ -325,9 +371,37 @@ extern "C" int ngp_x_step_window(const uint32_t *step_counter, uint32_t step_off
 {
     NGP_REQUIRE(step_counter && level_w, "step_window: null tensor");
     NGP_REQUIRE(L >= 1 && L <= 64 && iters > 0.0, "step_window: bad L / iters");
-    step_window_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(step_counter, step_offset, iters, start_annealing,
-                                                                    end_annealing, L, level_w, flags);
+    step_window_kernel<false><<<dim3(1), dim3(64), 0, as_stream(stream)>>>(step_counter, step_offset, iters, start_annealing,
+                                                                           end_annealing, L, level_w, flags);
     NGP_CHECK_LAUNCH("step_window");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_step_window_baa(const uint32_t *step_counter, uint32_t step_offset, double iters, float start_annealing,
+                                     float end_annealing, uint32_t L, float *level_w, int32_t *flags, ngp_stream_t stream)
+{
+    NGP_REQUIRE(step_counter && level_w, "step_window_baa: null tensor");
+    NGP_REQUIRE(L >= 2 && L <= 64 && iters > 0.0, "step_window_baa: bad L / iters");
+    step_window_kernel<true><<<dim3(1), dim3(64), 0, as_stream(stream)>>>(step_counter, step_offset, iters, start_annealing,
+                                                                          end_annealing, L, level_w, flags);
+    NGP_CHECK_LAUNCH("step_window_baa");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_slab_window(float *slab, uint32_t stride, uint32_t L, const float *level_w, const int32_t *M_dev,
+                                 uint32_t M, int backward, ngp_stream_t stream)
+{
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(slab && level_w, "slab_window: null tensor");
+    NGP_REQUIRE(L >= 1 && L <= 64 && stride >= M, "slab_window: bad L / stride");
+    NGP_REQUIRE(((uintptr_t)slab & 7u) == 0, "slab_window: slab must be 8-byte aligned");
+    if (backward)
+        slab_window_kernel<true><<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
+            reinterpret_cast<float2 *>(slab), stride, L, level_w, M_dev, M);
+    else
+        slab_window_kernel<false><<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
+            reinterpret_cast<float2 *>(slab), stride, L, level_w, M_dev, M);
+    NGP_CHECK_LAUNCH("slab_window");
     return NGP_OK;
 }
 

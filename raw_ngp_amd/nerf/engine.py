@@ -61,15 +61,20 @@ class FusedTrainer:
         self.rfield = bool(opt.rfield)
         self.pose = opt.pose_opt != "none"
         self.hdr = getattr(opt, "image_mode", "LDR") == "HDR"
-        assert opt.pose_opt in ("none", "barf"), "fused step: pose_opt 'baangp' is not implemented here -- use Trainer"
+        assert opt.pose_opt in ("none", "barf", "baangp"), f"fused step: unknown pose_opt {opt.pose_opt!r}"
+        # BAA-NGP (network.py:77-97): masked levels are replaced by the finest active one -- a blend on the encoder slab in
+        # front of the field kernels (and its adjoint behind them) instead of BARF's per-level factors inside them
+        self.baa = opt.pose_opt == "baangp"
         assert not self.pose or self.rfield, "fused step: pose refinement is fused for the rfield configuration only"
         assert not (getattr(opt, "adaptive_num_rays", False) and getattr(opt, "loss_weight", "none") != "none"), \
             "fused step: adaptive ray batches and a loss weight are not combined"
         assert not self.hdr or getattr(opt, "loss_weight", "none") in ("none", "planck"), \
             "fused step: HDR loss_weight gaussian / hanning need batch statistics -- use Trainer"
+        assert not (getattr(opt, "lambda_entropy", 0) > 0 and getattr(opt, "loss_weight", "none") == "planck"), \
+            "fused step: the entropy term and a planck loss weight are not combined"
         # terms of the reference's train_step (train_utils.py:544-564) this step does not compute: refuse them instead of
         # silently training a different objective than the per-op Trainer would with the same Options
-        unsupported = [k for k in ("lambda_entropy", "lambda_orientation", "lambda_distort") if getattr(opt, k, 0) > 0]
+        unsupported = [k for k in ("lambda_orientation", "lambda_distort") if getattr(opt, k, 0) > 0]
         assert not unsupported, f"fused step: {unsupported} not implemented here -- use nerf.trainer.Trainer"
         assert not getattr(opt, "fp16", False) or opt.loss_scale > 0, "fused step: --fp16 maps to the static loss scale"
         self.opt, self.model, self.data, self.device = opt, model.to(device), dataset, torch.device(device)
@@ -261,7 +266,7 @@ class FusedTrainer:
             # before the first step the reference's annealing value is 0.0 (train_utils.py:411): the first density-grid
             # refresh sees that window (level 0 only)
             eb.step_window(self.step_ctr, 0, float(opt.iters), opt.start_annealing, opt.end_annealing, self.L, self.level_w,
-                           self.flags)
+                           self.flags, baa=self.baa)
         self.enc = torch.empty(self.L, cap, 2, **f32)
         self.denc = torch.empty(self.L, cap, 2, **f32)
         self.x01 = torch.empty(cap, 3, **f32)
@@ -307,7 +312,9 @@ class FusedTrainer:
         """Field evaluation on self.enc (rgb None: density only).  rfield: light directions + the level window.
         step_begin: the step's scalar bookkeeping rides along with this launch (plain field only)."""
         if self.rfield:
-            self.mb.forward(self.enc, stride, dirs, ldirs, self.level_w, cnt, M, self.mlp_image, sigma, rgb)
+            if self.baa:            # f'_l = w_l f_l + (1 - w_l) f_c on the slab, in place
+                eb.slab_window(self.enc, stride, self.L, self.level_w, cnt, M)
+            self.mb.forward(self.enc, stride, dirs, ldirs, None if self.baa else self.level_w, cnt, M, self.mlp_image, sigma, rgb)
         else:
             self.mb.forward(self.enc, stride, dirs, cnt, M, self.mlp_image, sigma, rgb, step_begin=step_begin)
 
@@ -363,11 +370,15 @@ class FusedTrainer:
         def composite_train():      # forward + loss + backward of the compositor in one launch (the step path)
             if zero_loss:
                 self.loss.zero_()
-            if self.adaptive:       # loss over the rays the batch really carries
+            lam = float(getattr(opt, "lambda_entropy", 0.0))
+            if self.adaptive or (lam > 0 and not (self.hdr and opt.loss_weight == "planck")):
+                # loss over the rays the batch really carries (adaptive), + the entropy of the accumulated opacity
                 eb.composite_train_live(gt_rgba, bg_rgb, bg_const, slot.exposure if self.hdr else None, None, 1.0 / (3 * N),
-                                        slot.live, self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.ws,
-                                        self.depth, self.image, self.dsigma, self.drgb, self.loss)
-                self.rays_seen.add_(slot.live)
+                                        slot.live if self.adaptive else None, self.sigma, self.rgb, ar.ts, ar.rays, cap, N,
+                                        opt.T_thresh, self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
+                                        lambda_entropy=lam)
+                if self.adaptive:
+                    self.rays_seen.add_(slot.live)
                 return
             if self.hdr:            # exposure-scaled, clipped loss of train_utils.py:512-536
                 weight = None
@@ -382,9 +393,11 @@ class FusedTrainer:
 
         def mlp_backward():
             if self.rfield:         # one call: both view kernels, the density kernel, the weight-gradient reduction
-                self.mb.backward(self.enc, cap, ar.dirs, ar.ldirs, self.level_w, self.dsigma, self.drgb, cnt, cap,
-                                 self.mlp_image, opt.loss_scale, self.denc, self.ddirs if self.pose else None, self.dws,
-                                 self.ws_mlp)
+                self.mb.backward(self.enc, cap, ar.dirs, ar.ldirs, None if self.baa else self.level_w, self.dsigma, self.drgb,
+                                 cnt, cap, self.mlp_image, opt.loss_scale, self.denc, self.ddirs if self.pose else None,
+                                 self.dws, self.ws_mlp)
+                if self.baa:        # the blend's adjoint: d enc' -> d enc (what the table backward and the ray gradients read)
+                    eb.slab_window(self.denc, cap, self.L, self.level_w, cnt, cap, backward=True)
             else:
                 self.mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap, self.mlp_image, opt.loss_scale,
                                  self.denc, None if split_weights else self.dws, self.ws_mlp)
@@ -655,7 +668,8 @@ class FusedTrainer:
             # counter before step_begin advances it; + 1: the reference counts the step before it trains it
             # (train_utils.py:887-888 in front of :488)
             field.insert(1, ("ngp_x_step_window", lambda: eb.step_window(
-                self.step_ctr, 1, float(opt.iters), opt.start_annealing, opt.end_annealing, self.L, self.level_w, self.flags)))
+                self.step_ctr, 1, float(opt.iters), opt.start_annealing, opt.end_annealing, self.L, self.level_w, self.flags,
+                baa=self.baa)))
         # pose refinement, after the field's own backward: ray gradients (encoder input backward + segment sums) ->
         # per-camera pose gradients -> se(3) Adam step and the refined poses the next batch is cast from
         pose_tail = []

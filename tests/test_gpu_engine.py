@@ -121,6 +121,45 @@ def test_mse_backward_matches_autograd(lib, orc):
     assert np.all(np.abs(host(gs)[covered] - ref) <= 3e-3 * np.abs(ref) + 1e-7)
 
 
+@pytest.mark.parametrize("lam", [1e-2, 0.5])
+def test_entropy_term_of_the_fused_compositor_step_matches_autograd(lib, lam):
+    """lambda_entropy * mean_rays(H(clamp(weights_sum, 1e-5, 1 - 1e-5))) (train_utils.py:554-557) inside the one-launch
+    compositor step: loss value and d sigma / d rgb against torch autograd of the same expression over the per-op compositor.
+    Rays with weights_sum pinned at the clamp (opaque rays) get no entropy gradient, as with torch.clamp."""
+    rng = np.random.default_rng(13)
+    N = 1200
+    sig, rgb, ts, rays, M = synth_samples(rng, N)
+    sig[rays[7, 0]:rays[7, 0] + rays[7, 1]] = 1e4          # an opaque ray: weights_sum == 1 -> clamped
+    gt = rng.uniform(0, 1, (N, 4)).astype(np.float32)
+    e = lib.engine_backend
+    from raw_ngp_amd import raymarching
+    tsig, trgb = dev(sig).requires_grad_(True), dev(rgb).requires_grad_(True)
+    w, ws, dep, img = raymarching.composite_rays_train(tsig, trgb, dev(ts), dev(rays), 1e-4)
+    tgt = dev(gt)[:, :3] * dev(gt)[:, 3:]
+    wc = ws.clamp(1e-5, 1 - 1e-5)
+    ent = (-wc * torch.log2(wc) - (1 - wc) * torch.log2(1 - wc)).mean()
+    loss = ((img - tgt) ** 2).mean(-1).mean() + lam * ent
+    loss.backward()
+    gs, gc = torch.empty(M, device="cuda"), torch.empty(M, 3, device="cuda")
+    lo = torch.zeros(1, device="cuda")
+    ws2, dep2, img2 = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 3, device="cuda")
+    e.composite_train_live(dev(gt), None, 0.0, None, None, 1.0 / (3 * N), None, tsig.detach(), trgb.detach(), dev(ts), dev(rays),
+                           M, N, 1e-4, ws2, dep2, img2, gs, gc, lo, lambda_entropy=lam)
+    np.testing.assert_allclose(float(lo), float(loss.detach()), rtol=2e-5)
+    assert float(ent) > 0.05
+    covered = np.zeros(M, bool)
+    for n in range(N):
+        covered[rays[n, 0]:rays[n, 0] + rays[n, 1]] = True
+    np.testing.assert_allclose(host(gc)[covered], host(trgb.grad)[covered], rtol=1e-3, atol=1e-8)
+    ref = host(tsig.grad)[covered]
+    assert np.all(np.abs(host(gs)[covered] - ref) <= 3e-3 * np.abs(ref) + 1e-7 + 1e-6 * lam)
+    # the entropy term really contributes to d sigma
+    gs0 = torch.empty(M, device="cuda")
+    e.composite_train_live(dev(gt), None, 0.0, None, None, 1.0 / (3 * N), None, tsig.detach(), trgb.detach(), dev(ts), dev(rays),
+                           M, N, 1e-4, ws2, dep2, img2, gs0, gc, torch.zeros(1, device="cuda"))
+    assert float((gs - gs0).abs().max()) > 1e-5 * lam
+
+
 def test_adam_matches_torch(lib):
     torch.manual_seed(0)
     n = 100003                                   # exercises the scalar tail

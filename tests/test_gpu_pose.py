@@ -110,12 +110,13 @@ def _fused_setup(pose_opt, iters, views=24, noise=0.03, rays=2048, image_mode="L
     return P, data, FusedTrainer(opt, NeRFNetwork(opt), data, device=dev, seed=seed, capacity=rays * 200)
 
 
-def test_fused_pose_step_gradients_match_the_per_op_path():
-    """One batch through the fused light-conditioned + BARF step and through the per-op autograd path (torch MLPs in
-    fp32, the reference's call sequence over the `_backend` shims) with the same weights, rays and sample jitter: the
+@pytest.mark.parametrize("pose_opt", ["barf", "baangp"])
+def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt):
+    """One batch through the fused light-conditioned + BARF (or BAA-NGP) step and through the per-op autograd path (torch
+    MLPs in fp32, the reference's call sequence over the `_backend` shims) with the same weights, rays and sample jitter: the
     se(3) gradient, the MLP weight gradients and the loss must agree to what f16 MFMA operands allow."""
     from raw_ngp_amd.nerf import pose as Pm
-    P, data, ft = _fused_setup("barf", iters=300, views=6, noise=0.05, rays=1024)
+    P, data, ft = _fused_setup(pose_opt, iters=300, views=6, noise=0.05, rays=1024)
     model, opt = ft.model, ft.opt
     for _ in range(40):                                  # a few steps so that the field is not flat any more
         ft.train_step()
@@ -193,6 +194,10 @@ def test_fused_pose_step_gradients_match_the_per_op_path():
 
 def Pm_window(model, opt):
     from raw_ngp_amd.nerf.network import level_window
+    if opt.pose_opt == "baangp":        # network.py:77-97: level 0 always counts, level j >= 1 is the (j - 1)-th of 15
+        w = np.ones(16, dtype=np.float32)
+        w[1:] = level_window(model.annealing, opt.start_annealing, opt.end_annealing, 15, "cpu").numpy()
+        return w
     w = level_window(model.annealing, opt.start_annealing, opt.end_annealing, 16, "cpu").numpy().copy()
     w[0] = 1.0
     return w

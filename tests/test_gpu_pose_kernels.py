@@ -54,6 +54,39 @@ def test_step_window_matches_float16_restatement(lib, orc, iters, start, end):
     assert host(flags)[1] == 41 and host(flags)[0] == int(ann < np.float16(end))
 
 
+@pytest.mark.parametrize("ann,step", [(0.0, 0), (0.1, 100), (0.33, 330), (1.0, 1000)])
+def test_baa_window_on_the_slab_matches_the_reference_network(lib, golden_dir, ann, step):
+    """BAA-NGP (network.py:77-97): step_window_baa + slab_window on a level-major slab against what the reference's
+    common_forward fed its grid MLP (tests/golden/level_windows.npz: features 0.1 .. 3.2, annealing {0, 0.1, 0.33, 1}) --
+    and the backward pass is the blend's adjoint."""
+    import os
+    e = lib.engine_backend
+    g = np.load(os.path.join(golden_dir, "level_windows.npz"))
+    feat = g["feat"]                                                      # [4, 32] = (2 l + c)
+    B, L = feat.shape[0], 16
+    stride = B + 3
+    slab = torch.full((L, stride, 2), 9.0, device="cuda")
+    slab[:, :B] = dev(np.ascontiguousarray(feat.reshape(B, L, 2).transpose(1, 0, 2)))
+    ctr = torch.tensor([step], dtype=torch.int32, device="cuda")
+    lw = torch.empty(L, device="cuda")
+    e.step_window(ctr, 0, 1000, 0.0, 0.33, L, lw, None, baa=True)
+    e.slab_window(slab, stride, L, lw, None, B)
+    got = host(slab[:, :B]).transpose(1, 0, 2).reshape(B, 2 * L)
+    np.testing.assert_allclose(got, g[f"baangp_{ann}"], rtol=1e-6, atol=1e-6)
+    assert torch.all(slab[:, B:] == 9.0)                                  # rows beyond M untouched
+    # adjoint: <W x, y> == <x, W^T y>
+    rng = np.random.default_rng(int(step))
+    x, y = rng.normal(size=(L, stride, 2)).astype(np.float32), rng.normal(size=(L, stride, 2)).astype(np.float32)
+    wx, wty = dev(x).clone(), dev(y).clone()
+    cnt = torch.tensor([B], dtype=torch.int32, device="cuda")
+    e.slab_window(wx, stride, L, lw, cnt, stride)                         # (M_dev clamps the launch to B samples)
+    e.slab_window(wty, stride, L, lw, cnt, stride, backward=True)
+    lhs = float((wx[:, :B].double() * dev(y)[:, :B].double()).sum())
+    rhs = float((dev(x)[:, :B].double() * wty[:, :B].double()).sum())
+    np.testing.assert_allclose(lhs, rhs, rtol=1e-5, atol=1e-6)
+    assert torch.equal(wx[:, B:], dev(x)[:, B:]) and torch.equal(wty[:, B:], dev(y)[:, B:])
+
+
 def test_slab_jacobian_and_ray_gradients_match_oracle(lib, orc):
     rng = np.random.default_rng(3)
     e = lib.engine_backend
