@@ -44,17 +44,19 @@ METRIC = "training rays/sec + PSNR@5k-iters, NeRF-synthetic Lego 800², 1/2/4/8 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 # HBM-side traffic of the hash-grid kernels, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE ON THIS SCRIPT's own
-# steady state (tools/pmc_bench.sh, profiles/r02_pmc_bench_traffic.csv: last 30 steps before iteration 5000, 136.6 k live
-# samples per step; 16-byte streaming fetches doubled as the MI355X guide prescribes).  Counters cannot be read while this
-# script times itself, so the per-sample figures are carried as constants and scaled by the samples of the run:
-#   binned backward, Adam fused (one GPU):  fill 19.0 + 44.0 MB, reduce 2 x 92.7 + 143.1 MB = 391.5 MB per launch, of which
-#     292.7 MB are the optimiser state (24 B x 12.2 M table entries, independent of the samples) -> 723 B/sample + 292.7 MB
-#   binned backward, gradient written (data parallel): the round-1 passes on tools/grid_bench.py's synthetic samples
-#     (profiles/r01_pmc_grid_traffic.csv), 2 290 B/sample with 12-byte records; not re-measured this round
-#   slab forward: 41.7 + 22.1 MB = 63.8 MB per launch -> 467 B/sample (gathers of 8 / 16 bytes, counted as reported)
-PMC_TRAFFIC_BYTES_PER_SAMPLE = {"ngp_x_grid_backward_binned": 2290.0}
-PMC_FUSED_TRAFFIC_BYTES_PER_SAMPLE = 723.0
-PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 467.0
+# steady state (tools/pmc_bench.sh, profiles/r03_pmc_bench_traffic.csv: last 30 steps before iteration 5000, 136.6 k live
+# samples per step, --no-graph; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950 -- full-line reads are tallied
+# at 64 B).  Counters cannot be read while this script times itself, so the per-sample figures are carried as constants and
+# scaled by the samples of the run.  Round 3 = the tile-local record layout:
+#   binned backward, Adam fused (one GPU):  fill 2 x 28.3 + 46.2 MB, reduce 2 x 135.5 + 148.2 MB = 521.9 MB per launch, of
+#     which 292.7 MB are the optimiser state (24 B x 12.2 M table entries, independent of the samples) -> 1 677 B/sample +
+#     292.7 MB (round 2, global bins: 723 B/sample -- the reduce now collects ~ 20-record runs and fetches their partial lines)
+#   binned backward, gradient written (data parallel / --no-fuse-adam): fill 102.3 MB + reduce 2 x 60.5 + 47.6 MB = 271.0 MB
+#     -> 1 983 B/sample (the separate Adam launch, 2 x 95.4 + 143.1 MB, is not part of the probed entry point)
+#   slab forward: 62.5 + 24.9 MB = 87.4 MB per launch -> 640 B/sample (gathers of 8 / 16 bytes, counted as reported)
+PMC_TRAFFIC_BYTES_PER_SAMPLE = {"ngp_x_grid_backward_binned": 1983.0}
+PMC_FUSED_TRAFFIC_BYTES_PER_SAMPLE = 1677.0
+PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 640.0
 FWD_BYTES_PER_SAMPLE = 12 + 16 * (64 + 8)      # 1164 B/sample, SURVEY.md section 8d
 # What the forward's ADDRESS STREAM can reach with the arithmetic taken away: tools/ubench/gather_lines.hip issues exactly the
 # slab forward's loads (same table, same ray-ordered samples, same level -> XCD placement) and nothing else.  Best variant
@@ -442,10 +444,9 @@ def main():
             roof = {"bound": "hbm", "kernel": args.roofline_kernel + (" + Adam on the table (fused)" if fused_adam else ""),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_source": ("FETCH_SIZE + WRITE_SIZE measured on this script's steady state (profiles/r02_pmc_bench_"
-                                       "traffic.csv), per-sample part scaled to this run's samples, plus the optimiser's 24 B per "
-                                       "table entry" if fused_adam else
-                                       "PMC on tools/grid_bench.py (profiles/r01_pmc_grid_traffic.csv), scaled by samples"),
+                    "traffic_source": ("FETCH_SIZE + WRITE_SIZE measured on this script's steady state (profiles/r03_pmc_bench_"
+                                       "traffic.csv), per-sample part scaled to this run's samples"
+                                       + (", plus the optimiser's 24 B per table entry" if fused_adam else "")),
                     "launches": launches, "timed_every": args.probe_every, "avg_us": round(ksec / launches * 1e6, 2),
                     "bytes_per_sample": bytes_per_sample, "samples_per_launch": round(units / launches),
                     "optimizer_bytes_per_launch": opt_bytes, "achieved_grid_only": round(grid_only, 1),

@@ -730,16 +730,17 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4,
         };
         if (Q > 12u * tiles) {
             // a heavy chunk (the few chunks of the coarse levels collect hundreds of records from every tile): a wave streams
-            // a run -- 256 records per load round -- two runs per turn.  (Sharing such a chunk among several workgroups was
+            // a run -- 256 records per load round -- two (four) runs per turn.  (Sharing such a chunk among several workgroups was
             // tried -- parked 64-bit sums, a ticket, the last one finishes -- and is slower: the device-scope release /
             // acquire fences write back and invalidate a whole L2 in the middle of a kernel that streams the optimiser state.)
-            for (uint32_t t0 = wv; t0 < tiles; t0 += 2u * (kReduceBlock / 64u)) {
-                uint32_t nq[2];
-                size_t rq[2];   // first quad of the run
-                uint2 k4[2];
-                float4 a0[2], a1[2];
+            constexpr uint32_t kRuns = ADAM ? 2 : 4;   // (the fused variant holds the optimiser state of 8 rows in registers)
+            for (uint32_t t0 = wv; t0 < tiles; t0 += kRuns * (kReduceBlock / 64u)) {
+                uint32_t nq[kRuns];
+                size_t rq[kRuns];   // first quad of the run
+                uint2 k4[kRuns];
+                float4 a0[kRuns], a1[kRuns];
 #pragma unroll
-                for (uint32_t u = 0; u < 2; u++) {
+                for (uint32_t u = 0; u < kRuns; u++) {
                     const uint32_t t = min(t0 + u * (kReduceBlock / 64u), kMaxTiles - 1u);
                     nq[u] = s_pref[t + 1] - s_pref[t];
                     rq[u] = (level_region + (size_t)t * kRegion + s_start[t]) >> 2;
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4,
                     }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < 2; u++) {
+                for (uint32_t u = 0; u < kRuns; u++) {
                     if (ln < nq[u]) apply_quad(k4[u], a0[u], a1[u]);
                     for (uint32_t j = ln + 64u; j < nq[u]; j += 64u)   // runs longer than 256 records
                         apply_quad(kq[rq[u] + j], vq[(rq[u] + j) * 2], vq[(rq[u] + j) * 2 + 1]);
