@@ -712,7 +712,7 @@ class FusedTrainer:
         if self.pose:
             # the cameras are replicated: every rank folds its rays into its own pose gradient, the ranks average them and
             # all take the same se(3) step
-            pose_tail.insert(2, ("xchg_pose", lambda: self.xchg.all_reduce_avg(self.grad_pose.view(-1)), "main"))
+            pose_tail.insert(2, ("xchg_pose", lambda: self.xchg.all_reduce_avg(self.grad_pose.view(-1))))
             ops += [(n, o, "main") for n, o in pose_tail if n != "xchg_pose" or self.xchg.carrier != "none"]
         ops.append(("xchg_pre", self._xchg_pre, "main"))
         ops.append(("ngp_x_adam_step_dev", lambda: self.optimizer_step(device_hyper=True), "main"))
