@@ -694,7 +694,20 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4,
         // (one round trip), kept in LDS as a prefix of run lengths (in quads) + the runs' first slots; after that every load
         // is independent of every other.  Runs start at multiples of four slots and are padded with null records: a quad
         // is one 8-byte load of keys and two 16-byte loads of payloads, like the streams of the global-bins layout.
-        const size_t level_region = (size_t)level * loc.ntiles * kRegion;
+        // (more than kMaxTiles live tiles -- over a million samples -- are taken in batches of kMaxTiles)
+        const uint32_t all_tiles = tiles;
+        for (uint32_t tb = 0; tb == 0 || tb < all_tiles; tb += kMaxTiles) {
+        tiles = min(kMaxTiles, all_tiles - min(tb, all_tiles));
+        if (tb != 0) {
+            __syncthreads();   // everybody is done with the previous batch's prefix
+            const uint32_t *dcol = loc.dir + (size_t)chunk * loc.ntiles + tb;
+#pragma unroll
+            for (uint32_t q = 0; q < kDirPerLane; q++) {
+                const uint32_t t = threadIdx.x * kDirPerLane + q;
+                dirw[q] = t < tiles ? dcol[t] : 0u;
+            }
+        }
+        const size_t level_region = ((size_t)level * loc.ntiles + tb) * kRegion;
         constexpr uint32_t kPerLane = kDirPerLane;   // consecutive tiles per lane in the scan
         uint32_t sum = 0;
 #pragma unroll
@@ -785,6 +798,7 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4,
                 if (v1 < Q) apply_quad(kb, b0, b1);
             }
         }
+        }   // batches of tiles
     }
     const uint2 *key4 = reinterpret_cast<const uint2 *>(w.keys);       // 4 keys per uint2
     const float4 *val2 = reinterpret_cast<const float4 *>(w.vals);     // 2 payloads per float4
@@ -882,14 +896,14 @@ extern "C" size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, ui
 
 namespace {
 // record layout: tile-local regions + directory (default) or global bins with counts, scan and cursors (NGP_BINNED_LOCAL=0,
-// more than kMaxTiles fill tiles, or a level with more than kLocalBins chunks)
+// or a level with more than kLocalBins chunks)
 bool binned_local(uint32_t B, uint32_t nbins_cap)
 {
     static const bool enabled = [] {
         const char *e = getenv("NGP_BINNED_LOCAL");
         return !(e && e[0] == '0');
     }();
-    return enabled && ceil_div(B, kFillTile) <= kMaxTiles && nbins_cap <= kLocalBins;
+    return enabled && nbins_cap <= kLocalBins && (uint64_t)ceil_div(B, kFillTile) * kMaxLevels * kRegion < (1ull << 40);
 }
 
 struct BinnedCall {

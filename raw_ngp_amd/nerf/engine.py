@@ -7,15 +7,15 @@ the arithmetic is the same and the plumbing is not:
   * ray batches are drawn on the device (Philox) and marched ONCE into a sample arena by the chain-parallel march; the
     batch of step i+1 is prepared on a second stream while step i trains; nothing waits for a sample count on the host
     -- every kernel reads it from the arena's device counter
-  * the hash-grid encoder writes the level-major slab the fused MFMA MLP reads (no permutes, no concatenations) and
-    counts the records of the table backward while it has the rows in registers
+  * the hash-grid encoder writes the level-major slab the fused MFMA MLP reads (no permutes, no concatenations); with the
+    global-bins record layout it also counts the records of the table backward (the default tile-local layout needs no counts)
   * compositing runs one wave per ray; forward, MSE loss, background mix and backward are ONE kernel
   * the table gradient is binned and reduced in LDS (64-bit fixed point); on one GPU Adam is applied inside that
     reduction (the gradient never reaches HBM), under data parallelism the gradient is all-reduced first
   * learning-rate schedule, loss, sample counters live on the device; autograd, GradScaler, zeros_like and the foreach
     optimiser are gone (their work is in the kernels)
   * the density-grid refresh draws its cells, evaluates, EMA-maxes and re-packs the bitfield without a host round trip
-Main stream per step (one graph): encoder forward (+count) -> step_begin (+scan) -> MLP forward -> composite forward +
+Main stream per step (one graph): encoder forward -> MLP forward (+ step_begin as a passenger) -> composite forward +
 loss + backward -> MLP backward (2) -> dW reduction (+Adam on the MLP weights, + their entries in the f16 operand image)
 -> fill -> reduce (+Adam on the table).  Same seed, same bits: no float atomic feeds back into the state.
 """

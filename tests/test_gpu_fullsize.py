@@ -90,6 +90,37 @@ def test_encoder_is_linear_in_the_table_and_backward_is_its_adjoint(be, grid):
                                    atol=1e-3 * float(g[lvl].double().abs().sum()) ** 0.5)
 
 
+def test_binned_backward_beyond_one_batch_of_tiles(be, grid):
+    """More than 2 048 fill tiles (over a million samples: the tile-local reduce takes its directory in batches) with a
+    ragged tail: the binned backward and the reference-shaped atomic backward are two evaluations of the same sums."""
+    offsets, S, rows = grid
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    per_ray = 260
+    x = _ray_ordered_points(gen, 4040, per_ray)[: 2051 * 512 + 77]
+    B = x.shape[0]
+    assert B > 2048 * 512
+    t1 = torch.zeros(rows, 2, device="cuda")
+    g = torch.randn(16, B, 2, device="cuda", generator=gen)
+    g[:, torch.arange(B, device="cuda") % per_ray >= 200] = 0.0           # zero-gradient tails: runs that emit nothing
+    grads = {}
+    for binned in (True, False):
+        type(be.gridencoder_backend).use_binned_backward = binned
+        try:
+            gt = torch.zeros(rows, 2, device="cuda")
+            be.gridencoder_backend.grid_encode_backward(g, x, t1, offsets, gt, B, 3, 2, 16, 16, S, 16, None, None, 0,
+                                                        False, 0)
+        finally:
+            type(be.gridencoder_backend).use_binned_backward = True
+        grads[binned] = gt
+    diff = (grads[True] - grads[False]).abs()
+    scale = float(grads[False].abs().max())
+    assert scale > 1.0 and float(diff.max()) <= 2e-4 * scale and float(diff.mean()) <= 4e-6 * scale
+    for lvl in (0, 9, 15):
+        lo, hi = int(offsets[lvl]), int(offsets[lvl + 1])
+        np.testing.assert_allclose(float(grads[True][lo:hi].double().sum()), float(g[lvl].double().sum()), rtol=0,
+                                   atol=1e-3 * float(g[lvl].double().abs().sum()) ** 0.5)
+
+
 def test_sh_addition_theorem_at_full_size(be):
     gen = torch.Generator(device="cuda").manual_seed(1)
     d = torch.nn.functional.normalize(torch.randn(B_FULL, 3, device="cuda", generator=gen), dim=-1).contiguous()
