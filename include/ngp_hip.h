@@ -308,6 +308,13 @@ int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float *dirs, con
                        void *workspace, size_t workspace_bytes, ngp_stream_t stream);
 /* dw1..dw6 all NULL: the per-workgroup partial sums stay in `workspace` and ngp_x_mlp_reduce_dw (same M, loss_scale,
  * workspace) produces the six gradients later -- e.g. on another stream, off the critical path. */
+/* ... and d loss / d (un-normalised view direction) in ddirs [M,3] (NULL: not wanted): the SH Jacobian applied to the gradient
+ * of the view MLP's SH inputs, then the tangent projection of d / |d| (renderer.py:541, sphere_harmonics.py:81) -- what pose
+ * refinement needs from the field besides d enc. */
+int ngp_x_mlp_backward_dirs(const float *enc, uint32_t stride, const float *dirs, const float *dsigma,
+                            const float *drgb, const int32_t *M_dev, uint32_t M, const void *image, float loss_scale,
+                            float *denc, float *ddirs, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
+                            float *dw6, void *workspace, size_t workspace_bytes, ngp_stream_t stream);
 int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
                         float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
                         const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,
@@ -506,6 +513,8 @@ int ngp_x_step_window_baa(const uint32_t *step_counter, uint32_t step_offset, do
                           float end_annealing, uint32_t L, float *level_w, int32_t *flags, ngp_stream_t stream);
 int ngp_x_slab_window(float *slab, uint32_t stride, uint32_t L, const float *level_w, const int32_t *M_dev, uint32_t M,
                       int backward, ngp_stream_t stream);
+/* backward == 2: no blend, f'_l = w_l f_l in place (the BARF window, network.py:99-109, for field kernels that do not apply
+ * it themselves; it is its own adjoint) */
 int ngp_x_ray_gradients(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound, const float *ddirs,
                         const float *ts, const int32_t *rays, uint32_t N, uint32_t M, float *grad_rays_o,
                         float *grad_rays_d, ngp_stream_t stream);

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
+    "ngp_x_mlp_backward_dirs": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f, _f, _f, _p],
     "ngp_x_mlp_rf_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_rf_forward": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _p],
@@ -586,18 +587,21 @@ class _MlpBackend:
         return int(load().ngp_x_mlp_backward_workspace_bytes(M))
 
     @staticmethod
-    def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws, workspace=None):
+    def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws, workspace=None, ddirs=None):
         """dws: six pre-allocated fp32 tensors shaped like the weights (overwritten), or None to leave the partial
         sums in `workspace` for reduce_dw().  workspace: uint8 tensor of backward_workspace_bytes(M) (allocated per
-        call when omitted)."""
+        call when omitted).  ddirs [M,3] (optional): d loss / d (un-normalised view direction)."""
         nbytes = load().ngp_x_mlp_backward_workspace_bytes(M)
         ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
         if ws.numel() < nbytes or not ws.is_cuda:
             raise RuntimeError("mlp backward: workspace too small")
         grads = [_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)] if dws is not None else [None] * 6
-        _call("ngp_x_mlp_backward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"),
-              _ptr(dsigma, "f", "dsigma"), _ptr(drgb, "f", "drgb"), _ptr(M_dev, "i", "M_dev", True), M,
-              image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"), *grads, ws.data_ptr(), nbytes)
+        head = (_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"), _ptr(dsigma, "f", "dsigma"), _ptr(drgb, "f", "drgb"),
+                _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"))
+        if ddirs is not None:
+            _call("ngp_x_mlp_backward_dirs", enc, *head, _ptr(ddirs, "f", "ddirs"), *grads, ws.data_ptr(), nbytes)
+        else:
+            _call("ngp_x_mlp_backward", enc, *head, *grads, ws.data_ptr(), nbytes)
 
     @staticmethod
     def reduce_dw(M, loss_scale, dws, workspace, adam=None, image=None):
@@ -737,10 +741,11 @@ class _EngineBackend:
               _ptr(level_w, "f", "level_w"), _ptr(flags, "i", "flags", True))
 
     @staticmethod
-    def slab_window(slab, stride, L, level_w, M_dev, M, backward=False):
-        """BAA-NGP blend on the level-major encoder slab, in place (backward: its adjoint on the gradient slab)."""
+    def slab_window(slab, stride, L, level_w, M_dev, M, backward=False, scale_only=False):
+        """BAA-NGP blend on the level-major encoder slab, in place (backward: its adjoint on the gradient slab);
+        scale_only: the BARF window f'_l = w_l f_l (self-adjoint)."""
         _call("ngp_x_slab_window", slab, _ptr(slab, "f", "slab"), int(stride), int(L), _ptr(level_w, "f", "level_w"),
-              _ptr(M_dev, "i", "M_dev", True), int(M), int(bool(backward)))
+              _ptr(M_dev, "i", "M_dev", True), int(M), 2 if scale_only else int(bool(backward)))
 
     @staticmethod
     def ray_gradients(denc, dydx, stride, L, bound, ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d):

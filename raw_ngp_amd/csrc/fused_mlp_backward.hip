@@ -211,10 +211,15 @@ __device__ unsigned long long ngp_dbg_stamps[16];
 #endif
 
 // ---- view kernel ---------------------------------------------------------------------------------
+// DDIRS: also d loss / d (un-normalised view direction) [M,3] -- pose refinement without the light-conditioned field: the
+// gradient with respect to the SH features is rows 16..31 of d x3; the SH Jacobian and the tangent projection of d / |d|
+// follow as in fused_mlp_rf.hip
+template <bool DDIRS>
 __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
     const float *__restrict__ enc, uint32_t stride, const float *__restrict__ dirs, const float *__restrict__ dsigma,
     const float *__restrict__ drgb, const int32_t *__restrict__ M_dev, uint32_t M_host,
-    const half8 *__restrict__ image, float loss_scale, half8 *__restrict__ d3buf, float *__restrict__ partial)
+    const half8 *__restrict__ image, float loss_scale, half8 *__restrict__ d3buf, float *__restrict__ partial,
+    float *__restrict__ ddirs)
 {
     extern __shared__ half8 lds_w[];   // fragments 0..45 (46 KiB); reused as the f32 reduction image at the end
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
@@ -249,6 +254,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 #pragma unroll
                 for (int t = 0; t < 8; t++) z[t] = (_Float16)0.0f;
                 d3buf[(size_t)row * 2 + h] = z;
+                if (DDIRS && h == 0) ddirs[(size_t)row * 3] = ddirs[(size_t)row * 3 + 1] = ddirs[(size_t)row * 3 + 2] = 0.0f;
             }
             continue;
         }
@@ -411,6 +417,38 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
         // delta3: rows 1..15 = d features, row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp)
         if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
         if (valid) d3buf[(size_t)row * 2 + h] = pack_sat<0>(dx3);
+        if constexpr (DDIRS) {
+            float dx = 0.f, dy = 0.f, dz = 1.f;
+            if (valid) {
+                dx = dirs[(size_t)row * 3];
+                dy = dirs[(size_t)row * 3 + 1];
+                dz = dirs[(size_t)row * 3 + 2];
+            }
+            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+            const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            float sh[16], jx[16], jy[16], jz[16];
+            sh_eval<4, true>(ux, uy, uz, sh, jx, jy, jz);
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+            for (uint32_t t = 0; t < 8; t++) {   // register 8 + t = SH index 8 (t >> 2) + 4 h + (t & 3)
+                const uint32_t lo = 8 * (t >> 2) + (t & 3), hi = lo + 4;
+                const float gv = dx3[8 + t];
+                gx = fmaf(gv, h ? jx[hi] : jx[lo], gx);
+                gy = fmaf(gv, h ? jy[hi] : jy[lo], gy);
+                gz = fmaf(gv, h ? jz[hi] : jz[lo], gz);
+            }
+            gx += __shfl_xor(gx, 32, 64);
+            gy += __shfl_xor(gy, 32, 64);
+            gz += __shfl_xor(gz, 32, 64);
+            // through u = d / |d| (applied twice by the reference -- renderer.py:541 and the encoder module: the same tangent
+            // projection, idempotent); deltas carry the loss scale
+            const float dot = gx * ux + gy * uy + gz * uz, k = inv / loss_scale;
+            if (valid && h == 0) {
+                ddirs[(size_t)row * 3] = (gx - ux * dot) * k;
+                ddirs[(size_t)row * 3 + 1] = (gy - uy * dot) * k;
+                ddirs[(size_t)row * 3 + 2] = (gz - uz * dot) * k;
+            }
+        }
         NGP_STAMP_AT(5);      // dW4, d x3, store
     }
     NGP_STAMP_BEGIN();
@@ -624,7 +662,9 @@ __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(MlpDwReduce r)
 static bool mlp_backward_lds_ok()
 {
     static const bool ok = [] {
-        bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_view_kernel),
+        bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_view_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kViewLds) == hipSuccess;
+        r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_view_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kViewLds) == hipSuccess;
         r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
@@ -706,6 +746,16 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
                                   float loss_scale, float *denc, float *dw1, float *dw2, float *dw3, float *dw4,
                                   float *dw5, float *dw6, void *workspace, size_t workspace_bytes, ngp_stream_t stream)
 {
+    return ngp_x_mlp_backward_dirs(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, nullptr, dw1, dw2, dw3,
+                                   dw4, dw5, dw6, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ngp_x_mlp_backward_dirs(const float *enc, uint32_t stride, const float *dirs, const float *dsigma,
+                                       const float *drgb, const int32_t *M_dev, uint32_t M, const void *image,
+                                       float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2, float *dw3,
+                                       float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
+                                       ngp_stream_t stream)
+{
     const bool reduce_now = dw1 != nullptr;   // all NULL: leave the per-workgroup partials for ngp_x_mlp_reduce_dw
     NGP_REQUIRE(image && workspace, "mlp_backward: null tensor");
     NGP_REQUIRE(reduce_now ? (dw2 && dw3 && dw4 && dw5 && dw6) : (!dw2 && !dw3 && !dw4 && !dw5 && !dw6),
@@ -722,8 +772,12 @@ extern "C" int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float
     float *part_view = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (((size_t)M * 32 + 255) & ~(size_t)255));
     float *part_grid = part_view + (size_t)256 * kAccFloats;
     const half8 *img = reinterpret_cast<const half8 *>(image);
-    mlp_backward_view_kernel<<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
-                                                                        loss_scale, d3buf, part_view);
+    if (ddirs)
+        mlp_backward_view_kernel<true><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
+                                                                                  loss_scale, d3buf, part_view, ddirs);
+    else
+        mlp_backward_view_kernel<false><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M,
+                                                                                   img, loss_scale, d3buf, part_view, nullptr);
     mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
                                                                                d3buf, denc, part_grid, nullptr, T_W3);
     if (reduce_now)

@@ -58,14 +58,26 @@ __global__ void step_window_kernel(const uint32_t *__restrict__ step_counter, ui
 //   f'_l = w_l f_l + (1 - w_l) f_c          for every level l (f'_c = f_c)
 // applied in place to the level-major slab enc[L][stride][2] before the field reads it.  BWD: the adjoint, in place on
 // d enc:  d f_l = w_l d f'_l  (l != c),   d f_c = d f'_c + sum_{l != c} (1 - w_l) d f'_l.   One lane per sample.
-template <bool BWD>
+// MODE 0: blend, 1: its adjoint, 2: plain per-level scale (the BARF window; self-adjoint)
+template <int MODE>
 __global__ __launch_bounds__(256) void slab_window_kernel(float2 *__restrict__ slab, uint32_t stride, uint32_t L,
                                                           const float *__restrict__ level_w,
                                                           const int32_t *__restrict__ M_dev, uint32_t M)
 {
+    constexpr bool BWD = MODE == 1;
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     const uint32_t n = M_dev ? min((uint32_t)max(M_dev[0], 0), M) : M;
     if (b >= n) return;
+    if (MODE == 2) {
+        for (uint32_t l = 0; l < L; l++) {
+            const float w = level_w[l];
+            float2 f = slab[(size_t)l * stride + b];
+            f.x *= w;
+            f.y *= w;
+            slab[(size_t)l * stride + b] = f;
+        }
+        return;
+    }
     uint32_t c = 0;
     for (uint32_t l = 0; l < L; l++)
         if (level_w[l] > 0.0f) c = l;
@@ -395,11 +407,15 @@ extern "C" int ngp_x_slab_window(float *slab, uint32_t stride, uint32_t L, const
     NGP_REQUIRE(slab && level_w, "slab_window: null tensor");
     NGP_REQUIRE(L >= 1 && L <= 64 && stride >= M, "slab_window: bad L / stride");
     NGP_REQUIRE(((uintptr_t)slab & 7u) == 0, "slab_window: slab must be 8-byte aligned");
-    if (backward)
-        slab_window_kernel<true><<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
+    NGP_REQUIRE(backward >= 0 && backward <= 2, "slab_window: backward must be 0 (blend), 1 (adjoint) or 2 (scale)");
+    if (backward == 2)
+        slab_window_kernel<2><<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
+            reinterpret_cast<float2 *>(slab), stride, L, level_w, M_dev, M);
+    else if (backward)
+        slab_window_kernel<1><<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
             reinterpret_cast<float2 *>(slab), stride, L, level_w, M_dev, M);
     else
-        slab_window_kernel<false><<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
+        slab_window_kernel<0><<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
             reinterpret_cast<float2 *>(slab), stride, L, level_w, M_dev, M);
     NGP_CHECK_LAUNCH("slab_window");
     return NGP_OK;

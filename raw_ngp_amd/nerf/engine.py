@@ -65,7 +65,6 @@ class FusedTrainer:
         # BAA-NGP (network.py:77-97): masked levels are replaced by the finest active one -- a blend on the encoder slab in
         # front of the field kernels (and its adjoint behind them) instead of BARF's per-level factors inside them
         self.baa = opt.pose_opt == "baangp"
-        assert not self.pose or self.rfield, "fused step: pose refinement is fused for the rfield configuration only"
         assert not (getattr(opt, "adaptive_num_rays", False) and getattr(opt, "loss_weight", "none") != "none"), \
             "fused step: adaptive ray batches and a loss weight are not combined"
         assert not self.hdr or getattr(opt, "loss_weight", "none") in ("none", "planck"), \
@@ -316,6 +315,8 @@ class FusedTrainer:
                 eb.slab_window(self.enc, stride, self.L, self.level_w, cnt, M)
             self.mb.forward(self.enc, stride, dirs, ldirs, None if self.baa else self.level_w, cnt, M, self.mlp_image, sigma, rgb)
         else:
+            if self.pose:           # the plain field kernels carry no level window: BARF scale / BAA blend on the slab
+                eb.slab_window(self.enc, stride, self.L, self.level_w, cnt, M, scale_only=not self.baa)
             self.mb.forward(self.enc, stride, dirs, cnt, M, self.mlp_image, sigma, rgb, step_begin=step_begin)
 
     def march(self, slot, rays_o, rays_d, noises, aabb=None, plan=True, stage=0):
@@ -400,7 +401,10 @@ class FusedTrainer:
                     eb.slab_window(self.denc, cap, self.L, self.level_w, cnt, cap, backward=True)
             else:
                 self.mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap, self.mlp_image, opt.loss_scale,
-                                 self.denc, None if split_weights else self.dws, self.ws_mlp)
+                                 self.denc, None if split_weights else self.dws, self.ws_mlp,
+                                 ddirs=self.ddirs if self.pose else None)
+                if self.pose:       # the window's adjoint: d enc' -> d enc
+                    eb.slab_window(self.denc, cap, self.L, self.level_w, cnt, cap, backward=True, scale_only=not self.baa)
 
         ops = [
             ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(

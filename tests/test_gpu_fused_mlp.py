@@ -195,6 +195,48 @@ def test_backward_random_weights(M):
         assert l2 < 5e-2, (name, l2, mx)
 
 
+@pytest.mark.parametrize("M", [33, 5000])
+def test_backward_direction_gradient_matches_autograd(M):
+    """d loss / d (un-normalised view direction) out of the plain view kernel (ngp_x_mlp_backward_dirs: pose refinement
+    without the light-conditioned field) against autograd through the SH op (its own Jacobian kernel) and the torch field,
+    normalisation included; the other outputs must not change when it is requested.  Same 5e-2 L2 bound as the weight
+    gradients against fp32 autograd; the gradient is tangent to the direction."""
+    from raw_ngp_amd import _lib
+    from raw_ngp_amd.shencoder import SHEncoder
+    mb = _lib.mlp_backend
+    W = make_weights(3)
+    g = torch.Generator(device="cuda").manual_seed(700 + M)
+    stride = M + 5
+    enc = torch.randn(16, stride, 2, device="cuda", generator=g) * 0.5
+    dirs = torch.randn(M, 3, device="cuda", generator=g) * 1.5
+    dsigma = torch.randn(M, device="cuda", generator=g) * 1e-3
+    drgb = torch.randn(M, 3, device="cuda", generator=g) * 1e-3
+    image = torch.empty(mb.image_bytes(), dtype=torch.uint8, device="cuda")
+    mb.prepare(W, image)
+    denc, denc2 = torch.empty(16, stride, 2, device="cuda"), torch.empty(16, stride, 2, device="cuda")
+    dws, dws2 = [torch.empty_like(w) for w in W], [torch.empty_like(w) for w in W]
+    ddirs = torch.full((M + 3, 3), 7.0, device="cuda")
+    mb.backward(enc, stride, dirs, dsigma, drgb, None, M, image, 1024.0, denc, dws, ddirs=ddirs)
+    mb.backward(enc, stride, dirs, dsigma, drgb, None, M, image, 1024.0, denc2, dws2)
+    assert torch.equal(denc[:, :M], denc2[:, :M]) and all(torch.equal(a, b) for a, b in zip(dws, dws2))
+    assert torch.all(ddirs[M:] == 7.0)
+    # reference: fp32 torch field over the SH autograd op
+    enc_bf = enc[:, :M].permute(1, 0, 2).reshape(M, 32)
+    d = dirs.clone().requires_grad_(True)
+    h = torch.relu(enc_bf @ W[0].t())
+    h = torch.relu(h @ W[1].t())
+    h = h @ W[2].t()
+    sh = SHEncoder(degree=4)(d)                                  # normalises, like renderer.py:541 + the module
+    c = torch.relu(torch.cat([h[:, 1:], sh], -1) @ W[3].t())
+    c = torch.relu(c @ W[4].t())
+    c = c @ W[5].t()
+    (torch.clamp(torch.exp(c - 5.0), max=5.0) * drgb).sum().backward()
+    l2, mx = rel(ddirs[:M], d.grad)
+    assert float(d.grad.abs().max()) > 0 and l2 < 5e-2, (l2, mx)
+    radial = (ddirs[:M] * dirs).sum(-1).abs() / (ddirs[:M].norm(dim=-1) * dirs.norm(dim=-1) + 1e-30)
+    assert float(radial.max()) < 1e-3                            # tangent: scaling a direction does not change the colour
+
+
 def test_backward_is_deterministic_and_independent_of_loss_scale():
     from raw_ngp_amd import _lib
     mb = _lib.mlp_backend

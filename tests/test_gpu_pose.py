@@ -91,7 +91,7 @@ def test_split_k_linear_matches_nn_linear():
 
 
 # ----------------------------------------------------------------------------- the fused step of the same configuration
-def _fused_setup(pose_opt, iters, views=24, noise=0.03, rays=2048, image_mode="LDR", seed=0, **kw):
+def _fused_setup(pose_opt, iters, views=24, noise=0.03, rays=2048, image_mode="LDR", seed=0, rfield=True, **kw):
     from raw_ngp_amd.nerf import pose as P
     from raw_ngp_amd.nerf.network import NeRFNetwork
     from raw_ngp_amd.nerf.options import Options
@@ -99,10 +99,11 @@ def _fused_setup(pose_opt, iters, views=24, noise=0.03, rays=2048, image_mode="L
     from raw_ngp_amd.nerf.engine import FusedTrainer
     dev = torch.device("cuda")
     torch.manual_seed(0)
-    opt = Options(bound=1.0, num_rays=rays, iters=iters, rfield=True, pose_opt=pose_opt, noise=noise, image_mode=image_mode,
+    opt = Options(bound=1.0, num_rays=rays, iters=iters, rfield=rfield, pose_opt=pose_opt, noise=noise, image_mode=image_mode,
                   **kw)
     data = SyntheticDataset(opt, dev, "train", n_views=views, H=128, W=128)
-    data.ldirs = torch.from_numpy(P.synthetic_light_dirs(views)).to(dev)
+    if rfield:
+        data.ldirs = torch.from_numpy(P.synthetic_light_dirs(views)).to(dev)
     if image_mode == "HDR":
         data.exposures = torch.from_numpy(np.random.default_rng(5).choice([0.5, 1.0, 2.0], views).astype(np.float32)).to(dev)
         rgb = data.images[..., :3].float() * data.exposures.view(-1, 1, 1, 1)       # radiance x exposure, clipped at white
@@ -110,13 +111,13 @@ def _fused_setup(pose_opt, iters, views=24, noise=0.03, rays=2048, image_mode="L
     return P, data, FusedTrainer(opt, NeRFNetwork(opt), data, device=dev, seed=seed, capacity=rays * 200)
 
 
-@pytest.mark.parametrize("pose_opt", ["barf", "baangp"])
-def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt):
+@pytest.mark.parametrize("pose_opt,rfield", [("barf", True), ("baangp", True), ("barf", False), ("baangp", False)])
+def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield):
     """One batch through the fused light-conditioned + BARF (or BAA-NGP) step and through the per-op autograd path (torch
     MLPs in fp32, the reference's call sequence over the `_backend` shims) with the same weights, rays and sample jitter: the
     se(3) gradient, the MLP weight gradients and the loss must agree to what f16 MFMA operands allow."""
     from raw_ngp_amd.nerf import pose as Pm
-    P, data, ft = _fused_setup(pose_opt, iters=300, views=6, noise=0.05, rays=1024)
+    P, data, ft = _fused_setup(pose_opt, iters=300, views=6, noise=0.05, rays=1024, rfield=rfield)
     model, opt = ft.model, ft.opt
     for _ in range(40):                                  # a few steps so that the field is not flat any more
         ft.train_step()
@@ -128,7 +129,8 @@ def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt):
     step = ft.global_step
     assert step % opt.update_extra_interval != 0         # no density-grid refresh between the two evaluations
     ft.train_step()
-    rays_o, rays_d, ld = slot.rays_o.clone(), slot.rays_d.clone(), slot.rays_ldir.clone()
+    rays_o, rays_d = slot.rays_o.clone(), slot.rays_d.clone()
+    ld = slot.rays_ldir.clone() if rfield else None
     idx, gt, noises = slot.index.clone(), slot.gt.clone(), slot.noises.clone()
     loss_fused = float(ft.loss)
     g_pose_fused = ft.grad_pose.clone()
@@ -159,13 +161,13 @@ def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt):
     N = ro.shape[0]
     nears, fars = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
     eb.near_far_from_aabb_v2(ro.detach().contiguous(), rd.detach().contiguous(), model.aabb_train, N, model.min_near, nears, fars)
-    arena = raymarching.MarchArena(N, opt.max_steps, ft.cap, "cuda", with_ldirs=True)
+    arena = raymarching.MarchArena(N, opt.max_steps, ft.cap, "cuda", with_ldirs=rfield)
     xyzs, dirs, ts, rays, ldirs = raymarching.march_rays_train_arena(
         ro, rd, ld, model.real_bound, opt.contract, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
         arena, True, opt.dt_gamma, opt.max_steps, noises)
     M = int(arena.counter[0])
     assert M == int(slot.arena.counter[0])
-    xyzs, dirs, ts, ldirs = xyzs[:M], dirs[:M], ts[:M], ldirs[:M]
+    xyzs, dirs, ts, ldirs = xyzs[:M], dirs[:M], ts[:M], (ldirs[:M] if rfield else None)
     dirs = dirs / dirs.norm(dim=-1, keepdim=True)
     out = model(xyzs, dirs, ldirs)
     _, ws, _, image = raymarching.composite_rays_train(out["sigma"], out["color"], ts, rays, opt.T_thresh)
