@@ -17,8 +17,12 @@ from raw_ngp_amd import _lib  # noqa: E402
 from raw_ngp_amd._lib import engine_backend as eb, gridencoder_backend as gb  # noqa: E402
 from raw_ngp_amd.gridencoder.grid import level_table  # noqa: E402
 
-PHASES = ["header + zero hist", "x, grad arrive", "weights/runs/hash/hist", "barrier 1 skew", "scan + cursor issue",
-          "cursor RTT + staging", "stream-out"]
+# phase names of the global-bins kernel (NGP_BINNED_LOCAL=0) and of the tile-local one (the default)
+PHASES_GLOBAL = ["header + zero hist", "x, grad arrive", "weights/runs/hash/hist", "barrier 1 skew", "scan + cursor issue",
+                 "cursor RTT + staging", "stream-out"]
+PHASES_LOCAL = ["header + loads issued", "-", "loads arrive, weights/runs/hash/hist", "barrier 1 skew",
+                "scan + directory + padding", "staging (+ barrier)", "stream-out"]
+PHASES = PHASES_GLOBAL if os.environ.get("NGP_BINNED_LOCAL", "1") == "0" else PHASES_LOCAL
 
 
 def main():
@@ -70,7 +74,7 @@ def main():
     torch.cuda.synchronize()
     lib.ngp_dbg_read_fill_stamps(out, 1)
     a = np.array(list(out), dtype=np.float64).reshape(64, 8)[:L]
-    print(f"{B} samples; s_memtime ticks (100 MHz constant clock on gfx950 -> 10 ns each) per workgroup, mean over {iters} launches")
+    print(f"{B} samples; s_memtime ticks (shader-clock cycles) per workgroup, mean over {iters} launches")
     print("level   WGs  life  " + "  ".join(f"{p[:22]:>22}" for p in PHASES))
     for lv in range(L):
         n = a[lv, 0]
