@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE.  Run as `python oracle/gen_golden.py` in the container that
 modules that are not installed are replaced by inert MagicMock entries, SURVEY.md section 8c /
 Appendix B), feeds them seeded inputs and writes inputs + outputs to tests/golden/*.npz.
 Only data is written -- no reference source text.  The reference's CUDA kernels cannot be
-built or run here.  The wrapper-level fixtures (`wrapper_grid.npz`, `wrapper_sh.npz`) run the reference's own
+built or run here.  The wrapper-level fixtures (`wrapper_grid.npz`, `wrapper_sh.npz`, `wrapper_raymarching.npz`) run the reference's own
 `GridEncoder` / `_grid_encode` and `SHEncoder` / `_sh_encoder` Python (gridencoder/grid.py:24-99,149-174,
 shencoder/sphere_harmonics.py:14-89) on CPU with `_backend` replaced by a shim over THIS repo's CPU oracle
 (oracle/libngp_oracle.so): what they pin is the wrappers' share -- the [-bound, bound] -> [0, 1] map, flatten / permute /
@@ -216,6 +216,161 @@ def main():
         ws[f"d{degree}_dirs"], ws[f"d{degree}_gy"] = d.numpy(), gy.numpy()
         ws[f"d{degree}_out"], ws[f"d{degree}_gdirs"] = out.detach().numpy(), gd.numpy()
     np.savez(os.path.join(args.out, "wrapper_sh.npz"), size=2.0, **ws)
+
+    # ---------------------------------------------------------------- the raymarching WRAPPERS over an oracle-backed backend
+    # raymarching/raymarching.py:32-476 (R0): allocation, casting, the two-call march protocol with its .item() read, the
+    # autograd.Function plumbing of compositing, the ray-gradient backward of the march.  `_raymarching_mob` is replaced by a
+    # shim that hands the tensors' storage to the CPU oracle's C functions (same positional arguments as
+    # raymarching/src/bindings.cpp:5-19, results written in place); `.cuda()` is the identity on this CPU-only box;
+    # torch_scatter.segment_csr (not installable: SURVEY 8c) is restated as the segmented sum its documentation defines,
+    # out[i] = sum(src[indptr[i] : indptr[i + 1]]).
+    import ctypes
+    import raymarching.raymarching as RM
+    olib = orc.lib()
+    P_, cu, cf, ci = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_int
+
+    def dp(t):
+        return None if t is None else P_(t.data_ptr())
+
+    class OracleRayBackend:
+        @staticmethod
+        def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+            olib.orc_near_far_from_aabb(dp(rays_o), dp(rays_d), dp(aabb), cu(N), cf(min_near), dp(nears), dp(fars))
+
+        @staticmethod
+        def sph_from_ray(rays_o, rays_d, radius, N, coords):
+            olib.orc_sph_from_ray(dp(rays_o), dp(rays_d), cf(radius), cu(N), dp(coords))
+
+        @staticmethod
+        def morton3D(coords, N, indices):
+            olib.orc_morton3D(dp(coords.contiguous()), cu(N), dp(indices))
+
+        @staticmethod
+        def morton3D_invert(indices, N, coords):
+            olib.orc_morton3D_invert(dp(indices.contiguous()), cu(N), dp(coords))
+
+        @staticmethod
+        def packbits(grid, N, thresh, bitfield):
+            olib.orc_packbits(dp(grid), cu(N), cf(thresh), dp(bitfield))
+
+        @staticmethod
+        def flatten_rays(rays, N, M, res):
+            olib.orc_flatten_rays(dp(rays), cu(N), cu(M), dp(res))
+
+        @staticmethod
+        def march_rays_train(rays_o, rays_d, rays_ldir, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars, xyzs,
+                             dirs, ts, ldirs, rays, counter, noises):
+            olib.orc_march_rays_train(dp(rays_o), dp(rays_d), dp(rays_ldir), dp(grid), cf(bound), ci(int(contract)),
+                                      cf(dt_gamma), cu(max_steps), cu(N), cu(C), cu(H), dp(nears), dp(fars), dp(xyzs), dp(dirs),
+                                      dp(ts), dp(ldirs), dp(rays), dp(counter), dp(noises))
+
+        @staticmethod
+        def composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum, depth, image):
+            olib.orc_composite_rays_train_forward(dp(sigmas), dp(rgbs), dp(ts), dp(rays), cu(M), cu(N), cf(T_thresh), dp(weights),
+                                                  dp(weights_sum), dp(depth), dp(image))
+
+        @staticmethod
+        def composite_rays_train_backward(gw, gws, gd, gi, sigmas, rgbs, ts, rays, weights_sum, depth, image, M, N, T_thresh,
+                                          grad_sigmas, grad_rgbs):
+            olib.orc_composite_rays_train_backward(dp(gw), dp(gws), dp(gd), dp(gi), dp(sigmas), dp(rgbs), dp(ts), dp(rays),
+                                                   dp(weights_sum), dp(depth), dp(image), cu(M), cu(N), cf(T_thresh),
+                                                   dp(grad_sigmas), dp(grad_rgbs))
+
+        @staticmethod
+        def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, contract, dt_gamma, max_steps, C, H, grid, nears,
+                       fars, xyzs, dirs, ts, noises):
+            olib.orc_march_rays(cu(n_alive), cu(n_step), dp(rays_alive), dp(rays_t), dp(rays_o), dp(rays_d), cf(bound),
+                                ci(int(contract)), cf(dt_gamma), cu(max_steps), cu(C), cu(H), dp(grid), dp(nears), dp(fars),
+                                dp(xyzs), dp(dirs), dp(ts), dp(noises))
+
+        @staticmethod
+        def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, ts, weights_sum, depth, image):
+            olib.orc_composite_rays(cu(n_alive), cu(n_step), cf(T_thresh), dp(rays_alive), dp(rays_t), dp(sigmas), dp(rgbs), dp(ts),
+                                    dp(weights_sum), dp(depth), dp(image))
+
+    def segment_csr(src, indptr):
+        out = torch.zeros((indptr.numel() - 1,) + tuple(src.shape[1:]), dtype=src.dtype)
+        for i in range(indptr.numel() - 1):
+            out[i] = src[int(indptr[i]):int(indptr[i + 1])].sum(0)
+        return out
+
+    RM._backend = OracleRayBackend
+    RM.get_backend = lambda: OracleRayBackend
+    RM.segment_csr = segment_csr
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        wr = {}
+        rrng = np.random.default_rng(31)
+        Hg, Nr, STEPS = 32, 48, 128
+        # a procedural occupancy: a ball of radius 0.55 and a slab, Morton-ordered like the density grid
+        cc = (np.stack(np.meshgrid(*[np.arange(Hg)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.int32))
+        ctr = (cc + 0.5) / Hg * 2 - 1
+        occ = ((np.linalg.norm(ctr, axis=1) < 0.55) | (np.abs(ctr[:, 2] + 0.7) < 0.08)).astype(np.float32)
+        m_idx = RM.morton3D(torch.from_numpy(cc))
+        pick = rrng.choice(Hg ** 3, 2048, replace=False)          # (the fixture keeps a sample of the codes)
+        wr["morton_coords"], wr["morton_indices"] = cc[pick], m_idx.numpy()[pick]
+        wr["morton_roundtrip"] = RM.morton3D_invert(m_idx[torch.from_numpy(pick)]).numpy()
+        assert np.array_equal(RM.morton3D_invert(m_idx).numpy(), cc)
+        grid = torch.zeros(1, Hg ** 3)
+        # (values exactly representable in float16, which is how the fixture stores them; none is near the threshold)
+        noise16 = rrng.uniform(0, 1, Hg ** 3).astype(np.float16).astype(np.float32)
+        grid[0, m_idx.long()] = torch.from_numpy(occ) * 7.0 + torch.from_numpy(noise16)
+        grid = grid.to(torch.float16).float()
+        bits = RM.packbits(grid, 5.0)
+        wr["grid"], wr["bitfield"] = grid.numpy().astype(np.float16), bits.numpy()
+        ro = rrng.normal(size=(Nr, 3)).astype(np.float32)
+        ro = 2.4 * ro / np.linalg.norm(ro, axis=1, keepdims=True)
+        rd = (rrng.uniform(-0.5, 0.5, (Nr, 3)) - ro).astype(np.float32)
+        rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+        rd[:6] = rrng.normal(size=(6, 3)).astype(np.float32)        # some rays miss the box
+        ld = rrng.normal(size=(Nr, 3)).astype(np.float32)
+        aabb_t = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32)
+        t_ro, t_rd, t_ld = torch.from_numpy(ro), torch.from_numpy(rd), torch.from_numpy(ld)
+        nears_c, fars_c = RM.near_far_from_aabb(t_ro, t_rd, aabb_t, 0.05)
+        wr.update(rays_o=ro, rays_d=rd, rays_ldir=ld, nears=nears_c.numpy(), fars=fars_c.numpy())
+        wr["sph"] = RM.sph_from_ray(t_ro * 0.3, t_rd, 1.5).numpy()
+        for tag, ldir in (("plain", None), ("lit", t_ld)):
+            o_req, d_req = t_ro.clone().requires_grad_(True), t_rd.clone().requires_grad_(True)
+            xyzs, dirs, ts, rays, ldirs = RM.march_rays_train(o_req, d_req, ldir, 1.0, False, bits, 1, Hg, nears_c, fars_c, False, 0.0,
+                                                              STEPS)
+            wr[f"march_{tag}_xyzs"], wr[f"march_{tag}_dirs"] = xyzs.detach().numpy(), dirs.detach().numpy()
+            wr[f"march_{tag}_ts"], wr[f"march_{tag}_rays"] = ts.detach().numpy(), rays.numpy()
+            if ldirs is not None:
+                wr[f"march_{tag}_ldirs"] = ldirs.detach().numpy()
+            if tag == "plain":       # the march's backward: ray gradients from sample gradients (raymarching.py:319-329)
+                gx = torch.from_numpy(rrng.normal(size=tuple(xyzs.shape)).astype(np.float32))
+                gd_ = torch.from_numpy(rrng.normal(size=tuple(dirs.shape)).astype(np.float32))
+                g_o, g_d = torch.autograd.grad([xyzs, dirs], [o_req, d_req], [gx, gd_])
+                wr.update(march_gxyzs=gx.numpy(), march_gdirs=gd_.numpy(), march_grays_o=g_o.numpy(), march_grays_d=g_d.numpy())
+                wr["flatten"] = RM.flatten_rays(rays, xyzs.shape[0]).numpy()
+                # compositing through the autograd.Function (T_thresh: the Function's own default, 1e-4)
+                Mm = xyzs.shape[0]
+                sig = torch.from_numpy(rrng.lognormal(0.0, 1.5, Mm).astype(np.float32)).requires_grad_(True)
+                rgb = torch.from_numpy(rrng.uniform(0, 1, (Mm, 3)).astype(np.float32)).requires_grad_(True)
+                wts, wsum, dep, img = RM.composite_rays_train(sig, rgb, ts.detach(), rays)
+                gws_, gdep_, gimg_ = [torch.from_numpy(rrng.normal(size=tuple(t.shape)).astype(np.float32)) for t in (wsum, dep, img)]
+                gsig, grgb = torch.autograd.grad([wsum, dep, img], [sig, rgb], [gws_, gdep_, gimg_])
+                wr.update(comp_sigmas=sig.detach().numpy(), comp_rgbs=rgb.detach().numpy(), comp_weights=wts.detach().numpy(),
+                          comp_weights_sum=wsum.detach().numpy(), comp_depth=dep.detach().numpy(), comp_image=img.detach().numpy(),
+                          comp_g_weights_sum=gws_.numpy(), comp_g_depth=gdep_.numpy(), comp_g_image=gimg_.numpy(),
+                          comp_grad_sigmas=gsig.numpy(), comp_grad_rgbs=grgb.numpy())
+        # the inference pair, one round as renderer.py:575-616 drives it
+        n_alive, n_step = Nr, 4
+        alive = torch.arange(Nr, dtype=torch.int32)
+        rays_t = nears_c.clone()
+        xyz_i, dir_i, ts_i = RM.march_rays(n_alive, n_step, alive, rays_t, t_ro, t_rd, 1.0, False, bits, 1, Hg, nears_c, fars_c, False,
+                                           0.0, STEPS)
+        sig_i = torch.from_numpy(rrng.lognormal(0.0, 1.5, n_alive * n_step).astype(np.float32))
+        rgb_i = torch.from_numpy(rrng.uniform(0, 1, (n_alive * n_step, 3)).astype(np.float32))
+        ws_i, dep_i, img_i = torch.zeros(Nr), torch.zeros(Nr), torch.zeros(Nr, 3)
+        RM.composite_rays(n_alive, n_step, alive, rays_t, sig_i, rgb_i, ts_i, ws_i, dep_i, img_i, 1e-2)
+        wr.update(inf_xyzs=xyz_i.numpy(), inf_dirs=dir_i.numpy(), inf_ts=ts_i.numpy(), inf_sigmas=sig_i.numpy(),
+                  inf_rgbs=rgb_i.numpy(), inf_alive=alive.numpy(), inf_rays_t=rays_t.numpy(), inf_weights_sum=ws_i.numpy(),
+                  inf_depth=dep_i.numpy(), inf_image=img_i.numpy())
+        np.savez_compressed(os.path.join(args.out, "wrapper_raymarching.npz"), H=Hg, max_steps=STEPS, n_step=n_step, **wr)
+    finally:
+        torch.Tensor.cuda = _cuda
 
     # ---------------------------------------------------------------- checkpoint layout (state_dict keys/shapes)
     import json

@@ -12,6 +12,13 @@ container and wrote tests/golden/*.npz; the reference itself never travels):
                                        pins G0 / S0 (bound map, flatten / permute / reshape, double normalisation, dtype
                                        and which inputs get gradients); the kernels' arithmetic is the oracle's either way
 
+  wrapper_raymarching.npz              the reference's raymarching/raymarching.py wrappers (:32-476: near/far, sph, Morton,
+                                       packbits, flatten, the two-call march with ldirs, its ray-gradient backward, the
+                                       compositing Function forward / backward, one round of the inference pair) run the
+                                       same way over the oracle's C functions  ->  this repo's wrappers over HIP: pins R0
+                                       (allocation, casting, call protocol, autograd plumbing); torch_scatter.segment_csr
+                                       is restated in the generator as the segmented sum its documentation defines
+
 Tolerances: the MFMA kernels round every operand to f16 (the reference's --fp16 autocast precision): 3e-2 relative on the
 activated outputs, 5e-2 in the L2 sense on gradients (a ReLU whose pre-activation is within f16 rounding of zero may
 flip).  The compositors are f32: 3e-4 relative (prefix products and __expf against exp(-cumsum))."""
@@ -145,3 +152,75 @@ def test_sh_encoder_wrapper_matches_the_reference_wrapper(golden_dir, degree):
     np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"d{degree}_out"], rtol=1e-5, atol=1e-5)
     assert rel_l2(gd.cpu().numpy(), g[f"d{degree}_gdirs"]) < 1e-4
     assert torch.equal(she(d.clone(), size=float(g["size"])), out.detach())
+
+
+def test_raymarching_wrappers_match_the_reference_wrappers(golden_dir):
+    """R0: every wrapper of raymarching/raymarching.py the path uses, called like the reference calls it, on the fixture's
+    rays and occupancy grid.  Integer outputs (Morton codes, bitfield, ray offsets / counts, sample -> ray ids) bit for bit;
+    march positions, ts and directions to 1e-6 (same float expressions, -ffp-contract=off on both sides); compositing 3e-4
+    (wave prefix products, __expf); the march's ray gradients 1e-5 relative."""
+    from raw_ngp_amd import raymarching as RM
+    g = np.load(os.path.join(golden_dir, "wrapper_raymarching.npz"))
+    H, max_steps, n_step = int(g["H"]), int(g["max_steps"]), int(g["n_step"])
+    # Morton / packbits / flatten
+    idx = RM.morton3D(dev(g["morton_coords"]))
+    np.testing.assert_array_equal(idx.cpu().numpy(), g["morton_indices"])
+    np.testing.assert_array_equal(RM.morton3D_invert(idx).cpu().numpy(), g["morton_roundtrip"])
+    grid = dev(g["grid"].astype(np.float32))
+    bits = RM.packbits(grid, 5.0)
+    assert bits.dtype == torch.uint8
+    np.testing.assert_array_equal(bits.cpu().numpy(), g["bitfield"])
+    # near / far (the CUDA flavour: 1 / d, miss -> FLT_MAX) and the background-sphere coordinates
+    ro, rd, ld = dev(g["rays_o"]), dev(g["rays_d"]), dev(g["rays_ldir"])
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32, device="cuda")
+    nears, fars = RM.near_far_from_aabb(ro, rd, aabb, 0.05)
+    np.testing.assert_allclose(nears.cpu().numpy(), g["nears"], rtol=1e-6)
+    np.testing.assert_allclose(fars.cpu().numpy(), g["fars"], rtol=1e-6)
+    np.testing.assert_allclose(RM.sph_from_ray(ro * 0.3, rd, 1.5).cpu().numpy(), g["sph"], rtol=1e-5, atol=1e-6)
+    nears_f, fars_f = dev(g["nears"]), dev(g["fars"])              # (the fixture's own values from here on)
+    # the training march, with and without light directions; both call protocols of this repo's op
+    for single in (True, False):
+        RM.raymarching.single_pass = single
+        try:
+            for tag, ldir in (("plain", None), ("lit", ld)):
+                o_req, d_req = ro.clone().requires_grad_(True), rd.clone().requires_grad_(True)
+                xyzs, dirs, ts, rays, ldirs = RM.march_rays_train(o_req, d_req, ldir, 1.0, False, bits, 1, H, nears_f, fars_f, False,
+                                                                  0.0, max_steps)
+                np.testing.assert_array_equal(rays.cpu().numpy(), g[f"march_{tag}_rays"])
+                np.testing.assert_allclose(xyzs.detach().cpu().numpy(), g[f"march_{tag}_xyzs"], rtol=1e-6, atol=1e-6)
+                np.testing.assert_allclose(ts.detach().cpu().numpy(), g[f"march_{tag}_ts"], rtol=1e-6, atol=1e-7)
+                np.testing.assert_allclose(dirs.detach().cpu().numpy(), g[f"march_{tag}_dirs"], rtol=1e-6)
+                if ldir is not None:
+                    np.testing.assert_allclose(ldirs.detach().cpu().numpy(), g["march_lit_ldirs"], rtol=1e-6)
+                else:
+                    assert ldirs is None
+                    g_o, g_d = torch.autograd.grad([xyzs, dirs], [o_req, d_req], [dev(g["march_gxyzs"]), dev(g["march_gdirs"])])
+                    assert rel_l2(g_o.cpu().numpy(), g["march_grays_o"]) < 1e-5
+                    assert rel_l2(g_d.cpu().numpy(), g["march_grays_d"]) < 1e-5
+                    np.testing.assert_array_equal(RM.flatten_rays(rays, xyzs.shape[0]).cpu().numpy(), g["flatten"])
+        finally:
+            RM.raymarching.single_pass = True
+    # compositing through the autograd.Function, T_thresh = its default
+    sig, rgb = dev(g["comp_sigmas"]).requires_grad_(True), dev(g["comp_rgbs"]).requires_grad_(True)
+    wts, wsum, dep, img = RM.composite_rays_train(sig, rgb, dev(g["march_plain_ts"]), dev(g["march_plain_rays"]))
+    for got, key in ((wts, "comp_weights"), (wsum, "comp_weights_sum"), (dep, "comp_depth"), (img, "comp_image")):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), g[key], rtol=3e-4, atol=3e-4)
+    gsig, grgb = torch.autograd.grad([wsum, dep, img], [sig, rgb],
+                                     [dev(g["comp_g_weights_sum"]), dev(g["comp_g_depth"]), dev(g["comp_g_image"])])
+    assert rel_l2(grgb.cpu().numpy(), g["comp_grad_rgbs"]) < 1e-3
+    assert rel_l2(gsig.cpu().numpy(), g["comp_grad_sigmas"]) < 3e-3
+    # one round of the inference pair
+    N = ro.shape[0]
+    alive = torch.arange(N, dtype=torch.int32, device="cuda")
+    rays_t = nears_f.clone()
+    xyz_i, dir_i, ts_i = RM.march_rays(N, n_step, alive, rays_t, ro, rd, 1.0, False, bits, 1, H, nears_f, fars_f, False, 0.0, max_steps)
+    np.testing.assert_allclose(xyz_i.cpu().numpy(), g["inf_xyzs"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ts_i.cpu().numpy(), g["inf_ts"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dir_i.cpu().numpy(), g["inf_dirs"], rtol=1e-6)
+    ws_i, dep_i, img_i = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, 3, device="cuda")
+    RM.composite_rays(N, n_step, alive, rays_t, dev(g["inf_sigmas"]), dev(g["inf_rgbs"]), ts_i, ws_i, dep_i, img_i, 1e-2)
+    np.testing.assert_array_equal(alive.cpu().numpy(), g["inf_alive"])
+    np.testing.assert_allclose(rays_t.cpu().numpy(), g["inf_rays_t"], rtol=1e-6)
+    np.testing.assert_allclose(ws_i.cpu().numpy(), g["inf_weights_sum"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(dep_i.cpu().numpy(), g["inf_depth"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(img_i.cpu().numpy(), g["inf_image"], rtol=3e-4, atol=3e-5)
