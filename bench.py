@@ -60,10 +60,11 @@ PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 640.0
 FWD_BYTES_PER_SAMPLE = 12 + 16 * (64 + 8)      # 1164 B/sample, SURVEY.md section 8d
 # What the forward's ADDRESS STREAM can reach with the arithmetic taken away: tools/ubench/gather_lines.hip issues exactly the
 # slab forward's loads (same table, same ray-ordered samples, same level -> XCD placement) and nothing else.  Best variant
-# (8-byte gathers, 8 in flight per lane) on 139 264 samples: 54.9 us = 2.54 G samples/s, i.e. 2 953 GB/s in the forward's
-# algorithmic bytes (profiles/r03_ubench_gather_lines.txt; 3 060 GB/s at 204 800 samples).  The table is cache-resident: this,
-# not the 8 TB/s of HBM, is the kernel's ceiling -- `frac_of_line_rate` is measured against it.
-FWD_LINE_RATE_CEILING_GBPS = 2953.0
+# (8-byte gathers, 8 in flight per lane, snake placement of the levels over the XCDs) on 139 264 samples: 36.3 us = 3.84 G
+# samples/s, i.e. 4 465 GB/s in the forward's algorithmic bytes (profiles/r03_ubench_gather_lines.txt; 4 670 GB/s at 204 800
+# samples).  The table is cache-resident: this, not the 8 TB/s of HBM, is the kernel's ceiling -- `frac_of_line_rate` is
+# measured against it.
+FWD_LINE_RATE_CEILING_GBPS = 4465.0
 
 # entry point(s) timed with HIP events -> (index of the samples-per-launch argument, algorithmic bytes per sample)
 ROOFLINE_KERNELS = {

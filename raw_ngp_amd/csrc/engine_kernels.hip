@@ -29,12 +29,19 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     const float *__restrict__ xyzs, float bound, const float *__restrict__ table, const int32_t *__restrict__ offsets,
     float *__restrict__ out, float *__restrict__ inputs01, const int32_t *__restrict__ B_dev, uint32_t B_cap,
     uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w,
-    float *__restrict__ dydx = nullptr)
+    float *__restrict__ dydx = nullptr, uint32_t snake_levels = 0)
 {
     extern __shared__ uint32_t hist[];
-    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t level = item / nchunks;
-    const uint32_t b0 = (item - level * nchunks) * kBlock, b = b0 + threadIdx.x;
+    uint32_t level, tile_;
+    if (snake_levels) {
+        snake_level_tile(blockIdx.x, nchunks, snake_levels, level, tile_);
+        if (level == kNoLevel) return;
+    } else {
+        const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+        level = item / nchunks;
+        tile_ = item - level * nchunks;
+    }
+    const uint32_t b0 = tile_ * kBlock, b = b0 + threadIdx.x;
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
     if (b0 >= B) return;   // whole workgroup
 
@@ -63,8 +70,8 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     // The gathers are bound by the address pipeline (one lane per clock), not by bytes: fetch the two x-neighbours of a
     // corner pair with ONE 16-byte load whenever their rows are adjacent -- always on dense levels (stride 1 along x),
     // and on hashed levels when the cell's x is even (prime_x = 1, so the two hashes differ in bit 0 only).
-    // (PAIR = false, plain 8-byte gathers: 66 us against 60 in the step -- although in tools/ubench/gather_lines.hip, where
-    // nothing but the loads is left, the unpaired stream is the faster one: 55 us against 69.)
+    // (PAIR = false, plain 8-byte gathers: 48 us against 46 in the step -- although in tools/ubench/gather_lines.hip, where
+    // nothing but the loads is left, the unpaired stream is the faster one: 36 us against 46.)
     uint32_t row_id[8];
     float ax = 0.f, ay = 0.f;
     if (live) {
@@ -690,6 +697,12 @@ extern "C" int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound
     NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_forward_slab: L must be in [1, %u]", kMaxLevels);
     NGP_REQUIRE(max_level <= L, "grid_encode_forward_slab: max_level > L");
     const uint32_t nchunks = ceil_div(B_cap, kBlock);
+    // level -> XCD placement: snake (XCD k takes levels k and 15 - k: a cheap coarse level paired with an expensive fine one)
+    // instead of the contiguous split (levels 2k, 2k + 1: XCD 7 gets the two most expensive levels and decides when the
+    // kernel ends) -- 61 -> 46 us in the step; NGP_SNAKE=0 restores the contiguous split (fewer than 8 levels always take it)
+    static const bool snake_on = !(getenv("NGP_SNAKE") && getenv("NGP_SNAKE")[0] == '0');
+    const uint32_t snake_levels = (snake_on && max_level >= 8) ? max_level : 0u;
+    const dim3 grid(snake_levels ? snake_blocks(max_level, nchunks) : nchunks * max_level);
     if (binned_workspace) {
         // the workspace of ngp_x_grid_backward_binned_* for the same samples, planned (mode 2 of prepare): count here
         NGP_REQUIRE(max_level == L && ((uintptr_t)binned_workspace & 15u) == 0 && n_rows_total > 0,
@@ -698,21 +711,21 @@ extern "C" int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound
         NGP_REQUIRE(n_chunks_max <= kMaxChunks, "grid_encode_forward_slab: table too large for the binned backward");
         const WsLayout w = ws_layout(binned_workspace, n_chunks_max);
         if (dydx)
-            grid_forward_slab_kernel<true, true><<<dim3(nchunks * max_level), dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
+            grid_forward_slab_kernel<true, true><<<grid, dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
                 xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-                align_corners != 0, interp, w, dydx);
+                align_corners != 0, interp, w, dydx, snake_levels);
         else
-            grid_forward_slab_kernel<true><<<dim3(nchunks * max_level), dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
+            grid_forward_slab_kernel<true><<<grid, dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
                 xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-                align_corners != 0, interp, w);
+                align_corners != 0, interp, w, nullptr, snake_levels);
     } else if (dydx) {
-        grid_forward_slab_kernel<false, true><<<dim3(nchunks * max_level), dim3(kBlock), 0, as_stream(stream)>>>(
+        grid_forward_slab_kernel<false, true><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-            align_corners != 0, interp, WsLayout{}, dydx);
+            align_corners != 0, interp, WsLayout{}, dydx, snake_levels);
     } else {
-        grid_forward_slab_kernel<false><<<dim3(nchunks * max_level), dim3(kBlock), 0, as_stream(stream)>>>(
+        grid_forward_slab_kernel<false><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-            align_corners != 0, interp, WsLayout{});
+            align_corners != 0, interp, WsLayout{}, nullptr, snake_levels);
     }
     NGP_CHECK_LAUNCH("grid_encode_forward_slab");
     return NGP_OK;

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     const float *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ B_dev, uint32_t B_cap, uint32_t gstride, uint32_t ntiles, uint32_t nbins_cap, LevelRes lv,
     uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w, uint32_t *__restrict__ dir, uint32_t n_tail,
-    MlpDwReduce tail)
+    MlpDwReduce tail, uint32_t snake_levels)
 {
     extern __shared__ uint32_t lds[];
     if (blockIdx.x < n_tail) {   // passengers: the tiny MLPs' weight-gradient reduction (see bin_fill_kernel)
@@ -394,8 +394,15 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     __shared__ float s_wmax[kFillBlock / 64];
 
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
-    const uint32_t item = xcd_remap(blockIdx.x - n_tail, gridDim.x - n_tail);
-    const uint32_t level = item / ntiles, tile = item - level * ntiles;
+    uint32_t level, tile;
+    if (snake_levels) {
+        snake_level_tile(blockIdx.x - n_tail, ntiles, snake_levels, level, tile);
+        if (level == kNoLevel) return;
+    } else {
+        const uint32_t item = xcd_remap(blockIdx.x - n_tail, gridDim.x - n_tail);
+        level = item / ntiles;
+        tile = item - level * ntiles;
+    }
     const uint32_t b0 = tile * kFillTile;
     if (b0 >= B) return;
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
@@ -1010,10 +1017,11 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const float *g
         const WsLayout wl = ws_layout(workspace, c.n_chunks_max, rec_cap);
         uint32_t *dir = ws_dir(wl, rec_cap);
         const size_t lds = (size_t)c.nbins_cap * 8 + (size_t)kRegion * 10;
-        bin_fill_local_kernel<<<ft * max_level + n_tail, kFillBlock, lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft,
-                                                                              c.nbins_cap, c.lv, gridtype, align_corners != 0,
-                                                                              interp, wl, dir, n_tail,
-                                                                              tail ? *tail : MlpDwReduce{});
+        static const bool snake = !(getenv("NGP_SNAKE") && getenv("NGP_SNAKE")[0] == '0');   // (as the slab forward)
+        const bool sn = snake && max_level >= 8;
+        bin_fill_local_kernel<<<(sn ? snake_blocks(max_level, ft) : ft * max_level) + n_tail, kFillBlock, lds, st>>>(
+            grad, inputs, offsets, B_dev, B, grad_stride, ft, c.nbins_cap, c.lv, gridtype, align_corners != 0, interp, wl, dir,
+            n_tail, tail ? *tail : MlpDwReduce{}, sn ? max_level : 0u);
         LocalRecords loc;
         loc.dir = dir;
         loc.B_dev = B_dev;

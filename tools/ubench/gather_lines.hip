@@ -4,7 +4,7 @@
 // the kernel is limited by how fast single cache lines can be requested and returned.  This program issues
 // exactly that kernel's loads -- same table geometry (L = 16, F = 2, T = 2^19, base 16, finest 2048: the bound-1 table of
 // SURVEY.md section 8), same ray-ordered samples (rays through a shell, dt = 2 sqrt(3) / 1024 in world units), same
-// level -> XCD placement, the x-neighbour pairs fetched with one 16-byte load where their rows are adjacent -- and nothing
+// level -> XCD placements, the x-neighbour pairs fetched with one 16-byte load where their rows are adjacent -- and nothing
 // else: no weights, no interpolation, no slab store beyond one float2 per (sample, level) that keeps the loads alive.
 // Variants: levels per thread = 1 / 2 / 4, i.e. 8 / 16 / 32 gathers in flight per lane.
 // Output: microseconds per launch, "line requests" per second (4 lines per sample and hashed level, 1-2 on dense levels: the
@@ -30,14 +30,22 @@
 using namespace ngp;
 
 // LPT levels per thread; workgroup = 256 samples x LPT consecutive levels
-template <uint32_t LPT, bool PAIR>
+// SNAKE (LPT = 1): XCD k takes levels k and 15 - k instead of 2k and 2k + 1 (ngp_common.hpp: snake_level_tile)
+template <uint32_t LPT, bool PAIR, bool SNAKE = false>
 __global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ x01, const float *__restrict__ table,
                                                      const int32_t *__restrict__ offsets, float2 *__restrict__ out,
                                                      uint32_t B, uint32_t nchunks, LevelRes lv)
 {
-    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t lg = item / nchunks;
-    const uint32_t b = (item - lg * nchunks) * 256u + threadIdx.x;
+    uint32_t lg, tile;
+    if (SNAKE) {
+        snake_level_tile(blockIdx.x, nchunks, 16u, lg, tile);
+        if (lg == kNoLevel) return;
+    } else {
+        const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+        lg = item / nchunks;
+        tile = item - lg * nchunks;
+    }
+    const uint32_t b = tile * 256u + threadIdx.x;
     if (b >= B) return;
     float x[3];
 #pragma unroll
@@ -148,6 +156,12 @@ int main(int argc, char **argv)
     });
     run("8 in flight, paired 16-byte loads", [&] {
         gather_kernel<1, true><<<nchunks * 16, 256>>>(d_x, d_tab, d_off, d_out, B, nchunks, lv);
+    });
+    run("8 in flight, 8-byte, snake placement", [&] {
+        gather_kernel<1, false, true><<<snake_blocks(16, nchunks), 256>>>(d_x, d_tab, d_off, d_out, B, nchunks, lv);
+    });
+    run("8 in flight, paired, snake placement", [&] {
+        gather_kernel<1, true, true><<<snake_blocks(16, nchunks), 256>>>(d_x, d_tab, d_off, d_out, B, nchunks, lv);
     });
     run("16 in flight, paired", [&] {
         gather_kernel<2, true><<<nchunks * 8, 256>>>(d_x, d_tab, d_off, d_out, B, nchunks, lv);
