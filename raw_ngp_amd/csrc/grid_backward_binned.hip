@@ -1017,7 +1017,8 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const float *g
         const WsLayout wl = ws_layout(workspace, c.n_chunks_max, rec_cap);
         uint32_t *dir = ws_dir(wl, rec_cap);
         const size_t lds = (size_t)c.nbins_cap * 8 + (size_t)kRegion * 10;
-        static const bool snake = !(getenv("NGP_SNAKE") && getenv("NGP_SNAKE")[0] == '0');   // (as the slab forward)
+        static const bool snake = !(getenv("NGP_SNAKE") && getenv("NGP_SNAKE")[0] == '0') &&
+                                  !(getenv("NGP_SNAKE_FILL") && getenv("NGP_SNAKE_FILL")[0] == '0');   // (as the slab forward)
         const bool sn = snake && max_level >= 8;
         bin_fill_local_kernel<<<(sn ? snake_blocks(max_level, ft) : ft * max_level) + n_tail, kFillBlock, lds, st>>>(
             grad, inputs, offsets, B_dev, B, grad_stride, ft, c.nbins_cap, c.lv, gridtype, align_corners != 0, interp, wl, dir,

@@ -512,6 +512,200 @@ __global__ __launch_bounds__(256) void march_walk_kernel(const float *__restrict
     if (lane == 0) rays[(size_t)n * 2 + 1] = (int32_t)step;
 }
 
+// ------------------------------------------------------------------ constant-step march (arena pass 1, dt_gamma == 0)
+// With dt_gamma == 0 the recurrence is t_{k+1} = fl(t_k + d) for ONE float d, and repeated float addition of a constant has
+// a closed form per binade: inside [2^e, 2^(e+1)) every t is a multiple of u = 2^(e-23); with d = (q + f) u the rounded sum
+// is t + q u or t + (q + 1) u, decided by f alone -- except for f == 1/2 (a tie, broken by the parity of t / u), where the
+// FIRST step of a binade may differ and every later one is the even one of q, q + 1.  So once two consecutive steps inside
+// a binade are equal, every following element of that binade is   bits(t_j) = bits(t_0) + j * s   (bit patterns of positive
+// floats are linear in the mantissa), up to and including the last one below 2^(e+1): the rounded sum stays in the binade
+// exactly when the integer model says so (x = a + q + f < 2^24 - 1/2  <=>  a + s < 2^24 in each of the cases above).  A ray's
+// chain is therefore a short table of segments {first element, its bits, step in ulps}: one run per binade plus the
+// elements produced by real float additions at its edges (the first, irregular, step; the addition that crosses into the
+// next binade).  ~2-3 segments per binade between d's and far's: 20-30, built by ~100 scalar-ish instructions.
+// With the table, element k of the chain is two integer operations, and "the first element >= tt" (the jump out of an empty
+// cell) is one division -- so chain, classify and walk become ONE kernel, wave = ray, that touches no chain or code buffer:
+// the window of 64 candidates is computed, classified and walked in registers.  Same float values as the serial loop, hence
+// the same samples, bit for bit (tests/test_gpu_parity.py: the chain mode with dt_gamma == 0, and the binade / tie sweep).
+constexpr uint32_t kSegCap = 64;   // segments per ray; a chain that needs more is reported like a short chain buffer
+constexpr uint32_t kCsRays = 16;   // rays (= waves) per workgroup: they share one LDS copy of the occupancy index
+
+// the windows of one ray: 64 candidates at a time are computed from the table, classified and walked (the walk is scalar
+// code: k, step, pos live in SGPRs).  Returns the ray's sample count; sample start times go to `slab`.
+template <class Occ>
+__device__ __forceinline__ uint32_t const_step_windows(const Marcher &m, Occ occupied, const uint32_t *seg_k,
+                                                       const uint32_t *seg_b, const uint32_t *seg_s, uint32_t ns,
+                                                       uint32_t len, uint32_t max_steps, float *__restrict__ slab,
+                                                       uint32_t lane)
+{
+    uint32_t k = 0, step = 0, si = 0;   // wave-uniform
+    while (k < len && step < max_steps) {
+        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_k[si + 1]) <= k) si++;
+        const uint32_t e = k + lane;
+        const bool have = e < len;
+        uint32_t c = 0xffffffffu;
+        float tk = 0.0f;
+        if (have) {
+            uint32_t i = si;
+            while (seg_k[i + 1] <= e) i++;
+            tk = __uint_as_float(seg_b[i] + (e - seg_k[i]) * seg_s[i]);
+            float dt, px, py, pz, tt;
+            if (m.classify(tk, dt, px, py, pz, tt, occupied)) {
+                c = 0u;
+            } else {
+                // the serial loop steps until t >= tt: the first element after e that is not below tt (NaN compares false:
+                // one step), or the end of the chain
+                uint32_t j = e + 1u;
+                if (tt == tt) {
+                    const uint32_t btt = __float_as_uint(tt);   // tt >= t >= 0: positive floats order like their bits
+                    j = len;
+                    for (uint32_t ii = i; ii < ns; ii++) {
+                        const uint32_t k0 = seg_k[ii], k1 = seg_k[ii + 1], b0 = seg_b[ii], s = seg_s[ii];
+                        uint32_t jj = k0;
+                        if (btt > b0) jj = s ? k0 + min((btt - b0 + s - 1u) / s, k1 - k0) : k1;
+                        jj = max(jj, e + 1u);
+                        if (jj < k1) {
+                            j = jj;
+                            break;
+                        }
+                    }
+                }
+                c = j - e;
+            }
+        }
+        // The walk.  Serially: pos = 0; while pos is inside the window: a sample is emitted and pos += 1, an empty candidate
+        // jumps, pos += c.  Followed hop by hop that is ~15 dependent scalar iterations per window, and with sixteen rays per
+        // CU the ONE scalar unit of the CU was the kernel's limit (3 200 SALU against 1 600 VALU instructions per ray).  Here
+        // the visited positions are computed by pointer doubling instead: with T(i) = the position after lane i (64 = left
+        // the window) and P_r = T applied 2^r times, lane m composes the P_r of its binary digits and ends with the m-th
+        // visited position o_m -- six rounds of two cross-lane gathers, no scalar loop.
+        uint32_t T = 64u;
+        if (have) T = min(lane + (c ? min(c, 64u) : 1u), 64u);
+        uint32_t P = T, o = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < 6u; r++) {
+            const uint32_t Po = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(o, 63u) << 2), (int)P);
+            if ((lane >> r) & 1u) o = o < 64u ? Po : 64u;
+            if (r < 5u) {
+                const uint32_t PP = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(P, 63u) << 2), (int)P);
+                P = P < 64u ? PP : 64u;
+            }
+        }
+        // o_0 < o_1 < ... while inside the window (and inside the chain: a jump to the chain's end lands on len - k)
+        const uint32_t lim = min(64u, len - k);
+        const bool visited = o < lim;
+        const uint32_t oc = min(o, 63u) << 2;
+        const float t_o = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)oc, (int)__float_as_uint(tk)));
+        const uint32_t c_o = (uint32_t)__builtin_amdgcn_ds_bpermute((int)oc, (int)c);
+        const unsigned long long vis = __ballot(visited), smp = __ballot(visited && c_o == 0u);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(smp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smp, 0u));
+        const uint32_t room = max_steps - step, total = (uint32_t)__popcll(smp);
+        if (visited && c_o == 0u && rank < room) slab[step + rank] = t_o;   // samples in order: one coalesced store
+        step += min(total, room);
+        // where the last visited position leads (not capped: it is the next window's first candidate)
+        const uint32_t last = (uint32_t)__popcll(vis) - 1u;   // (lane 0 is always visited: o_0 = 0 < lim)
+        k += (uint32_t)__builtin_amdgcn_readlane((int)(o + (c_o ? c_o : 1u)), (int)last);
+    }
+    return step;
+}
+
+// index: the occupancy index of occupancy_index_kernel or NULL.  When its non-empty blocks fit `lds_blocks_cap` the
+// workgroup stages it in LDS and every probe is one or two LDS reads instead of a byte load from L2 -- the kernel runs
+// beside the encoder's forward pass, which is bound by exactly those L2 requests; otherwise (early training: every cell
+// occupied) the probes go to the bitfield in global memory.  Same bits either way.
+__global__ __launch_bounds__(kCsRays * 64) void march_const_step_kernel(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid,
+    const uint32_t *__restrict__ index, uint32_t lds_blocks_cap, float bound, bool contract, uint32_t max_steps, uint32_t N,
+    uint32_t C, uint32_t H, const float *__restrict__ nears, const float *__restrict__ fars,
+    const float *__restrict__ noises, uint32_t chain_cap, int32_t *__restrict__ rays, float *__restrict__ t_scratch,
+    int32_t *__restrict__ counter)
+{
+    extern __shared__ uint64_t occ_lds[];
+    __shared__ uint32_t seg_k[kCsRays][kSegCap + 1], seg_b[kCsRays][kSegCap], seg_s[kCsRays][kSegCap];
+    // (readfirstlane: the wave index, and with it everything that depends on the ray alone, in scalar registers)
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    const uint32_t n = blockIdx.x * kCsRays + w;
+    const bool ray = n < N;
+    uint32_t n_groups = 0;
+    bool staged = false;
+    if (index) {
+        const uint32_t nnz = index[0];
+        n_groups = index[1] >> 5;
+        staged = nnz <= lds_blocks_cap;   // uniform over the grid
+        if (staged) {   // pairs and blocks are contiguous in the index: one flat copy of n_groups + nnz 8-byte words
+            const uint64_t *__restrict__ src = reinterpret_cast<const uint64_t *>(index + kOccHeader);
+            for (uint32_t i = threadIdx.x; i < n_groups + nnz; i += kCsRays * 64u) occ_lds[i] = src[i];
+        }
+    }
+    Marcher m;
+    m.setup(rays_o + (size_t)(ray ? n : 0u) * 3, rays_d + (size_t)(ray ? n : 0u) * 3, false, bound, contract, 0.0f, max_steps, C,
+            H, grid);
+    // ---- the segment table (every lane computes the same values; lane 0 stores them)
+    const float d = clampf(0.0f, m.dt_min, m.dt_max);
+    const float far = ray ? fars[n] : 0.0f;
+    float t = ray ? nears[n] : 0.0f;
+    if (ray) t = fmaf(d, noises[n], t);
+    uint32_t len = 0, ns = 0;
+    bool cut = false;
+    // (a loop every lane runs with the same values: the ballot says so to the compiler, which then keeps its counters scalar)
+    while (__ballot(t < far && len < chain_cap) != 0ull) {
+        const uint32_t bt = __float_as_uint(t);
+        if (ns == kSegCap || (bt >> 31)) {   // (negative parameters: not a case the callers produce -- near >= min_near >= 0)
+            cut = true;
+            break;
+        }
+        const float t1 = t + d;
+        const uint32_t b1 = __float_as_uint(t1);
+        uint32_t s = 0, cnt = 1;
+        float tn = t1;
+        if ((bt >> 23) == (b1 >> 23) && b1 > bt) {
+            const uint32_t b2 = __float_as_uint(t1 + d);
+            if ((b2 >> 23) == (bt >> 23) && b2 - b1 == b1 - bt) {   // two equal steps inside the binade: the steady state
+                s = b1 - bt;
+                const uint32_t top = ((bt >> 23) + 1u) << 23, bf = __float_as_uint(far);   // far > t >= 0
+                cnt = (top - 1u - bt) / s + 1u;
+                if (bf < top) cnt = min(cnt, (bf - bt + s - 1u) / s);   // elements below far
+                cnt = min(cnt, chain_cap - len);
+                tn = __uint_as_float(bt + (cnt - 1u) * s) + d;
+            }
+        }
+        if (lane == 0) {
+            seg_k[w][ns] = len;
+            seg_b[w][ns] = bt;
+            seg_s[w][ns] = s;
+        }
+        ns++;
+        len += cnt;
+        t = tn;
+    }
+    if (lane == 0) {
+        seg_k[w][ns] = len;
+        if (ray && (cut || t < far)) atomicOr(counter + 2, 1);   // cut short: reported, never silent (as march_chain_kernel)
+    }
+    __syncthreads();
+    if (!ray) return;
+    len = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+    ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)ns);
+    float *slab = t_scratch + (size_t)n * max_steps;
+    uint32_t step;
+    if (staged) {
+        const uint64_t *pairs = occ_lds, *blocks = occ_lds + n_groups;
+        step = const_step_windows(m, [pairs, blocks](uint32_t bit) -> uint32_t {
+            const uint32_t wd = bit >> 6, k = wd & 31u;
+            const uint64_t pr = pairs[wd >> 5];
+            const uint32_t mask = (uint32_t)pr;
+            if (!((mask >> k) & 1u)) return 0u;
+            const uint32_t idx = (uint32_t)(pr >> 32) + __popc(mask & ((1u << k) - 1u));
+            return (uint32_t)(blocks[idx] >> (bit & 63u)) & 1u;
+        }, seg_k[w], seg_b[w], seg_s[w], ns, len, max_steps, slab, lane);
+    } else {
+        const uint8_t *__restrict__ g = grid;
+        step = const_step_windows(m, [g](uint32_t bit) -> uint32_t { return (g[bit >> 3] >> (bit & 7u)) & 1u; }, seg_k[w],
+                                  seg_b[w], seg_s[w], ns, len, max_steps, slab, lane);
+    }
+    if (lane == 0) rays[(size_t)n * 2 + 1] = (int32_t)step;
+}
+
 // Exclusive prefix sum of rays[:,1] into rays[:,0] in ray order; one workgroup of 1024 lanes
 // walks the rays in tiles (wave shuffle scan + one LDS hop per tile).
 //   reference protocol (arena == false): offsets start at the incoming counter[0]; counter[0] = end.
@@ -955,17 +1149,48 @@ extern "C" int ngp_x_march_rays_train_arena_stage(const float *rays_o, const flo
         NGP_REQUIRE(chain_code && chain_len && chain_cap > 0 && chain_cap < 65536u,
                     "march_rays_train_arena: chain buffers incomplete (chain_cap must be in 1..65535)");
         const float dt_min = 2.0f * kSqrt3 / (float)max_steps, dt_max = 2.0f * kSqrt3 * bound / (float)H;
-        if (stage != 2)
+        // dt_gamma == 0: the chain has a closed form and the three kernels are one (march_const_step_kernel); stage 1 then
+        // has nothing to do.  NGP_MARCH_CONST_STEP=0 keeps the general kernels (A/B runs, tests of both)
+        static const bool const_step_on = !(getenv("NGP_MARCH_CONST_STEP") && getenv("NGP_MARCH_CONST_STEP")[0] == '0');
+        const bool const_step = const_step_on && dt_gamma == 0.0f;
+        if (stage != 2 && !const_step)
             march_chain_kernel<<<NGP_1D(N, kRayBlock)>>>(nears, fars, noises, dt_gamma, dt_min, dt_max, N, chain_cap, chain,
                                                         chain_len, counter);
         if (stage == 1) {
             NGP_CHECK_LAUNCH("march_rays_train_arena");
             return NGP_OK;
         }
-        march_classify_kernel<<<dim3(ceil_div(chain_cap, 256u), min(N, 65535u)), dim3(256), 0, as_stream(stream)>>>(
-            rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, chain_cap, chain, chain_len, chain_code);
-        march_walk_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(chain, chain_len, chain_code, N,
-                                                                                     chain_cap, max_steps, rays, t_scratch);
+        if (const_step) {
+            // with an occupancy index: staged in LDS when it fits.  80 KiB (+ 12 of tables), not all 160: it runs beside the main
+            // stream's kernels and must leave room for their workgroups on its CUs
+            constexpr uint32_t kLdsBudget = 80u * 1024u;
+            uint32_t lds = 0, cap = 0;
+            if (occ_index) {
+                NGP_REQUIRE(n_bits % 2048u == 0 && ((uintptr_t)occ_index & 7u) == 0,
+                            "march_rays_train_arena: occupancy index needs C*H^3 to be a multiple of 2048 and an 8-byte aligned buffer");
+                const uint32_t n_groups = (uint32_t)(n_bits / 2048u);
+                if ((size_t)n_groups * 8 + 8 * 1024 <= kLdsBudget) {
+                    lds = kLdsBudget;
+                    cap = (kLdsBudget - n_groups * 8u) / 8u;
+                    static bool attr_set = false;
+                    if (!attr_set) {
+                        NGP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(march_const_step_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget) == hipSuccess,
+                                    "march_rays_train_arena: cannot raise the dynamic LDS limit");
+                        attr_set = true;
+                    }
+                }
+            }
+            march_const_step_kernel<<<dim3(ceil_div(N, kCsRays)), dim3(kCsRays * 64u), lds, as_stream(stream)>>>(
+                rays_o, rays_d, grid, lds ? occ_index : nullptr, cap, bound, contract != 0, max_steps, N, C, H, nears, fars,
+                noises, chain_cap, rays, t_scratch, counter);
+        } else {
+            march_classify_kernel<<<dim3(ceil_div(chain_cap, 256u), min(N, 65535u)), dim3(256), 0, as_stream(stream)>>>(
+                rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, chain_cap, chain, chain_len,
+                chain_code);
+            march_walk_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(chain, chain_len, chain_code, N,
+                                                                                         chain_cap, max_steps, rays, t_scratch);
+        }
     } else if (occ_index) {
         NGP_REQUIRE(n_bits % 2048u == 0 && ((uintptr_t)grid & 7u) == 0 && ((uintptr_t)occ_index & 7u) == 0,
                     "march_rays_train_arena: occupancy index needs C*H^3 to be a multiple of 2048 and 8-byte aligned buffers");

@@ -185,7 +185,10 @@ class FusedTrainer:
         self.aux = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         # compressed occupancy bitfield the march keeps in LDS (rebuilt after every density-grid refresh)
         self.occ_index = None
-        if self.march_mode == "index" and (model.cascade * model.grid_size ** 3) % 2048 == 0:
+        # (chain mode with dt_gamma == 0: the constant-step march kernel stages the same index in LDS when it fits)
+        indexed = self.march_mode == "index" or (self.march_mode == "chain" and opt.dt_gamma == 0 and dev.type == "cuda"
+                                                 and os.environ.get("NGP_MARCH_INDEX", "1") != "0")
+        if indexed and (model.cascade * model.grid_size ** 3) % 2048 == 0:
             self.occ_index = torch.zeros(rb.occupancy_index_bytes(model.cascade, model.grid_size) // 4,
                                          dtype=torch.int32, device=dev)
         self._occ_version = None
@@ -324,10 +327,7 @@ class FusedTrainer:
         stage 1: only what does not read the occupancy bitfield (near/far, the chain kernel); 2: the rest."""
         opt, m, ar, N = self.opt, self.model, slot.arena, self.N
         if stage != 1:
-            version = getattr(m, "bitfield_version", 0)
-            if self.occ_index is not None and version != self._occ_version:      # the bitfield was re-packed
-                rb.build_occupancy_index(m.density_bitfield, m.cascade, m.grid_size, self.occ_index)
-                self._occ_version = version
+            self._sync_occ_index()
         if stage != 2:
             eb.near_far_from_aabb_v2(rays_o, rays_d, m.aabb_train if aabb is None else aabb, N, m.min_near, slot.nears,
                                      slot.fars)
@@ -469,6 +469,7 @@ class FusedTrainer:
             self._refresh_launches(decay, full)
         m.iter_density += 1
         m.bitfield_version = getattr(m, "bitfield_version", 0) + 1
+        self._occ_version = m.bitfield_version      # (_refresh_launches rebuilt the index)
 
     def _refresh_head_ok(self):
         """May the cell draw of the next refresh (a third kernel chain that reads the density grid but no weights) run
@@ -510,6 +511,16 @@ class FusedTrainer:
             eb.density_grid_scatter(self.dg_indices[:total], self.dg_sigma[:total], total, self.dg_tmp[cas])
         eb.density_grid_update(m.density_grid, self.dg_tmp, decay, self.dg_stats)
         eb.packbits_mean(m.density_grid, self.dg_stats, m.density_thresh, m.density_bitfield)
+        if self.occ_index is not None:              # the march's LDS copy of the bitfield: rebuilt with it
+            rb.build_occupancy_index(m.density_bitfield, m.cascade, m.grid_size, self.occ_index)
+
+    def _sync_occ_index(self):
+        """Rebuild the occupancy index if the bitfield was re-packed behind this object's back (model.update_extra_state)."""
+        m = self.model
+        version = getattr(m, "bitfield_version", 0)
+        if self.occ_index is not None and version != self._occ_version:
+            rb.build_occupancy_index(m.density_bitfield, m.cascade, m.grid_size, self.occ_index)
+            self._occ_version = version
 
     @property
     def mean_density(self):
@@ -824,6 +835,7 @@ class FusedTrainer:
                 if self.world_size > 1:
                     torch.manual_seed(1234567 + step)
                 model.update_extra_state()
+                self._sync_occ_index()
         if not self._image_ready:                       # later steps prepare it right after their Adam step
             self._mlp_prepare()
             self._image_ready = True
@@ -937,13 +949,16 @@ class FusedTrainer:
                 cur = self.slots[(parity + k) % 2]
                 whole = k + 1 < G or last_ahead         # (else a refresh follows: only the bitfield-independent part)
                 nxt = self.slots[(parity + k + 1) % 2] if (whole or self._split_march) else None
+                ops = self._step_ops(cur)
+                at = min(max(int(os.environ.get("NGP_SIDE_FORK_AT", "0")), 0), len(ops) - 1) if nxt is not None else 0
+                self._run_ops(ops[:at], fork=False)
                 if nxt is not None:         # fork: the next step's rays, on the side stream
                     self.side.wait_stream(main)
                     with torch.cuda.stream(self.side):
                         self._load_slot(nxt, stage=0 if whole else 1)
                         if not whole and head:
                             self._refresh_launches(0.95, False, 1)
-                self._run_ops(self._step_ops(cur), fork=bool(getattr(opt, "aux_stream", False)))
+                self._run_ops(ops[at:], fork=bool(getattr(opt, "aux_stream", False)) and at == 0)
                 if nxt is not None:
                     main.wait_stream(self.side)     # join
         self._graphs_alive.append(g)

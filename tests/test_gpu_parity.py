@@ -321,15 +321,16 @@ def test_occupancy_index_is_the_bitfield(be, fill):
     np.testing.assert_array_equal(blocks, words[hot])
 
 
-@pytest.mark.parametrize("mode", ["bitfield", "lds-index", "chain"])
+@pytest.mark.parametrize("mode", ["bitfield", "lds-index", "chain", "chain-index"])
 @pytest.mark.parametrize("case", MARCH_CASES, ids=lambda c: f"N{c[0]}H{c[1]}C{c[3]}b{c[4]}c{int(c[5])}g{c[6] > 0}")
 def test_march_rays_train_arena(be, orc, case, mode):
-    """All three first passes (serial on the bitfield, serial on the LDS index, chain-parallel) against the oracle:
-    counts, ray-ordered offsets, positions and ts bit for bit."""
+    """All first passes (serial on the bitfield, serial on the LDS index, chain-parallel -- which is the one constant-step
+    kernel when dt_gamma == 0 -- without and with the index staged in LDS) against the oracle: counts, ray-ordered offsets,
+    positions and ts bit for bit."""
     N, H, max_steps, C, bound, contract, dt_gamma, ldir = case
     bits, o, d, ld, nears, fars, noises = march_inputs(orc, case, seed=1)
-    index = occupancy_index(be, bits, C, H) if mode == "lds-index" else None
-    chain_cap = max_steps * int(np.ceil(bound)) + 2 if mode == "chain" else 0
+    index = occupancy_index(be, bits, C, H) if mode in ("lds-index", "chain-index") else None
+    chain_cap = max_steps * int(np.ceil(bound)) + 2 if mode.startswith("chain") else 0
     rx, rd, rt, rrays, rl, M = orc.march_rays_train(o, d, ld, bits, bound, contract, dt_gamma, max_steps, C, H, nears,
                                                     fars, noises)
     from raw_ngp_amd.raymarching import MarchArena
@@ -423,6 +424,54 @@ def test_march_chain_reports_a_short_chain_buffer(be, orc):
                                                   ar.xyzs, ar.dirs, ar.ts, None, ar.rays, ar.counter, None, None, ar.chain)
     assert int(ar.counter[2]) == 1
     assert int(host(ar.rays)[:, 1].max()) <= 40
+
+
+def _step_lengths_with_ties():
+    """max_steps values whose step d = 2 sqrt(3) / max_steps (float32, as the kernels compute it) ends in a 1 followed by p
+    zero mantissa bits, p = 3..10: then fl(t + d) is a TIE for every t of the binade whose ulp is 2^(p+1) ulp(d) -- binades
+    inside the range a ray's parameter really takes (0.05 .. 8) -- which is the one case where the closed form of
+    march_const_step_kernel has an irregular first step."""
+    picks = {}
+    for ms in range(200, 5000):
+        dt = np.float32(2.0) * np.float32(1.7320508075688772) / np.float32(ms)
+        mant = (int(dt.view(np.uint32)) & 0x7FFFFF) | 0x800000
+        p = (mant & -mant).bit_length() - 1
+        if 3 <= p <= 10 and p not in picks:
+            picks[p] = ms
+    return sorted(picks.values())
+
+
+@pytest.mark.parametrize("staged", [False, True], ids=["bitfield", "lds-index"])
+@pytest.mark.parametrize("grid", ["full", "bricks"])
+def test_march_constant_step_closed_form_is_the_serial_recurrence(be, orc, grid, staged):
+    """dt_gamma == 0: the candidate parameters come from a per-binade closed form instead of t += dt (raymarching.hip:
+    march_const_step_kernel).  Against the oracle's serial loop, bit for bit, with ray parameters that start anywhere from
+    1e-7 to 7 (up to twenty binades per ray), step lengths that produce round-to-even ties in those binades, a fully
+    occupied grid (every candidate is a sample: ts IS the chain) and a sparse one (every jump target comes from the table)."""
+    from raw_ngp_amd.raymarching import MarchArena
+    H, C, bound, N = 64, 1, 1.0, 768
+    rng = np.random.default_rng(11)
+    bits = np.full(H ** 3 // 8, 0xFF, dtype=np.uint8) if grid == "full" else brick_bitfield(orc, H, cascades=1, seed=4, fill=0.1)[0]
+    steps = _step_lengths_with_ties()
+    assert len(steps) >= 6
+    index = occupancy_index(be, bits, C, H) if staged else None
+    for max_steps in steps + [1024, 333]:
+        o, d = make_rays(rng, N, radius=2.5, jitter=0.6)
+        nears = np.exp(rng.uniform(np.log(1e-7), np.log(7.0), N)).astype(np.float32)
+        nears[:8] = np.float32([0.0, 2.0, 4.0, 0.5, 1.0, 3.9999998, 1.9999999, 0.99999994])
+        fars = (nears + rng.uniform(0.05, 3.5, N)).astype(np.float32)
+        noises = rng.uniform(0, 1, N).astype(np.float32)
+        noises[:8] = 0.0
+        rx, rd, rt, rrays, rl, M = orc.march_rays_train(o, d, None, bits, bound, False, 0.0, max_steps, C, H, nears, fars, noises)
+        assert M > 0
+        ar = MarchArena(N, max_steps, M + 8, "cuda", chain_cap=4 * max_steps)
+        be.raymarching_backend.march_rays_train_arena(dev(o), dev(d), None, dev(bits), bound, False, 0.0, max_steps, N, C, H,
+                                                      dev(nears), dev(fars), dev(noises), ar.t_scratch, M + 8, ar.xyzs,
+                                                      ar.dirs, ar.ts, None, ar.rays, ar.counter, ar.ray_idx, index, ar.chain)
+        written, needed, cut = host(ar.counter)[:3]
+        assert cut == 0 and needed == M and written == M, (max_steps, written, needed, M, cut)
+        assert np.array_equal(host(ar.rays), rrays), max_steps
+        assert np.array_equal(host(ar.ts)[:M], rt) and np.array_equal(host(ar.xyzs)[:M], rx), max_steps
 
 
 def test_march_empty_inputs(be, orc):
