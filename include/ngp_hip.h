@@ -535,6 +535,10 @@ int ngp_x_near_far_from_aabb_v2(const float *rays_o, const float *rays_d, const 
  *                               n_uniform = H^3) then n_occupied cells drawn uniformly among those with density > 0
  *                               (index -1 when none is); xyz = (2 c/(H-1) - 1) * span + (2u - 1) * half with
  *                               span = bound_cas - half (renderer.py:868-872).  Philox4x32-10, counters (i, draw, 2|3, 0).
+ *                               Random draws (full == 0) are DELIVERED half by half in Morton order of their cells, up
+ *                               to the width of a sorting bin (4096 bins per half; any order inside a bin) -- the encoder
+ *                               that evaluates them runs faster on neighbouring points; the multiset of (index, xyz)
+ *                               pairs of each half is that of its draws i.
  *   (caller evaluates the density at xyzs)
  *   ngp_x_density_grid_scatter  tmp[index] = max(tmp[index], sigma); tmp holds -1 where nothing was evaluated
  * then over all cascades:

@@ -326,17 +326,35 @@ def test_density_grid_refresh_kernels_match_oracle(lib, orc, full):
     dgrid = dev(grid)
     e.density_grid_sample(dgrid[0], H, bound - half, half, n_uni, n_occ, full, seed, draw, ws, idx, xyz)
     ridx, rxyz = orc.density_grid_sample(grid[0], H, bound - half, half, n_uni, n_occ, full, seed, draw)
-    np.testing.assert_array_equal(host(idx), ridx)
-    np.testing.assert_allclose(host(xyz), rxyz, rtol=0, atol=2e-7)
+    gidx, gxyz = host(idx), host(xyz)
     if not full:
-        assert np.all(grid[0, ridx[n_uni:]] > 0)                 # second half only picks occupied cells
-        hist = np.bincount(ridx[n_uni:], minlength=cells)[grid[0] > 0]
+        # random draws arrive half by half in Morton order of their cells, up to the width of a sorting bin (4096 bins per
+        # half: blocks of cells for the uniform half, ranges of picks for the occupied one): the same draws as the
+        # restatement's, as a multiset
+        shift = max(int(np.ceil(np.log2(cells))) - 12, 0)
+        assert np.all(np.diff(gidx[:n_uni] >> shift) >= 0)
+        occ = np.flatnonzero(grid[0] > 0)
+        rank = np.searchsorted(occ, gidx[n_uni:])
+        assert np.all(occ[rank] == gidx[n_uni:]) and np.all(np.diff(rank) >= -(len(occ) // 4096 + 2))
+        assert np.array_equal(np.sort(gidx[:n_uni]), np.sort(ridx[:n_uni]))          # (the halves stay where they were)
+        canon = lambda i, x: np.lexsort((x[:, 2], x[:, 1], x[:, 0], i))      # noqa: E731
+        og, orf = canon(gidx, gxyz), canon(ridx, rxyz)
+        np.testing.assert_array_equal(gidx[og], ridx[orf])
+        np.testing.assert_allclose(gxyz[og], rxyz[orf], rtol=0, atol=2e-7)
+        ridx = gidx                                                          # (the order the scatter below sees)
+    else:
+        np.testing.assert_array_equal(gidx, ridx)
+        np.testing.assert_allclose(gxyz, rxyz, rtol=0, atol=2e-7)
+    if not full:
+        ro, _ = orc.density_grid_sample(grid[0], H, bound - half, half, n_uni, n_occ, full, seed, draw)
+        assert np.all(grid[0, ro[n_uni:]] > 0)                   # second half only picks occupied cells
+        hist = np.bincount(ro[n_uni:], minlength=cells)[grid[0] > 0]
         assert hist.max() <= 12 and abs(hist.mean() - n_occ / (grid[0] > 0).sum()) < 1e-9
     # device counter as the draw number gives the same cells
     idx2 = torch.empty_like(idx)
     e.density_grid_sample(dgrid[0], H, bound - half, half, n_uni, n_occ, full, seed,
                           torch.tensor([draw], dtype=torch.int32, device="cuda"), ws, idx2, torch.empty_like(xyz))
-    assert torch.equal(idx, idx2)
+    assert torch.equal(torch.sort(idx).values, torch.sort(idx2).values)
     # scatter + update + packbits
     sig = rng.uniform(0, 4, n).astype(np.float32)
     tmp = torch.full((1, cells), -1.0, device="cuda")
