@@ -214,6 +214,10 @@ int ngp_x_build_occupancy_index(const uint8_t *grid, uint32_t C, uint32_t H, uin
  * counting forward + stage 2), 0 = it only needs the header reset of prepare stage 1 (counting and scanning are wasted). */
 size_t ngp_x_grid_backward_workspace_bytes(uint32_t B, uint32_t L, uint32_t n_rows_total);
 int ngp_x_grid_backward_binned_counts(uint32_t B, uint32_t L, uint32_t n_rows_total, uint32_t max_level_rows);
+/* the workspace's geometry, for tools and tests that look inside it (host call, no GPU): out[0] = table rows per chunk,
+ * out[1] = samples per fill tile, out[2] = record slots per (level, tile) region of the tile-local layout, out[3] = tiles
+ * the tile-local reduce indexes per batch */
+int ngp_x_grid_backward_binned_geometry(uint32_t *out);
 int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,
                                       float *grad_embeddings, const int32_t *B_dev, uint32_t B,
                                       uint32_t grad_stride, uint32_t L, uint32_t max_level,

@@ -120,6 +120,8 @@ def load():
         lib.ngp_x_grid_backward_workspace_bytes.restype = ctypes.c_size_t
         lib.ngp_x_grid_backward_binned_counts.argtypes = [_u, _u, _u, _u]
         lib.ngp_x_grid_backward_binned_counts.restype = ctypes.c_int
+        lib.ngp_x_grid_backward_binned_geometry.argtypes = [ctypes.POINTER(ctypes.c_uint32)]
+        lib.ngp_x_grid_backward_binned_geometry.restype = ctypes.c_int
         lib.ngp_x_occupancy_index_bytes.argtypes = [_u, _u]
         lib.ngp_x_occupancy_index_bytes.restype = ctypes.c_size_t
         lib.ngp_x_density_grid_workspace_bytes.argtypes = [_u]
@@ -141,7 +143,7 @@ def load():
 
 
 def declared_symbols():
-    return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes", "ngp_x_grid_backward_binned_counts",
+    return ["ngp_abi_version", "ngp_last_error", "ngp_x_grid_backward_workspace_bytes", "ngp_x_grid_backward_binned_counts", "ngp_x_grid_backward_binned_geometry",
             "ngp_x_mlp_image_bytes", "ngp_x_mlp_backward_workspace_bytes", "ngp_x_mlp_rf_image_bytes",
             "ngp_x_mlp_rf_backward_workspace_bytes", "ngp_x_occupancy_index_bytes",
             "ngp_x_density_grid_workspace_bytes"] + list(_SIGNATURES)
@@ -385,6 +387,14 @@ class _GridBackend:
     @staticmethod
     def backward_workspace_bytes(B, L, rows):
         return int(load().ngp_x_grid_backward_workspace_bytes(B, L, rows))
+
+    @staticmethod
+    def binned_geometry():
+        """(table rows per chunk, samples per fill tile, record slots per tile-local region, tiles per reduce batch)."""
+        out = (ctypes.c_uint32 * 4)()
+        if load().ngp_x_grid_backward_binned_geometry(out) != 0:
+            raise RuntimeError("ngp_x_grid_backward_binned_geometry failed")
+        return tuple(int(v) for v in out)
 
     @staticmethod
     def backward_needs_counts(B, L, offsets):

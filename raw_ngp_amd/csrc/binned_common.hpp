@@ -5,10 +5,18 @@
 
 namespace ngp {
 
-constexpr uint32_t kChunkRows = 4096;    // rows per chunk: 4096 x float2 = 32 KiB of LDS
-constexpr uint32_t kChunkShift = 12;
+// rows per chunk.  The reduce workgroup of a chunk holds its sums as 2 x int64 per row in LDS: 4096 rows = 64 KiB, two
+// workgroups per CU.  -DNGP_CHUNK_SHIFT=11 builds the 2048-row variant (32 KiB, three workgroups per CU at 80 registers a
+// lane, optimiser state requested after the record gather): measured even with this one in the step (0.3244 / 0.3318 against
+// 0.3270 / 0.3301 ms, same-box pairs) although ONE workgroup per CU costs 55 % (124 against 80 us) -- beyond two the kernel
+// is not short of workgroups in flight; twice the directory words and quad padding eat what the third one brings.
+#ifndef NGP_CHUNK_SHIFT
+#define NGP_CHUNK_SHIFT 12
+#endif
+constexpr uint32_t kChunkShift = NGP_CHUNK_SHIFT;
+constexpr uint32_t kChunkRows = 1u << kChunkShift;
 constexpr uint32_t kSeg = 32768;         // records per reduce work item
-constexpr uint32_t kMaxChunks = 2048;    // LDS histogram bound of the binned path (tables up to 8 M rows)
+constexpr uint32_t kMaxChunks = (1u << 23) >> kChunkShift;   // LDS histogram bound of the binned path (tables up to 8 M rows)
 constexpr uint32_t kSegBig = 8 * kSeg;   // ... of a heavy chunk (coarse dense levels): fewer, longer items
 constexpr uint32_t kReduceBlock = 512;
 constexpr int kHeadroomBits = 25;        // records that may land on one row without overflowing the int64 sum
@@ -63,7 +71,7 @@ __host__ __device__ inline WsLayout ws_layout(void *ws, uint32_t n_chunks_max, s
 // from every tile through the directory column of that chunk.
 constexpr uint32_t kMaxTiles = 2048;     // fill tiles per call the tile-local reduce can index (B <= 1 Mi samples)
 __host__ __device__ inline uint32_t ws_tiles(uint32_t B) { return (B + kFillTile - 1) / kFillTile; }
-constexpr uint32_t kLocalBins = 128;                          // chunks per level the tile-local layout is sized for
+constexpr uint32_t kLocalBins = (1u << 19) >> kChunkShift;    // chunks per level the tile-local layout is sized for (T = 2^19)
 constexpr uint32_t kRegion = kFillTile * 8 + 4 * kLocalBins;  // 8 records per sample + up to 3 slots of padding per chunk
 __host__ __device__ inline size_t ws_rec_cap_local(uint32_t B, uint32_t L) { return (size_t)ws_tiles(B) * L * kRegion; }
 // the directory sits behind the key stream (4-byte aligned: the key stream has an even number of entries)

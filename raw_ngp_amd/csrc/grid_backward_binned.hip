@@ -473,35 +473,38 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
 
     // exclusive scan of the histogram (each chunk's count rounded up to a quad) -> staging offsets = offsets inside the
     // tile's region; the directory words leave right here (plain stores, nothing waits for them) and the up to three
-    // slots of padding behind each run become null records.  Wave 0 scans the level's <= 128 bins, two per lane.
+    // slots of padding behind each run become null records.  Wave 0 scans the level's <= kLocalBins bins, kLocalBins / 64 per lane.
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     uint32_t *dcol = dir + (size_t)first * ntiles + tile;   // dir[chunk][tile]
     if (wid == 0) {
-        const uint32_t i0 = 2u * lane, i1 = i0 + 1u;
-        const uint32_t n0 = i0 < nbins ? hist[i0] : 0u, n1 = i1 < nbins ? hist[i1] : 0u;
-        const uint32_t q0 = (n0 + 3u) & ~3u, q1 = (n1 + 3u) & ~3u;
-        uint32_t inc = q0 + q1;
+        constexpr uint32_t K = kLocalBins / 64u;   // consecutive bins per lane
+        uint32_t n[K], q[K], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < K; j++) {
+            const uint32_t i = K * lane + j;
+            n[j] = i < nbins ? hist[i] : 0u;
+            q[j] = (n[j] + 3u) & ~3u;
+            sum += q[j];
+        }
+        uint32_t inc = sum;
 #pragma unroll
         for (uint32_t d = 1; d < 64u; d <<= 1) {
             const uint32_t up = __shfl_up(inc, d, 64);
             if (lane >= d) inc += up;
         }
-        const uint32_t run0 = inc - (q0 + q1), run1 = run0 + q0;
-        if (i0 < nbins) {
-            lbase[i0] = run0;
-            dcol[(size_t)i0 * ntiles] = run0 | (n0 << 16);
-            for (uint32_t k = n0; k < q0; k++) {
-                stage_key[run0 + k] = 0;
-                stage_val[run0 + k] = make_float2(0.f, 0.f);
+        uint32_t run = inc - sum;
+#pragma unroll
+        for (uint32_t j = 0; j < K; j++) {
+            const uint32_t i = K * lane + j;
+            if (i < nbins) {
+                lbase[i] = run;
+                dcol[(size_t)i * ntiles] = run | (n[j] << 16);
+                for (uint32_t k = n[j]; k < q[j]; k++) {
+                    stage_key[run + k] = 0;
+                    stage_val[run + k] = make_float2(0.f, 0.f);
+                }
             }
-        }
-        if (i1 < nbins) {
-            lbase[i1] = run1;
-            dcol[(size_t)i1 * ntiles] = run1 | (n1 << 16);
-            for (uint32_t k = n1; k < q1; k++) {
-                stage_key[run1 + k] = 0;
-                stage_val[run1 + k] = make_float2(0.f, 0.f);
-            }
+            run += q[j];
         }
         if (lane == 63u) s_total = inc;
     }
@@ -562,6 +565,11 @@ struct AdamArgs {
 // (modes 1 and 2 need one segment per chunk and visit every chunk, also the ones without records)
 // LOCAL: the records live in per-tile regions (bin_fill_local_kernel); the chunk's runs are found through its directory
 // column.  One workgroup per chunk in every mode (the += of mode 0 needs no atomics then).
+// waves per SIMD the reduce kernel is compiled for: 8 per workgroup, as many workgroups per CU as its LDS allows
+constexpr uint32_t kReduceWaves = kChunkShift <= 11 ? 6 : 4;
+#ifndef NGP_REDUCE_PREFETCH
+#define NGP_REDUCE_PREFETCH 0
+#endif
 struct LocalRecords {
     const uint32_t *dir = nullptr;    // [n_chunks][ntiles]: first slot | count << 16
     const int32_t *B_dev = nullptr;
@@ -569,12 +577,12 @@ struct LocalRecords {
 };
 
 template <int MODE, bool LOCAL = false>
-__global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
+__global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(kReduceWaves, kReduceWaves))) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
                                                                  float *__restrict__ grad_table, uint32_t L, WsLayout w,
                                                                  AdamArgs opt, LocalRecords loc = LocalRecords{})
 {
     constexpr bool ADAM = MODE == 1, ALL = MODE != 0 || LOCAL;
-    __shared__ unsigned long long acc[kChunkRows * 2];   // 64 KiB: int64 fixed-point sums, [row][channel]
+    __shared__ unsigned long long acc[kChunkRows * 2];   // 16 bytes a row: int64 fixed-point sums, [row][channel]
     __shared__ uint32_t s_chunk, s_level;
     __shared__ uint32_t s_base[kMaxLevels + 1];
     __shared__ uint32_t s_pref[LOCAL ? kMaxTiles + 1 : 1], s_wsum[kReduceBlock / 64];
@@ -659,7 +667,12 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4,
     constexpr uint32_t kPer = kChunkRows / kReduceBlock;
     float2 pp[kPer], mm[kPer], vv[kPer];
     const size_t adam_base = (size_t)(uint32_t)offsets[level] + row0;
-    if (ADAM) {
+    // When is the optimiser state requested?  NGP_REDUCE_PREFETCH = 1: in front of the record gather (its latency hides
+    // behind the gather, but its 48 registers a lane next to the gather's made the compiler spill 12 at the 128 a lane that
+    // two workgroups per CU allow); 0 (default): behind the gather -- 102 registers, no spill, the other workgroup of the CU
+    // covers the latency: table backward 142 → 135 us in the step, same-box pairs; 2: the parameter in front, the moments behind.
+    constexpr int kPrefetch = NGP_REDUCE_PREFETCH;
+    auto load_state = [&](bool param, bool moments) {
         const float2 *p2 = reinterpret_cast<const float2 *>(opt.param) + adam_base,
                      *m2 = reinterpret_cast<const float2 *>(opt.exp_avg) + adam_base,
                      *v2 = reinterpret_cast<const float2 *>(opt.exp_avg_sq) + adam_base;
@@ -667,17 +680,20 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4,
         for (uint32_t j = 0; j < kPer; j++) {
             const uint32_t i = threadIdx.x + j * kReduceBlock;
             if (i < rows_here) {
-                pp[j] = p2[i];
-                // (the moments are touched once per step, here: streamed past the caches, so that the 98 MB of them do not
-                // evict the table the next forward pass gathers from -- measured -0.75 % step time)
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                const f2 tm = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(m2 + i));
-                const f2 tv = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(v2 + i));
-                mm[j] = make_float2(tm.x, tm.y);
-                vv[j] = make_float2(tv.x, tv.y);
+                if (param) pp[j] = p2[i];
+                if (moments) {
+                    // (the moments are touched once per step, here: streamed past the caches, so that the 98 MB of them do
+                    // not evict the table the next forward pass gathers from -- measured -0.75 % step time)
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const f2 tm = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(m2 + i));
+                    const f2 tv = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(v2 + i));
+                    mm[j] = make_float2(tm.x, tm.y);
+                    vv[j] = make_float2(tv.x, tv.y);
+                }
             }
         }
-    }
+    };
+    if (ADAM && kPrefetch != 0) load_state(true, kPrefetch == 1);
 
     // fixed-point scale: max |g| < 2^e  ->  |g * 2^k| < 2^(62 - headroom) with k = 62 - headroom - e
     int e;
@@ -753,7 +769,7 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4,
             // a run -- 256 records per load round -- two (four) runs per turn.  (Sharing such a chunk among several workgroups was
             // tried -- parked 64-bit sums, a ticket, the last one finishes -- and is slower: the device-scope release /
             // acquire fences write back and invalidate a whole L2 in the middle of a kernel that streams the optimiser state.)
-            constexpr uint32_t kRuns = ADAM ? 2 : 4;   // (the fused variant holds the optimiser state of 8 rows in registers)
+            constexpr uint32_t kRuns = (ADAM || kReduceWaves > 4) ? 2 : 4;   // (register budget: optimiser state, or 80 a lane)
             for (uint32_t t0 = wv; t0 < tiles; t0 += kRuns * (kReduceBlock / 64u)) {
                 uint32_t nq[kRuns];
                 size_t rq[kRuns];   // first quad of the run
@@ -829,6 +845,7 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(4,
         if (i1 + 2 < end) apply(kb.y & 0xffffu, b1.x, b1.y);
         if (i1 + 3 < end) apply(kb.y >> 16, b1.z, b1.w);
     }
+    if (ADAM && kPrefetch != 1) load_state(kPrefetch == 0, true);
     __syncthreads();
     float *dst = grad_table + ((size_t)(uint32_t)offsets[level] + row0) * 2;
     auto to_float = [&](unsigned long long q) { return (float)scalbn((double)(long long)q, -k); };
@@ -941,6 +958,16 @@ int binned_setup(BinnedCall &c, const char *who, const int32_t *offsets, uint32_
     return NGP_OK;
 }
 }  // namespace
+
+extern "C" int ngp_x_grid_backward_binned_geometry(uint32_t *out)
+{
+    NGP_REQUIRE(out, "grid_backward_binned_geometry: null pointer");
+    out[0] = kChunkRows;
+    out[1] = kFillTile;
+    out[2] = kRegion;
+    out[3] = kMaxTiles;
+    return NGP_OK;
+}
 
 extern "C" int ngp_x_grid_backward_binned_counts(uint32_t B, uint32_t L, uint32_t n_rows_total, uint32_t max_level_rows)
 {

@@ -430,7 +430,7 @@ def test_slab_forward_counts_like_the_count_kernel(lib, orc):
     xyz[::997] = 1.5
     gb, eb = lib.gridencoder_backend, lib.engine_backend
     table = dev(rng.uniform(-1, 1, (rows, 2)).astype(np.float32))
-    n_chunks_max = rows // 4096 + L + 1
+    n_chunks_max = rows // gb.binned_geometry()[0] + L + 1
     head_words = 64 + 4 + 4 * n_chunks_max + 2
     for merge in (0, 300):
         ws_a = torch.zeros(gb.backward_workspace_bytes(B, L, rows), dtype=torch.uint8, device="cuda")
@@ -478,7 +478,8 @@ def test_binned_backward_with_zero_gradient_tails(lib, orc):
     gb.grid_backward_binned(dev(grad), dev(x01), dev(offsets), out, cnt, B, B, L, L, S, H, ws)
     np.testing.assert_allclose(host(out), ref, rtol=2e-5, atol=2e-6)
     # fewer records were written than the samples would have emitted with gradients everywhere
-    n_chunks_max = rows // 4096 + L + 1
+    chunk_rows, fill_tile, region, _ = gb.binned_geometry()
+    n_chunks_max = rows // chunk_rows + L + 1
     if gb.backward_needs_counts(B, L, dev(offsets)):     # global-bins layout: per-chunk counts (reserved) and cursors (written)
         head = host(ws[:(68 + 2 * n_chunks_max) * 4]).view(np.uint32)
         reserved, written = head[68:68 + n_chunks_max].sum(), head[68 + n_chunks_max:68 + 2 * n_chunks_max].sum()
@@ -487,7 +488,7 @@ def test_binned_backward_with_zero_gradient_tails(lib, orc):
             out_ = torch.zeros(rows, 2, device="cuda")
             ws_ = torch.zeros(gb.backward_workspace_bytes(B, L, rows), dtype=torch.uint8, device="cuda")
             gb.grid_backward_binned(dev(g), dev(x01), dev(offsets), out_, cnt, B, B, L, L, S, H, ws_)
-            tiles, region = (B + 511) // 512, 512 * 8 + 4 * 128
+            tiles = (B + fill_tile - 1) // fill_tile
             head_bytes = (68 + 4 * n_chunks_max + 2) * 4
             head_bytes += (4 - (head_bytes // 4) % 4) % 4 * 4
             at = head_bytes + tiles * L * region * 10
