@@ -68,18 +68,24 @@ __device__ __forceinline__ TileIn load_tile(const float *__restrict__ enc, size_
     return in;
 }
 
-// One 64-wide layer from a 64-feature input held as fragments xin[kb][s]:  acc[rb] = sum W[rb][kb][s] * xin[kb][s]
-#define NGP_LAYER64(acc, wf, base, xin)                                                   \
-    do {                                                                                  \
-        _Pragma("unroll") for (int rb = 0; rb < 2; rb++) {                                \
-            acc[rb] = zero16();                                                           \
-            _Pragma("unroll") for (int kb = 0; kb < 2; kb++)                              \
-                _Pragma("unroll") for (int s = 0; s < 2; s++)                             \
-                    acc[rb] = mfma(wf[(base) + rb * 4 + kb * 2 + s], xin[kb][s], acc[rb]); \
-        }                                                                                 \
+// One 64-wide layer from a 64-feature input held as fragments xin[kb][s]:  acc[rb] = sum W[rb][kb][s] * xin[kb][s],
+// the weight fragments read from LDS (local fragment ids)
+#define NGP_LAYER64_LDS(acc, lds, lbase, xin)                                                              \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int rb = 0; rb < 2; rb++) {                                                 \
+            acc[rb] = zero16();                                                                            \
+            _Pragma("unroll") for (int kb = 0; kb < 2; kb++)                                               \
+                _Pragma("unroll") for (int s = 0; s < 2; s++)                                              \
+                    acc[rb] = mfma(lds[((lbase) + rb * 4 + kb * 2 + s) * 64 + lane], xin[kb][s], acc[rb]); \
+        }                                                                                                  \
     } while (0)
 
 // ------------------------------------------------------------------ forward
+// Where the weights live: the fragments of the two 64 x 64 layers and of the last one (20 of 32, 20 KiB) in LDS, the rest
+// (W1, W3, W4: 48 registers) in registers.  With all 32 in registers the kernel needs 215 VGPRs -- two waves per SIMD when it
+// has the GPU to itself, but only ONE next to the four waves x 56 registers of the side stream's march
+// (march_const_step_kernel), and half of its 512 workgroups then run in a second round: 25 us beside the march against 12
+// alone.  At 135 registers two waves fit beside the march.
 // PASSENGER: workgroup 0 does the step's one-workgroup bookkeeping (binned_common.hpp: step_begin_block) instead of
 // evaluating the field -- as a kernel of its own it sat on the step's critical path with a dependent-launch gap on top,
 // although nothing consumes its results before the compositor
@@ -101,11 +107,20 @@ __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const float *__rest
     const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_host) : M_host;
     const uint32_t n_tiles = (M + 31u) >> 5;
 
-    half8 wf[32];   // all forward fragments live in registers for the whole kernel
+    __shared__ half8 lds_w[20 * 64];   // local 0..7 = F_W2, 8..15 = F_W5, 16..19 = F_W6
+    constexpr uint32_t L_W2 = 0, L_W5 = 8, L_W6 = 16;
+    for (uint32_t i = threadIdx.x; i < 20u * 64u; i += 256u) {
+        const uint32_t f = i >> 6;
+        lds_w[i] = image[(size_t)(f < 8u ? F_W2 + f : (f < 16u ? F_W5 + (f - 8u) : F_W6 + (f - 16u))) * 64 + (i & 63u)];
+    }
+    half8 wf[20];   // F_W1 (0..3), F_W3 (12..15), F_W4 (16..19) stay in registers; the slots in between are never touched
 #pragma unroll
-    for (int i = 0; i < 32; i++) wf[i] = image[(size_t)i * 64 + lane];
+    for (int i = 0; i < 20; i++)
+        if (i < 4 || i >= 12) wf[i] = image[(size_t)i * 64 + lane];
+    __syncthreads();
 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        asm volatile("" ::: "memory");   // keep the LDS fragments in LDS: no hoisting of 80 registers' worth out of the loop
         const uint32_t row = tile * 32u + n;
         const bool valid = row < M;
         const TileIn in = load_tile(enc, stride, dirs, row, valid, h);
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const float *__rest
             x[kb][1] = pack<1, true>(a[kb]);
         }
         // layer 2: 64 -> 64
-        NGP_LAYER64(a, wf, F_W2, x);
+        NGP_LAYER64_LDS(a, lds_w, L_W2, x);
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
             x[kb][0] = pack<0, true>(a[kb]);
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const float *__rest
             x[kb][1] = pack<1, true>(a[kb]);
         }
         // layer 5: 64 -> 64
-        NGP_LAYER64(a, wf, F_W5, x);
+        NGP_LAYER64_LDS(a, lds_w, L_W5, x);
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
             x[kb][0] = pack<0, true>(a[kb]);
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const float *__rest
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-            for (int s = 0; s < 2; s++) c = mfma(wf[F_W6 + kb * 2 + s], x[kb][s], c);
+            for (int s = 0; s < 2; s++) c = mfma(lds_w[(L_W6 + kb * 2 + s) * 64 + lane], x[kb][s], c);
 
         if (valid && h == 0) {   // rows 0..3 of a tile live in registers 0..3 of the h = 0 lanes
             sigma[row] = __expf(sigma_raw);
