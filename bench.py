@@ -184,7 +184,10 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     # the north star also names the encoder's forward: timed the same way, reported as roofline_forward
     fwd_symbol = "ngp_x_grid_encode_forward_slab"
     probed = symbols + ((fwd_symbol,) if fused and fwd_symbol not in symbols else ())
-    _lib.set_probe(None if (args.no_probe or not probe_on) else probed, arg_idx, every=args.probe_every)
+    # (every probe_every-th step, in the middle of the period: with the default 16 these are the steps half way between two
+    # density-grid refreshes -- a timed step splits its graphs around the probed launches, ~ 50 us the other steps do not pay)
+    _lib.set_probe(None if (args.no_probe or not probe_on) else probed, arg_idx, every=args.probe_every,
+                   phase=args.probe_every // 2)
     if fused and trainer.xchg is not None and trainer.xchg.carrier != "none" and not args.no_probe and probe_on:
         # HIP events around the collectives of the steps whose kernels are probed (the other steps replay them from inside
         # their graphs, where nothing can be timed); switched on BEFORE the burn-in, so that the step variant with its
@@ -350,7 +353,7 @@ def main():
     ap.add_argument("--group-steps", type=int, default=8,
                     help="fused step: consecutive steps per captured graph (1 = one graph launch per step)")
     ap.add_argument("--precapture", action="store_true", help="capture step groups of every length up front instead of 2/4/8 on demand")
-    ap.add_argument("--probe-every", type=int, default=8,
+    ap.add_argument("--probe-every", type=int, default=16,
                     help="time every N-th launch of the roofline entry point with HIP events (each timed launch drains the queue)")
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event roofline probe (roofline: null)")
     ap.add_argument("--no-graph", action="store_true", help="fused step: launch kernels one by one (no hipGraph replay)")

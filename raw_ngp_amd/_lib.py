@@ -171,18 +171,19 @@ def _ptr(t, kind, name, optional=False):
 # C symbol, plus the value of one integer argument (the number of samples the launch processes).  Events cannot be
 # timed inside a captured graph, so the fused engine keeps the probed entry point out of its graphs (it asks
 # `probed_symbol()` when it captures).
-_probe = {"names": (), "arg": 0, "events": [], "every": 1, "calls": {}}
+_probe = {"names": (), "arg": 0, "events": [], "every": 1, "phase": 0, "calls": {}}
 
 
-def set_probe(names, units_arg=0, every=1):
+def set_probe(names, units_arg=0, every=1, phase=0):
     """names: one C symbol or a tuple of them (e.g. the two halves of one operation); units_arg applies to the first.
     every = k times only every k-th call of each symbol (timing events drain the queue around the launch: sampling
-    keeps the measurement from slowing down what it measures)."""
+    keeps the measurement from slowing down what it measures); phase: which of every k calls (call number % k == phase)."""
     if names is None:
         names = ()
     elif isinstance(names, str):
         names = (names,)
-    _probe.update(names=tuple(names), arg=units_arg, events=[], every=max(int(every), 1), calls={})
+    every = max(int(every), 1)
+    _probe.update(names=tuple(names), arg=units_arg, events=[], every=every, phase=int(phase) % every, calls={})
 
 
 def probed_symbols():
@@ -205,7 +206,7 @@ def probe_next_timed():
     """True when the next call of a probed symbol will be bracketed by timing events (see `every`)."""
     if not _probe["names"]:
         return False
-    return _probe["calls"].get(_probe["names"][0], 0) % _probe["every"] == 0
+    return _probe["calls"].get(_probe["names"][0], 0) % _probe["every"] == _probe["phase"]
 
 
 def probe_untimed_run():
@@ -213,7 +214,7 @@ def probe_untimed_run():
     if not _probe["names"]:
         return 1 << 30
     k = _probe["calls"].get(_probe["names"][0], 0) % _probe["every"]
-    return 0 if k == 0 else _probe["every"] - k
+    return (_probe["phase"] - k) % _probe["every"]
 
 
 def probe_skip(names=None):
@@ -245,7 +246,7 @@ def _call(name, anchor, *args):
     if probing and not torch.cuda.is_current_stream_capturing():
         k = _probe["calls"].get(name, 0)
         _probe["calls"][name] = k + 1
-        timed = k % _probe["every"] == 0
+        timed = k % _probe["every"] == _probe["phase"]
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
         if timed:
