@@ -117,12 +117,19 @@ class FusedTrainer:
         self.collective_events = None           # bench.py: [(start, stop)] HIP events around the collectives of timed steps
         self.collective_steps = 0               # ... and how many steps they cover
         if self.dp_mode is not None:
-            self.xchg = parallel.Exchange(dev, carrier=getattr(opt, "dp_exchange", None) if self.dp else "none")
-            if self.xchg.carrier == "rccl" and self.world_size > 1 and not self.xchg.self_test():
-                # (known answers, eagerly and replayed from a graph, agreed on by all ranks)
-                if self.rank == 0:
-                    print("[raw_ngp_amd] direct RCCL exchange failed its self-test: falling back to torch.distributed", flush=True)
-                self.xchg = parallel.Exchange(dev, carrier="torch")
+            want = getattr(opt, "dp_exchange", None) if self.dp else "none"
+            direct = self.dp and self.world_size > 1 and dev.type == "cuda" and want in (None, "rccl") and \
+                parallel.is_dist() and torch.distributed.get_backend() == "nccl"
+            if direct:
+                # bare RCCL calls, captured inside the step graphs -- after known answers (eagerly and replayed from a graph,
+                # agreed on by all ranks, under a deadline: parallel.guarded_rccl_exchange); else torch.distributed's calls
+                self.xchg = parallel.guarded_rccl_exchange(dev)
+                if self.xchg is None:
+                    if self.rank == 0:
+                        print("[raw_ngp_amd] direct RCCL exchange failed its self-test: falling back to torch.distributed", flush=True)
+                    self.xchg = parallel.Exchange(dev, carrier="torch")
+            else:
+                self.xchg = parallel.Exchange(dev, carrier=want)
             # f32 wire: table and MLP weights share ONE flat parameter (and one flat gradient): one collective each way
             n_flat = parallel.padded_numel(n_t + (0 if self.wire16 else n_w))
             self.flat = torch.zeros(n_flat, **f32)

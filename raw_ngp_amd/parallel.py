@@ -212,10 +212,10 @@ class Exchange:
                     dist.all_reduce(b)
                     b.div_(self.R)
 
-    def self_test(self, graph=True):
+    def self_test(self, graph=True, agree=True):
         """Known-answer check of the three collectives on this carrier (rank r contributes r + 1), eagerly and -- for a
         capturable carrier on a GPU -- replayed from a captured graph.  Returns True when every rank agrees that every
-        result is right (the verdict itself is reduced over torch.distributed)."""
+        result is right (the verdict itself is reduced over torch.distributed; agree=False: this rank's own verdict)."""
         ok = True
         try:
             n = 4 * self.R * 256
@@ -249,9 +249,45 @@ class Exchange:
         except Exception as e:      # noqa: BLE001 -- any failure means "do not use this carrier"
             print(f"[rank {self.r}] Exchange.self_test({self.carrier}) failed: {e}", flush=True)
             ok = False
-        if is_dist():
-            on = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
-            v = torch.tensor([1.0 if ok else 0.0], device=on)
-            dist.all_reduce(v, op=dist.ReduceOp.MIN)
-            ok = bool(v.item() == 1.0)
-        return ok
+        return all_ranks_agree(ok, self.device) if agree else ok
+
+
+def all_ranks_agree(ok, device):
+    """True when `ok` is true on every rank (reduced over torch.distributed's default group)."""
+    if is_dist():
+        on = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+        v = torch.tensor([1.0 if ok else 0.0], device=on)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        ok = bool(v.item() == 1.0)
+    return bool(ok)
+
+
+def guarded_rccl_exchange(device, timeout_s=None):
+    """An Exchange over bare RCCL calls that has passed its self-test on every rank -- or None, on every rank.
+
+    Communicator set-up and the self-test (eager and replayed from a captured graph) run in a worker thread with a
+    deadline: a carrier that has never seen more than one rank must not be able to hang the job it is supposed to speed
+    up.  A rank whose worker is still busy at the deadline votes "no" from its main thread; the vote travels over
+    torch.distributed's own communicator, so it completes whatever state the abandoned worker is in."""
+    import threading
+    timeout_s = float(os.environ.get("NGP_RCCL_TIMEOUT", "240")) if timeout_s is None else float(timeout_s)
+    box = {}
+
+    def work():
+        try:
+            if torch.device(device).type == "cuda":
+                torch.cuda.set_device(device)
+            x = Exchange(device, carrier="rccl")
+            box["ok"] = x.carrier == "rccl" and x.self_test(agree=False)
+            box["x"] = x
+        except Exception as e:      # noqa: BLE001 -- any failure means "do not use this carrier"
+            box["ok"] = False
+            print(f"[rank {rank()}] direct RCCL exchange: {e}", flush=True)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    mine = (not t.is_alive()) and bool(box.get("ok"))
+    if t.is_alive():
+        print(f"[rank {rank()}] direct RCCL exchange: no answer within {timeout_s:.0f} s", flush=True)
+    return box.get("x") if all_ranks_agree(mine, device) else None

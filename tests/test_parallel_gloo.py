@@ -78,6 +78,9 @@ def _shard_worker(rank, world, port, out_dir):
     grad[:n] = torch.randn(n, generator=torch.Generator().manual_seed(50 + rank))    # every rank: its own gradient
     x = parallel.Exchange("cpu")
     assert x.carrier == "gloo" and not x.capturable and x.self_test()
+    # the guarded set-up of the bare-RCCL carrier: not available over gloo -> None on every rank, after the vote, quickly
+    assert parallel.guarded_rccl_exchange(torch.device("cpu"), timeout_s=30) is None
+    assert parallel.all_ranks_agree(True, "cpu") and not parallel.all_ranks_agree(rank == 0, "cpu")
     lo, hi = x.shard_bounds(param)
     assert (hi - lo) * world == N and lo == rank * (hi - lo)
     m, v = torch.zeros(hi - lo), torch.zeros(hi - lo)               # moments exist for this rank's shard only
