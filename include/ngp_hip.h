@@ -172,12 +172,18 @@ int ngp_x_march_rays_train_arena(const float *rays_o, const float *rays_d, const
 /* chain != NULL selects the chain-parallel first pass (same result, no serial per-ray loop over the grid): chain
  * (chain_cap * N f32) and chain_code (chain_cap * N u16) are scratch (stored ray-major), chain_len [N] i32; chain_cap must cover
  * (far - near) / dt_min + 1 candidate parameters per ray (max_steps * ceil(bound) + 2 always does).  counter then
- * needs 4 ints: counter[2] becomes non-zero (and stays so) if a ray's chain did not fit. */
+ * needs 4 ints: counter[2] becomes non-zero (and stays so) if a ray's chain did not fit.
+ * With dt_gamma == 0 (constant step) the chain is not stored at all: the candidate parameters have a closed form per
+ * binade and ONE kernel computes, classifies and walks them (raymarching.hip: march_const_step_kernel; same samples bit
+ * for bit; the chain buffers stay untouched, chain_cap still bounds the candidates per ray, near must be >= 0 -- a
+ * negative parameter is reported through counter[2]).  occ_index (ngp_x_build_occupancy_index) then lets that kernel
+ * probe an LDS copy of the bitfield; NULL: probes go to `grid`. */
 
 /* The same march in two halves (chain-parallel variant only, chain != NULL).  stage 0: everything (= the call above);
  * 1: the first kernel alone -- every ray's candidate parameters, from rays, near/far and noise: it does not read the
  * occupancy grid; 2: everything after it.  A caller whose grid is still being rebuilt (density-grid refresh) can run stage 1
- * early and stage 2 once the grid is final; together they are stage 0 bit for bit. */
+ * early and stage 2 once the grid is final; together they are stage 0 bit for bit.  (dt_gamma == 0: stage 1 has nothing to
+ * do, stage 2 is the whole march.) */
 int ngp_x_march_rays_train_arena_stage(const float *rays_o, const float *rays_d, const float *rays_ldir,
                                        const uint8_t *grid, float bound, int contract, float dt_gamma,
                                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
