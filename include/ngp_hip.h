@@ -265,6 +265,19 @@ int ngp_x_grid_backward_binned_apply_mlp(
     const void *mlp_workspace, size_t mlp_workspace_bytes, float *mlp_adam_param, const float *mlp_adam_grad,
     float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq, uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1,
     float mlp_beta2, float mlp_eps, void *mlp_adam_image, ngp_stream_t stream);
+/* ngp_x_grid_backward_binned_apply_mlp over a LIST of samples (tile-local layout only): entry b of the call is sample
+ * sample_index[b] -- `inputs` is addressed by sample, the gradient slab `grad` is in list order (as ngp_x_mlp_backward_list
+ * writes it), *B_dev entries are used.  NULL: samples 0 .. B - 1. */
+int ngp_x_grid_backward_binned_apply_mlp_list(
+    const float *grad, const float *inputs, const int32_t *sample_index, const int32_t *offsets, float *grad_embeddings,
+    const int32_t *B_dev, uint32_t B, uint32_t grad_stride, uint32_t L, uint32_t max_level, float S, uint32_t H,
+    uint32_t gridtype, int align_corners, uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
+    size_t workspace_bytes, float *adam_param, float *adam_exp_avg, float *adam_exp_avg_sq, const float *adam_hyper,
+    float beta1, float beta2, float eps, int overwrite, uint32_t mlp_M, float mlp_loss_scale, float *dw1, float *dw2,
+    float *dw3, float *dw4, float *dw5, float *dw6, const void *mlp_workspace, size_t mlp_workspace_bytes,
+    float *mlp_adam_param, const float *mlp_adam_grad, float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq,
+    uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1, float mlp_beta2, float mlp_eps, void *mlp_adam_image,
+    ngp_stream_t stream);
 /* overwrite != 0 (workspace prepared with single_segment, max_level == L): grad_embeddings = sums for EVERY row of every
  * level (zeros where nothing landed) instead of +=, so the caller neither zeroes the gradient nor pays its read.
  * overwrite == 2: the same, stored as bfloat16 (round to nearest even) -- grad_embeddings then points to
@@ -325,6 +338,15 @@ int ngp_x_mlp_backward_dirs(const float *enc, uint32_t stride, const float *dirs
                             const float *drgb, const int32_t *M_dev, uint32_t M, const void *image, float loss_scale,
                             float *denc, float *ddirs, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
                             float *dw6, void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+/* ngp_x_mlp_backward_dirs over a LIST of samples: sample_index [M] int32 (device; NULL = samples 0 .. M - 1), *M_dev entries
+ * of it are used.  enc / dirs / dsigma / drgb / ddirs are addressed by sample, `denc` (and the delta-3 scratch) in LIST order:
+ * denc[level][c] belongs to sample sample_index[c].  The fused step runs the backward over the samples in front of the
+ * compositor's early stop only (ngp_x_composite_mse_train_idx) -- the others have exactly zero gradients. */
+int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const float *dirs, const float *dsigma,
+                            const float *drgb, const int32_t *M_dev, uint32_t M, const int32_t *sample_index,
+                            const void *image, float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2,
+                            float *dw3, float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
+                            ngp_stream_t stream);
 int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
                         float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
                         const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,
@@ -412,6 +434,14 @@ int ngp_x_composite_mse_train(const float *gt_rgba, const float *bg_rgb, float b
                               const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
                               float T_thresh, float *weights_sum, float *depth, float *image, float *grad_sigmas,
                               float *grad_rgbs, float *loss_out, ngp_stream_t stream);
+/* ngp_x_composite_mse_train that also lists the samples in front of the early stop -- the only ones whose output gradients
+ * can be non-zero: live_n [N] = their number per ray, live_idx [M] = their indices in ray order, live_count [1] = how many.
+ * The backward kernels of the fused step run over that list (ngp_x_mlp_backward_list, ..._binned_apply_mlp_list). */
+int ngp_x_composite_mse_train_idx(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *sigmas,
+                                  const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
+                                  float T_thresh, float *weights_sum, float *depth, float *image, float *grad_sigmas,
+                                  float *grad_rgbs, float *loss_out, int32_t *live_n, int32_t *live_idx,
+                                  int32_t *live_count, ngp_stream_t stream);
 /* The same launch with the HDR loss of nerf/train_utils.py:512-536 (`--image_mode HDR`, the RawNeRF loss) in place of the
  * MSE:  clip = min(1, pred * exposure[n]);  loss = sum((clip - gt)^2 / (1e-3 + sg(clip))^2 * weight) * inv_norm, no
  * gradient where pred * exposure >= 1.  exposure [N]; weight [N,3] = lossmult * loss_weight or NULL (ones);

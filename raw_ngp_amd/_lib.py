@@ -51,12 +51,17 @@ _SIGNATURES = {
                                              ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i,
                                              _u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f,
                                              _f, _f, _p],
+    "ngp_x_grid_backward_binned_apply_mlp_list": [_p, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
+                                                  ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i,
+                                                  _u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p,
+                                                  _f, _f, _f, _p],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u, _i],
     "ngp_x_grid_encode_forward_jac": [_p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _p, _u, _i, _u, _i],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_mlp_backward_dirs": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
+    "ngp_x_mlp_backward_list": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f, _f, _f, _p],
     "ngp_x_mlp_rf_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_rf_forward": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _p],
@@ -80,6 +85,7 @@ _SIGNATURES = {
     "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
     "ngp_x_composite_mse_backward": [_p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p],
     "ngp_x_composite_mse_train": [_p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
+    "ngp_x_composite_mse_train_idx": [_p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "ngp_x_adam_step": [_p, _p, _p, _p, ctypes.c_uint64, _f, _d, _d, _f, _u, _i],
     "ngp_x_near_far_from_aabb_v2": [_p, _p, _p, _u, _f, _p, _p],
     "ngp_x_adam_step_dev": [_p, _p, _p, _p, ctypes.c_uint64, _p, _f, _f, _f, _i],
@@ -238,14 +244,15 @@ def probe_results(names=None):
             sum(a.elapsed_time(b) for _, a, b, _ in ev) * 1e-3)
 
 
-def _call(name, anchor, *args):
+def _call(name, anchor, *args, probe_as=None, probe_shift=0):
     lib = load()
     dev = anchor.device
-    probing = name in _probe["names"]
+    pname = probe_as or name      # (variants of one operation are probed under the operation's name)
+    probing = pname in _probe["names"]
     timed = False
     if probing and not torch.cuda.is_current_stream_capturing():
-        k = _probe["calls"].get(name, 0)
-        _probe["calls"][name] = k + 1
+        k = _probe["calls"].get(pname, 0)
+        _probe["calls"][pname] = k + 1
         timed = k % _probe["every"] == _probe["phase"]
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
@@ -255,8 +262,8 @@ def _call(name, anchor, *args):
         rc = getattr(lib, name)(*args, stream.cuda_stream)
         if timed:
             stop.record(stream)
-            units = int(args[_probe["arg"]]) if name == _probe["names"][0] else 0
-            _probe["events"].append((name, start, stop, units))
+            units = int(args[_probe["arg"] + probe_shift]) if pname == _probe["names"][0] else 0
+            _probe["events"].append((pname, start, stop, units))
     if rc != 0:
         raise RuntimeError(lib.ngp_last_error().decode())
 
@@ -351,12 +358,14 @@ class _GridBackend:
     @staticmethod
     def grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
                                    workspace, gridtype=0, align_corners=False, interp=0, adam=None, overwrite=False,
-                                   mlp_tail=None):
+                                   mlp_tail=None, sample_index=None):
         """Fill + reduce on a workspace prepared for the same positions.  adam = (param, exp_avg, exp_avg_sq, hyper,
         beta1, beta2, eps): apply the optimiser inside the reduce kernel instead of writing grad_embeddings.
         overwrite: grad_embeddings = sums for every row (no +=); a bfloat16 grad_embeddings selects the 16-bit store.
         mlp_tail = (M, loss_scale, dws, workspace, adam, image), the arguments of mlp_backend.reduce_dw: that reduction
-        rides along as extra workgroups of the fill kernel (ngp_x_grid_backward_binned_apply_mlp)."""
+        rides along as extra workgroups of the fill kernel (ngp_x_grid_backward_binned_apply_mlp).
+        sample_index (int32, with mlp_tail): the call runs over a LIST of samples -- `inputs` by sample, `grad` in list order,
+        B_dev[0] entries (ngp_x_grid_backward_binned_apply_mlp_list)."""
         n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
         wire16 = grad_embeddings is not None and grad_embeddings.dtype == torch.bfloat16
         if wire16 and not overwrite:
@@ -372,6 +381,8 @@ class _GridBackend:
                 int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets),
                 workspace.data_ptr(), workspace.numel(), *extra, 2 if wire16 else int(bool(overwrite))]
         if mlp_tail is None:
+            if sample_index is not None:
+                raise RuntimeError("grid_backward_binned_apply: a sample list comes with mlp_tail")
             _call("ngp_x_grid_backward_binned_apply", grad, *args)
             return
         M, loss_scale, dws, mlp_ws, mlp_adam, image = mlp_tail
@@ -381,9 +392,14 @@ class _GridBackend:
             mextra = [_ptr(p_, "f", "mlp_adam_param"), _ptr(g_, "f", "mlp_adam_grad"), _ptr(m_, "f", "mlp_adam_exp_avg"),
                       _ptr(v_, "f", "mlp_adam_exp_avg_sq"), g_.numel(), _ptr(hyper, "f", "mlp_adam_hyper"), float(b1),
                       float(b2), float(eps)]
-        _call("ngp_x_grid_backward_binned_apply_mlp", grad, *args, M, float(loss_scale),
-              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], mlp_ws.data_ptr(), mlp_ws.numel(), *mextra,
-              image.data_ptr() if image is not None else None)
+        tail = [M, float(loss_scale), *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], mlp_ws.data_ptr(), mlp_ws.numel(),
+                *mextra, image.data_ptr() if image is not None else None]
+        if sample_index is not None:
+            # (the probe and the engine know the operation by ONE name: the list variant reports as the plain one)
+            _call("ngp_x_grid_backward_binned_apply_mlp_list", grad, *args[:2], _ptr(sample_index, "i", "sample_index"), *args[2:],
+                  *tail, probe_as="ngp_x_grid_backward_binned_apply_mlp", probe_shift=1)
+        else:
+            _call("ngp_x_grid_backward_binned_apply_mlp", grad, *args, *tail)
 
     @staticmethod
     def backward_workspace_bytes(B, L, rows):
@@ -598,10 +614,12 @@ class _MlpBackend:
         return int(load().ngp_x_mlp_backward_workspace_bytes(M))
 
     @staticmethod
-    def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws, workspace=None, ddirs=None):
+    def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws, workspace=None, ddirs=None,
+                 sample_index=None):
         """dws: six pre-allocated fp32 tensors shaped like the weights (overwritten), or None to leave the partial
         sums in `workspace` for reduce_dw().  workspace: uint8 tensor of backward_workspace_bytes(M) (allocated per
-        call when omitted).  ddirs [M,3] (optional): d loss / d (un-normalised view direction)."""
+        call when omitted).  ddirs [M,3] (optional): d loss / d (un-normalised view direction).  sample_index (int32,
+        optional): run over a LIST of M_dev[0] samples; enc / dirs / dsigma / drgb by sample, denc in list order."""
         nbytes = load().ngp_x_mlp_backward_workspace_bytes(M)
         ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
         if ws.numel() < nbytes or not ws.is_cuda:
@@ -609,7 +627,10 @@ class _MlpBackend:
         grads = [_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)] if dws is not None else [None] * 6
         head = (_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"), _ptr(dsigma, "f", "dsigma"), _ptr(drgb, "f", "drgb"),
                 _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"))
-        if ddirs is not None:
+        if sample_index is not None:
+            _call("ngp_x_mlp_backward_list", enc, *head[:7], _ptr(sample_index, "i", "sample_index"), *head[7:],
+                  _ptr(ddirs, "f", "ddirs", True), *grads, ws.data_ptr(), nbytes)
+        elif ddirs is not None:
             _call("ngp_x_mlp_backward_dirs", enc, *head, _ptr(ddirs, "f", "ddirs"), *grads, ws.data_ptr(), nbytes)
         else:
             _call("ngp_x_mlp_backward", enc, *head, *grads, ws.data_ptr(), nbytes)
@@ -713,12 +734,18 @@ class _EngineBackend:
 
     @staticmethod
     def composite_mse_train(gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, M, N, T_thresh, weights_sum, depth, image,
-                            grad_sigmas, grad_rgbs, loss_out):
-        _call("ngp_x_composite_mse_train", rays, _ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
-              float(bg_const), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"),
-              _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
-              _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
-              _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
+                            grad_sigmas, grad_rgbs, loss_out, live=None):
+        """live = (live_n [N], live_idx [M], live_count [1]) int32: also list the samples in front of the early stop."""
+        args = [_ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
+                float(bg_const), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"),
+                _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
+                _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
+                _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out")]
+        if live is None:
+            _call("ngp_x_composite_mse_train", rays, *args)
+        else:
+            _call("ngp_x_composite_mse_train_idx", rays, *args, _ptr(live[0], "i", "live_n"), _ptr(live[1], "i", "live_idx"),
+                  _ptr(live[2], "i", "live_count"))
 
     @staticmethod
     def composite_hdr_train(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, sigmas, rgbs, ts, rays, M, N, T_thresh,

@@ -269,6 +269,9 @@ struct HdrLoss {
     // entropy of the accumulated opacity (train_utils.py:554-557): loss += lambda * mean_rays(H(clamp(ws, 1e-5, 1 - 1e-5))),
     // H(w) = -w log2 w - (1 - w) log2(1 - w); its gradient joins d loss / d weights_sum
     float lambda_entropy = 0.0f;
+    // MODE 2: the number of samples in front of (and including) the compositor's early stop, per ray slot -- the samples
+    // that can have a gradient at all (live_index_kernel turns the counts into a compact list for the backward kernels)
+    int32_t *live_out = nullptr;
 };
 
 template <int MODE>
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
     float rF, gF, bF, wsF, dF;
     if (MODE == 2) {
         float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0;
+        uint32_t used = live ? cnt : 0u;   // samples up to and including the early stop
         if (live) {
             for (uint32_t base = 0; base < cnt; base += 64u) {
                 const uint32_t i = off + base + lane;
@@ -318,9 +322,13 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
                 ws += wave_sum(w);
                 d += wave_sum(w * t);
                 T = __shfl(Ta, min(last, 63u), 64);
-                if (hit != 0ull) break;   // wave-uniform
+                if (hit != 0ull) {   // wave-uniform
+                    used = base + last + 1u;
+                    break;
+                }
             }
         }
+        if (hdr.live_out && lane == 0 && n < N) hdr.live_out[n] = (int32_t)used;
         rF = r, gF = g, bF = b, wsF = ws, dF = d;
         if (lane == 0 && in_range) {
             ws_out[n] = ws;
@@ -451,6 +459,43 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
         T = __shfl(Ta, min(last, 63u), 64);
         stopped = hit != 0ull;
     }
+}
+
+// ------------------------------------------------------------------ the samples that can have a gradient
+// Behind the compositor's early stop (T < T_thresh) every sample of a ray has exactly zero output gradients -- a third of
+// the batch late in training -- and ray tails do not line up with the 32-sample tiles of the MLP backward or the 512-sample
+// tiles of the table backward's fill, which therefore carry them along.  This kernel turns the per-ray counts of samples in
+// front of the stop (composite_backward_wave_kernel<2>: hdr.live_out) into a compact, ray-ordered list of sample indices;
+// the backward kernels then run over the list (ngp_x_mlp_backward_dirs, ngp_x_grid_backward_binned_apply: sample_index).
+// Same sums, fewer tiles.  One workgroup = 16 rays (a wave each); a workgroup adds up the counts of all rays in front of
+// its own -- N integers out of L2 -- instead of waiting for its predecessors: no scan kernel, no look-back, any order.
+__global__ __launch_bounds__(1024) void live_index_kernel(const int32_t *__restrict__ rays,
+                                                         const int32_t *__restrict__ live_n, uint32_t N, uint32_t M_cap,
+                                                         int32_t *__restrict__ live_idx, int32_t *__restrict__ live_count)
+{
+    __shared__ uint32_t s_part[16], s_mine[16];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, r0 = blockIdx.x * 16u, n = r0 + w;
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < r0; i += 1024u) part += (uint32_t)live_n[i];
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    const uint32_t mine = n < N ? (uint32_t)live_n[n] : 0u;
+    if (lane == 0) {
+        s_part[w] = part;
+        s_mine[w] = mine;
+    }
+    __syncthreads();
+    uint32_t at = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        at += s_part[k] + (k < w ? s_mine[k] : 0u);
+        total += s_part[k] + s_mine[k];
+    }
+    if (n < N) {
+        const uint32_t off = (uint32_t)rays[(size_t)n * 2];
+        for (uint32_t k = lane; k < mine && at + k < M_cap; k += 64u) live_idx[at + k] = (int32_t)(off + k);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) live_count[0] = (int32_t)min(total, M_cap);
 }
 
 // ------------------------------------------------------------------ Adam
@@ -793,6 +838,28 @@ extern "C" int ngp_x_composite_mse_train(const float *gt_rgba, const float *bg_r
         nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, nullptr, nullptr, nullptr, M,
         N, T_thresh, grad_sigmas, grad_rgbs, loss_out, weights_sum, depth, image);
     NGP_CHECK_LAUNCH("composite_mse_train");
+    return NGP_OK;
+}
+
+// ngp_x_composite_mse_train + the list of samples in front of the early stop (live_n [N], live_idx [M], live_count [1])
+extern "C" int ngp_x_composite_mse_train_idx(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *sigmas,
+                                             const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
+                                             float T_thresh, float *weights_sum, float *depth, float *image,
+                                             float *grad_sigmas, float *grad_rgbs, float *loss_out, int32_t *live_n,
+                                             int32_t *live_idx, int32_t *live_count, ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(gt_rgba && rays && weights_sum && depth && image && loss_out && live_n && live_idx && live_count,
+                "composite_mse_train_idx: null tensor");
+    NGP_REQUIRE(M > 0 && sigmas && rgbs && ts && grad_sigmas && grad_rgbs, "composite_mse_train_idx: null sample tensor");
+    NGP_REQUIRE(((uintptr_t)gt_rgba & 15u) == 0, "composite_mse_train_idx: gt_rgba must be 16-byte aligned");
+    HdrLoss hdr;
+    hdr.live_out = live_n;
+    composite_backward_wave_kernel<2><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
+        nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, nullptr, nullptr, nullptr, M,
+        N, T_thresh, grad_sigmas, grad_rgbs, loss_out, weights_sum, depth, image, hdr);
+    live_index_kernel<<<dim3(ceil_div(N, 16u)), dim3(1024), 0, as_stream(stream)>>>(rays, live_n, N, M, live_idx, live_count);
+    NGP_CHECK_LAUNCH("composite_mse_train_idx");
     return NGP_OK;
 }
 

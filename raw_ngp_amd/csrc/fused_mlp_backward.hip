@@ -83,8 +83,10 @@ struct RawTile {
 template <bool VIEW>
 __device__ __forceinline__ RawTile fetch_raw(const float *__restrict__ enc, size_t stride, const float *__restrict__ dirs,
                                              const float *__restrict__ dsigma, const float *__restrict__ drgb,
-                                             const half8 *__restrict__ d3buf, uint32_t row, bool valid, uint32_t h)
+                                             const half8 *__restrict__ d3buf, uint32_t row, uint32_t c, bool valid,
+                                             uint32_t h)
 {
+    // row: the sample (encoder slab, directions, output gradients); c: its place in the list the kernel runs over (delta3)
     RawTile r;
 #pragma unroll
     for (uint32_t s = 0; s < 2; s++)
@@ -113,7 +115,7 @@ __device__ __forceinline__ RawTile fetch_raw(const float *__restrict__ enc, size
             r.gr[1] = drgb[(size_t)row * 3 + 1];
             r.gr[2] = drgb[(size_t)row * 3 + 2];
         } else {
-            r.p3 = d3buf[(size_t)row * 2 + h];
+            r.p3 = d3buf[(size_t)c * 2 + h];
         }
     }
     return r;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
     const float *__restrict__ enc, uint32_t stride, const float *__restrict__ dirs, const float *__restrict__ dsigma,
     const float *__restrict__ drgb, const int32_t *__restrict__ M_dev, uint32_t M_host,
     const half8 *__restrict__ image, float loss_scale, half8 *__restrict__ d3buf, float *__restrict__ partial,
-    float *__restrict__ ddirs)
+    float *__restrict__ ddirs, const int32_t *__restrict__ live_idx)
 {
     extern __shared__ half8 lds_w[];   // fragments 0..45 (46 KiB); reused as the f32 reduction image at the end
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
@@ -235,16 +237,26 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
     for (int i = 0; i < 8; i++) g[i] = zero16();
 
     NGP_STAMP_DECL;
-    RawTile nxt = fetch_raw<true>(enc, stride, dirs, dsigma, drgb, nullptr, wave * 32u + n, wave * 32u + n < M, h);
+    // live_idx: the kernel runs over a LIST of samples (M of them: the ones in front of the compositor's early stop, engine_
+    // kernels.hip: live_index_kernel) instead of samples 0 .. M - 1; delta3 is stored in list order.  The list entry of a tile
+    // is requested two tiles ahead, the tile's inputs one tile ahead.
+    auto sample_of = [&](uint32_t t) -> uint32_t {
+        const uint32_t c = t * 32u + n;
+        return (t < n_tiles && c < M && live_idx) ? (uint32_t)live_idx[c] : c;
+    };
+    uint32_t row_cur = sample_of(wave), row_nxt = sample_of(wave + n_waves);
+    RawTile nxt = fetch_raw<true>(enc, stride, dirs, dsigma, drgb, nullptr, row_cur, wave * 32u + n, wave * 32u + n < M, h);
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         asm volatile("" ::: "memory");   // keep the weight fragments in LDS: no hoisting of 46 KiB into VGPRs
         NGP_STAMP_BEGIN();
-        const uint32_t row = tile * 32u + n;
-        const bool valid = row < M;
+        const uint32_t c_idx = tile * 32u + n, row = row_cur;
+        const bool valid = c_idx < M;
         const RawTile cur = nxt;
         {
-            const uint32_t nrow = (tile + n_waves) * 32u + n;
-            nxt = fetch_raw<true>(enc, stride, dirs, dsigma, drgb, nullptr, nrow, tile + n_waves < n_tiles && nrow < M, h);
+            const uint32_t nc = (tile + n_waves) * 32u + n;
+            nxt = fetch_raw<true>(enc, stride, dirs, dsigma, drgb, nullptr, row_nxt, nc, tile + n_waves < n_tiles && nc < M, h);
+            row_cur = row_nxt;
+            row_nxt = sample_of(tile + 2u * n_waves);
         }
         // samples behind the compositor's early stop (T < T_thresh) have exactly zero output gradients: a tile made of
         // such samples contributes nothing to any weight gradient and its encoder gradient is zero
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
                 half8 z;
 #pragma unroll
                 for (int t = 0; t < 8; t++) z[t] = (_Float16)0.0f;
-                d3buf[(size_t)row * 2 + h] = z;
+                d3buf[(size_t)c_idx * 2 + h] = z;
                 if (DDIRS && h == 0) ddirs[(size_t)row * 3] = ddirs[(size_t)row * 3 + 1] = ddirs[(size_t)row * 3 + 2] = 0.0f;
             }
             continue;
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             for (int s = 0; s < 2; s++) dx3 = mfma(NGP_FRAG(T_W4 + kb * 2 + s), p4[kb][s], dx3);
         // delta3: rows 1..15 = d features, row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp)
         if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
-        if (valid) d3buf[(size_t)row * 2 + h] = pack_sat<0>(dx3);
+        if (valid) d3buf[(size_t)c_idx * 2 + h] = pack_sat<0>(dx3);
         if constexpr (DDIRS) {
             float dx = 0.f, dy = 0.f, dz = 1.f;
             if (valid) {
@@ -468,7 +480,8 @@ template <bool WINDOW>
 __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
     const float *__restrict__ enc, uint32_t stride, const int32_t *__restrict__ M_dev, uint32_t M_host,
     const half8 *__restrict__ image, float inv_loss_scale, const half8 *__restrict__ d3buf,
-    float *__restrict__ denc, float *__restrict__ partial, const float *__restrict__ level_w, uint32_t t3_base)
+    float *__restrict__ denc, float *__restrict__ partial, const float *__restrict__ level_w, uint32_t t3_base,
+    const int32_t *__restrict__ live_idx)
 {
     extern __shared__ half8 lds_w[];   // local 0..11 = F_W1, F_W2 ; 12..25 = T_W3, T_W2, T_W1
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
@@ -487,15 +500,23 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
 #pragma unroll
     for (int i = 0; i < 8; i++) g[i] = zero16();
 
-    RawTile nxt = fetch_raw<false>(enc, stride, nullptr, nullptr, nullptr, d3buf, wave * 32u + n, wave * 32u + n < M, h);
+    // live_idx: as in the view kernel -- the encoder rows of sample live_idx[c], delta3 and d enc in list order (c)
+    auto sample_of = [&](uint32_t t) -> uint32_t {
+        const uint32_t c = t * 32u + n;
+        return (t < n_tiles && c < M && live_idx) ? (uint32_t)live_idx[c] : c;
+    };
+    uint32_t row_nxt = sample_of(wave + n_waves);
+    RawTile nxt = fetch_raw<false>(enc, stride, nullptr, nullptr, nullptr, d3buf, sample_of(wave), wave * 32u + n,
+                                   wave * 32u + n < M, h);
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         asm volatile("" ::: "memory");   // keep the weight fragments in LDS (see the view kernel)
-        const uint32_t row = tile * 32u + n;
+        const uint32_t row = tile * 32u + n;   // (list order: where delta3 is read and d enc written)
         const bool valid = row < M;
         const RawTile cur = nxt;
         {
-            const uint32_t nrow = (tile + n_waves) * 32u + n;
-            nxt = fetch_raw<false>(enc, stride, nullptr, nullptr, nullptr, d3buf, nrow, tile + n_waves < n_tiles && nrow < M, h);
+            const uint32_t nc = (tile + n_waves) * 32u + n;
+            nxt = fetch_raw<false>(enc, stride, nullptr, nullptr, nullptr, d3buf, row_nxt, nc, tile + n_waves < n_tiles && nc < M, h);
+            row_nxt = sample_of(tile + 2u * n_waves);
         }
         const half8 p3 = cur.p3;
         {   // all-zero deltas (see the view kernel): the tile's encoder gradient is zero, nothing else changes
@@ -682,10 +703,12 @@ int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *lev
     NGP_REQUIRE(mlp_backward_lds_ok(), "mlp_backward_grid: cannot raise the dynamic LDS limit");
     if (level_w)
         mlp_backward_grid_kernel<true><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
-                                                                                  d3buf, denc, partial, level_w, t3_base);
+                                                                                  d3buf, denc, partial, level_w, t3_base,
+                                                                                  nullptr);
     else
         mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
-                                                                                   d3buf, denc, partial, nullptr, t3_base);
+                                                                                   d3buf, denc, partial, nullptr, t3_base,
+                                                                                   nullptr);
     NGP_CHECK_LAUNCH("mlp_backward_grid");
     return NGP_OK;
 }
@@ -756,6 +779,16 @@ extern "C" int ngp_x_mlp_backward_dirs(const float *enc, uint32_t stride, const 
                                        float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
                                        ngp_stream_t stream)
 {
+    return ngp_x_mlp_backward_list(enc, stride, dirs, dsigma, drgb, M_dev, M, nullptr, image, loss_scale, denc, ddirs, dw1, dw2,
+                                   dw3, dw4, dw5, dw6, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const float *dirs, const float *dsigma,
+                                       const float *drgb, const int32_t *M_dev, uint32_t M, const int32_t *sample_index,
+                                       const void *image, float loss_scale, float *denc, float *ddirs, float *dw1,
+                                       float *dw2, float *dw3, float *dw4, float *dw5, float *dw6, void *workspace,
+                                       size_t workspace_bytes, ngp_stream_t stream)
+{
     const bool reduce_now = dw1 != nullptr;   // all NULL: leave the per-workgroup partials for ngp_x_mlp_reduce_dw
     NGP_REQUIRE(image && workspace, "mlp_backward: null tensor");
     NGP_REQUIRE(reduce_now ? (dw2 && dw3 && dw4 && dw5 && dw6) : (!dw2 && !dw3 && !dw4 && !dw5 && !dw6),
@@ -774,12 +807,15 @@ extern "C" int ngp_x_mlp_backward_dirs(const float *enc, uint32_t stride, const 
     const half8 *img = reinterpret_cast<const half8 *>(image);
     if (ddirs)
         mlp_backward_view_kernel<true><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
-                                                                                  loss_scale, d3buf, part_view, ddirs);
+                                                                                  loss_scale, d3buf, part_view, ddirs,
+                                                                                  sample_index);
     else
         mlp_backward_view_kernel<false><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M,
-                                                                                   img, loss_scale, d3buf, part_view, nullptr);
+                                                                                   img, loss_scale, d3buf, part_view, nullptr,
+                                                                                   sample_index);
     mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
-                                                                               d3buf, denc, part_grid, nullptr, T_W3);
+                                                                               d3buf, denc, part_grid, nullptr, T_W3,
+                                                                               sample_index);
     if (reduce_now)
         mlp_reduce_dw_kernel<<<dim3(kDwGroups), dim3(256), 0, st>>>(
             MlpDwReduce{part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, MlpAdam{}});

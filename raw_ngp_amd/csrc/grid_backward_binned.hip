@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     const float *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ B_dev, uint32_t B_cap, uint32_t gstride, uint32_t ntiles, uint32_t nbins_cap, LevelRes lv,
     uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w, uint32_t *__restrict__ dir, uint32_t n_tail,
-    MlpDwReduce tail, uint32_t snake_levels)
+    MlpDwReduce tail, uint32_t snake_levels, const int32_t *__restrict__ sample_index)
 {
     extern __shared__ uint32_t lds[];
     if (blockIdx.x < n_tail) {   // passengers: the tiny MLPs' weight-gradient reduction (see bin_fill_kernel)
@@ -414,12 +414,15 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     NGP_FILL_STAMP(0);
     const uint32_t b = b0 + threadIdx.x;
     // position and gradient do not depend on each other: both requests leave before anything waits
+    // (sample_index: the call runs over a LIST of B samples -- the position of entry b is that of sample sample_index[b],
+    // the gradient slab is in list order; ngp_x_mlp_backward_list wrote it that way)
     float x[3] = {0.f, 0.f, 0.f};
     float2 gr = make_float2(0.0f, 0.0f);
     if (b < B) {
-#pragma unroll
-        for (uint32_t d = 0; d < 3; d++) x[d] = inputs[(size_t)b * 3 + d];
         gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * gstride + b];
+        const size_t sb = sample_index ? (size_t)(uint32_t)sample_index[b] : (size_t)b;
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) x[d] = inputs[sb * 3 + d];
     }
     for (uint32_t i = threadIdx.x; i < nbins; i += kFillBlock) hist[i] = 0;
     __syncthreads();
@@ -1007,7 +1010,8 @@ extern "C" int ngp_x_grid_backward_binned_prepare(const float *inputs, float in_
 }
 
 // fill + reduce on a prepared workspace (same inputs, in [0,1], and the same B_dev value as the prepare call)
-static int binned_apply(const char *who, const MlpDwReduce *tail, const float *grad, const float *inputs, const int32_t *offsets,
+static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t *sample_index, const float *grad,
+                        const float *inputs, const int32_t *offsets,
                                                 float *grad_embeddings, const int32_t *B_dev, uint32_t B,
                                                 uint32_t grad_stride, uint32_t L, uint32_t max_level, float S,
                                                 uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
@@ -1049,7 +1053,7 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const float *g
         const bool sn = snake && max_level >= 8;
         bin_fill_local_kernel<<<(sn ? snake_blocks(max_level, ft) : ft * max_level) + n_tail, kFillBlock, lds, st>>>(
             grad, inputs, offsets, B_dev, B, grad_stride, ft, c.nbins_cap, c.lv, gridtype, align_corners != 0, interp, wl, dir,
-            n_tail, tail ? *tail : MlpDwReduce{}, sn ? max_level : 0u);
+            n_tail, tail ? *tail : MlpDwReduce{}, sn ? max_level : 0u, sample_index);
         LocalRecords loc;
         loc.dir = dir;
         loc.B_dev = B_dev;
@@ -1069,6 +1073,7 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const float *g
         NGP_CHECK_LAUNCH("grid_backward_binned_apply");
         return NGP_OK;
     }
+    NGP_REQUIRE(!sample_index, "grid_backward_binned_apply: a sample list needs the tile-local layout (see ..._binned_counts)");
     bin_fill_kernel<<<ft * max_level + n_tail, kFillBlock, c.fill_lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft,
                                                                             c.nbins_cap, c.lv, gridtype, align_corners != 0,
                                                                             interp, c.w, n_tail, tail ? *tail : MlpDwReduce{});
@@ -1094,7 +1099,7 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
                                                 float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
                                                 float beta2, float eps, int overwrite, ngp_stream_t stream)
 {
-    return binned_apply("grid_backward_binned_apply", nullptr, grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L,
+    return binned_apply("grid_backward_binned_apply", nullptr, nullptr, grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L,
                         max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
                         workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
                         stream);
@@ -1112,6 +1117,27 @@ extern "C" int ngp_x_grid_backward_binned_apply_mlp(
     float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq, uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1,
     float mlp_beta2, float mlp_eps, void *mlp_adam_image, ngp_stream_t stream)
 {
+    return ngp_x_grid_backward_binned_apply_mlp_list(
+        grad, inputs, nullptr, offsets, grad_embeddings, B_dev, B, grad_stride, L, max_level, S, H, gridtype, align_corners, interp,
+        n_rows_total, max_level_rows, workspace, workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1,
+        beta2, eps, overwrite, mlp_M, mlp_loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, mlp_workspace, mlp_workspace_bytes,
+        mlp_adam_param, mlp_adam_grad, mlp_adam_exp_avg, mlp_adam_exp_avg_sq, mlp_adam_n, mlp_adam_hyper, mlp_beta1, mlp_beta2,
+        mlp_eps, mlp_adam_image, stream);
+}
+
+// ... over a LIST of samples: entry b of the call is sample sample_index[b] (its position is inputs[sample_index[b]]), the
+// gradient slab `grad` is in list order, *B_dev entries are used (NULL = samples 0 .. B - 1: the call above)
+extern "C" int ngp_x_grid_backward_binned_apply_mlp_list(
+    const float *grad, const float *inputs, const int32_t *sample_index, const int32_t *offsets, float *grad_embeddings,
+    const int32_t *B_dev, uint32_t B, uint32_t grad_stride, uint32_t L, uint32_t max_level, float S, uint32_t H,
+    uint32_t gridtype, int align_corners, uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
+    size_t workspace_bytes, float *adam_param, float *adam_exp_avg, float *adam_exp_avg_sq, const float *adam_hyper,
+    float beta1, float beta2, float eps, int overwrite, uint32_t mlp_M, float mlp_loss_scale, float *dw1, float *dw2,
+    float *dw3, float *dw4, float *dw5, float *dw6, const void *mlp_workspace, size_t mlp_workspace_bytes,
+    float *mlp_adam_param, const float *mlp_adam_grad, float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq,
+    uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1, float mlp_beta2, float mlp_eps, void *mlp_adam_image,
+    ngp_stream_t stream)
+{
     NGP_REQUIRE(B != 0 && max_level != 0, "grid_backward_binned_apply_mlp: nothing to launch the reduction with");
     MlpDwReduce r;
     const int rc = mlp_dw_reduce_args(r, "grid_backward_binned_apply_mlp", mlp_M, mlp_loss_scale, dw1, dw2, dw3, dw4, dw5, dw6,
@@ -1119,8 +1145,8 @@ extern "C" int ngp_x_grid_backward_binned_apply_mlp(
                                       mlp_adam_exp_avg_sq, mlp_adam_n, mlp_adam_hyper, mlp_beta1, mlp_beta2, mlp_eps,
                                       mlp_adam_image);
     if (rc != NGP_OK) return rc;
-    return binned_apply("grid_backward_binned_apply_mlp", &r, grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L,
-                        max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
+    return binned_apply("grid_backward_binned_apply_mlp", &r, sample_index, grad, inputs, offsets, grad_embeddings, B_dev, B,
+                        grad_stride, L, max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
                         workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
                         stream);
 }

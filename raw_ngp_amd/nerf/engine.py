@@ -51,6 +51,10 @@ class _Slot:
         self.head_step = -1                # ... or whose rays are drawn and half marched (in front of a grid refresh)
 
 
+def dev_is_cuda(device):
+    return torch.device(device).type == "cuda"
+
+
 class FusedTrainer:
     """Drop-in for Trainer.train_step / train on models that satisfy NeRFNetwork._fused()."""
 
@@ -281,6 +285,11 @@ class FusedTrainer:
         self.x01 = torch.empty(cap, 3, **f32)
         self.sigma, self.rgb = torch.empty(cap, **f32), torch.empty(cap, 3, **f32)
         self.dsigma, self.drgb = torch.empty(cap, **f32), torch.empty(cap, 3, **f32)
+        # the samples in front of the compositor's early stop, as a list the backward kernels run over (the others -- a third
+        # of the batch late in training -- have exactly zero gradients): plain field, MSE loss, tile-local table backward
+        self.live_n = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.live_idx = torch.zeros(cap, dtype=torch.int32, device=dev)
+        self.live_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.weights_buf = torch.empty(cap, **f32)
         self.ws, self.depth, self.image = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, 3, **f32)
         self.loss = torch.zeros(1, **f32)
@@ -397,7 +406,16 @@ class FusedTrainer:
                                        self.drgb, self.loss)
                 return
             eb.composite_mse_train(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh,
-                                   self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss)
+                                   self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
+                                   live=(self.live_n, self.live_idx, self.live_count) if live_list else None)
+
+        # the backward over the list of samples that can have a gradient (see __init__): the step path of the plain field
+        # with the MSE loss, when the weight-gradient reduction rides on the fill launch and the records are tile-local
+        lam_ = float(getattr(opt, "lambda_entropy", 0.0))
+        live_list = bool(fuse_composite and mlp_tail is not None and not (self.rfield or self.pose or self.hdr or self.adaptive)
+                         and lam_ == 0.0 and not self.binned_counts and dev_is_cuda(self.device)
+                         and os.environ.get("NGP_LIVE_LIST", "1") != "0")
+        back_n, back_idx = (self.live_count, self.live_idx) if live_list else (cnt, None)
 
         def mlp_backward():
             if self.rfield:         # one call: both view kernels, the density kernel, the weight-gradient reduction
@@ -407,9 +425,9 @@ class FusedTrainer:
                 if self.baa:        # the blend's adjoint: d enc' -> d enc (what the table backward and the ray gradients read)
                     eb.slab_window(self.denc, cap, self.L, self.level_w, cnt, cap, backward=True)
             else:
-                self.mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, cnt, cap, self.mlp_image, opt.loss_scale,
+                self.mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, back_n, cap, self.mlp_image, opt.loss_scale,
                                  self.denc, None if split_weights else self.dws, self.ws_mlp,
-                                 ddirs=self.ddirs if self.pose else None)
+                                 ddirs=self.ddirs if self.pose else None, sample_index=back_idx)
                 if self.pose:       # the window's adjoint: d enc' -> d enc
                     eb.slab_window(self.denc, cap, self.L, self.level_w, cnt, cap, backward=True, scale_only=not self.baa)
 
@@ -428,8 +446,9 @@ class FusedTrainer:
             ("ngp_x_composite_mse_backward", loss_and_composite_backward),
             ("ngp_x_mlp_backward", mlp_backward),
             ("ngp_x_grid_backward_binned_apply" + ("_mlp" if mlp_tail is not None else ""), lambda: gb.grid_backward_binned_apply(
-                self.denc, self.x01, offsets, self._wire if overwrite and self.wire16 else self.table_grad, cnt, cap, cap,
-                self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite, mlp_tail=mlp_tail)),
+                self.denc, self.x01, offsets, self._wire if overwrite and self.wire16 else self.table_grad, back_n, cap, cap,
+                self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite, mlp_tail=mlp_tail,
+                sample_index=back_idx)),
         ]
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]

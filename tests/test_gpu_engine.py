@@ -895,3 +895,90 @@ def test_grid_kernels_at_their_boundaries_stay_inside_their_buffers(lib, orc):
     last = int(offsets[-1]) - 1
     assert np.abs(ref_g[int(offsets[-2]):]).sum() > 0             # the last level received gradient
     assert host(grad)[last].tolist() == pytest.approx(ref_g[last].tolist(), rel=1e-4, abs=1e-6)
+
+
+def test_compositor_lists_the_samples_in_front_of_the_early_stop(lib, orc):
+    """ngp_x_composite_mse_train_idx: per ray the number of samples up to and including the one that drives the
+    transmittance below T_thresh (what the oracle's compositor uses), their indices in ray order, and their total -- and the
+    output gradients behind the list are exactly zero."""
+    from test_oracle_raymarching import synth_samples
+    e = lib.engine_backend
+    rng = np.random.default_rng(17)
+    N = 3000
+    sig, rgb, ts, rays, M = synth_samples(rng, N)
+    sig *= 6.0                                                   # dense enough for early stops
+    T_thresh = 1e-3
+    w_ref, *_ = orc.composite_rays_train_forward(sig, rgb, ts, rays, M, N, T_thresh)
+    gt = rng.uniform(0, 1, (N, 4)).astype(np.float32)
+    outs = [torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 3, device="cuda")]
+    ds, dc, loss = torch.empty(M, device="cuda"), torch.empty(M, 3, device="cuda"), torch.zeros(1, device="cuda")
+    live_n = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    live_idx = torch.full((M,), -1, dtype=torch.int32, device="cuda")
+    live_count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    e.composite_mse_train(dev(gt), None, 1.0, dev(sig), dev(rgb), dev(ts), dev(rays), M, N, T_thresh, *outs, ds, dc, loss,
+                          live=(live_n, live_idx, live_count))
+    # reference: replay the stop rule per ray (alpha, transmittance in float32 like the kernels: the stop index may differ by
+    # one where T crosses the threshold within rounding -- none of the 3000 rays does here, checked below through the gradients)
+    want_n = np.zeros(N, np.int64)
+    for n in range(N):
+        o, c = rays[n]
+        T = np.float32(1.0)
+        used = c
+        for k in range(c):
+            a = np.float32(1.0) - np.exp(np.float32(-sig[o + k] * ts[o + k, 1]), dtype=np.float32)
+            T = np.float32(T * (np.float32(1.0) - a))
+            if T < T_thresh:
+                used = k + 1
+                break
+        want_n[n] = used
+    got_n = host(live_n).astype(np.int64)
+    assert np.abs(got_n - want_n).max() <= 1 and (got_n != want_n).mean() < 0.01
+    assert 0.3 * M < got_n.sum() < 0.95 * M                       # stops do happen, and not everywhere
+    assert int(live_count[0]) == got_n.sum()
+    want_idx = np.concatenate([rays[n, 0] + np.arange(got_n[n]) for n in range(N)])
+    np.testing.assert_array_equal(host(live_idx)[:len(want_idx)], want_idx)
+    dead = np.ones(M, bool)
+    dead[want_idx] = False
+    assert np.all(host(ds)[dead] == 0.0) and np.all(host(dc)[dead] == 0.0)
+    assert np.count_nonzero(host(ds)[~dead]) > 0.9 * (~dead).sum()
+
+
+def test_table_backward_over_a_sample_list(lib, orc):
+    """ngp_x_grid_backward_binned_apply_mlp_list: fill + reduce over a list of samples (positions by sample, gradient slab in
+    list order) against the same call over all samples with zero gradients at the unlisted ones."""
+    gb, mb = lib.gridencoder_backend, lib.mlp_backend
+    rng = np.random.default_rng(23)
+    L, H, B = 16, 16, 20000
+    offsets, scale = orc.grid_offsets(desired_resolution=2048)
+    S, rows = float(np.log2(scale)), int(offsets[-1])
+    o = rng.uniform(0.1, 0.9, (400, 1, 3))
+    d = rng.normal(size=(400, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x01 = np.clip(o + d * (np.arange(50)[None, :, None] * 0.0017), 0.001, 0.999).reshape(-1, 3).astype(np.float32)
+    live = np.ones(B, bool)
+    live.reshape(400, 50)[:, 33:] = False                         # every ray's tail is dead
+    idx = np.flatnonzero(live).astype(np.int32)
+    g_full = rng.normal(size=(L, B, 2)).astype(np.float32)
+    g_full[:, ~live] = 0.0
+    g_list = np.zeros_like(g_full)
+    g_list[:, :len(idx)] = g_full[:, idx]
+    W = [torch.zeros(o_, i_, device="cuda") for o_, i_ in [(64, 32), (64, 64), (16, 64), (64, 31), (64, 64), (3, 64)]]
+    mws = torch.zeros(mb.backward_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+
+    def run(grad, sample_index, count):
+        out = torch.zeros(rows, 2, device="cuda")
+        ws = torch.zeros(gb.backward_workspace_bytes(B, L, rows), dtype=torch.uint8, device="cuda")
+        cnt = torch.tensor([count, count, 0, 0], dtype=torch.int32, device="cuda")
+        gb.grid_backward_binned_prepare(None, 0.0, dev(offsets), rows, cnt, B, L, L, S, H, ws, stage=1)
+        dws = [torch.empty_like(w) for w in W]
+        gb.grid_backward_binned_apply(dev(grad), dev(x01), dev(offsets), out, cnt, B, B, L, L, S, H, ws,
+                                      mlp_tail=(B, 1.0, dws, mws, None, None), sample_index=sample_index)
+        return host(out)
+    if gb.backward_needs_counts(B, L, dev(offsets)):
+        pytest.skip("global-bins layout: no sample lists")
+    full = run(g_full, None, B)
+    listed = run(g_list, dev(idx), len(idx))
+    ref, _ = orc.grid_encode_backward(g_full, x01, np.zeros((rows, 2), np.float32), offsets, B, 3, 2, L, L, S, H, None, 0, False, 0)
+    scale_ = np.abs(ref).max()
+    np.testing.assert_allclose(full, ref, rtol=1e-4, atol=2e-5 * scale_)
+    np.testing.assert_allclose(listed, full, rtol=1e-5, atol=1e-6 * scale_)

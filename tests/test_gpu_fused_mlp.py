@@ -273,3 +273,51 @@ def test_backward_saturates_instead_of_overflowing():
     denc, dws = run_backward(W, enc, M, dirs, dsigma, drgb, M)
     assert torch.isfinite(denc).all() and all(torch.isfinite(g).all() for g in dws)
     assert float(denc.abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,dead", [(1000, 0.35), (30000, 0.33), (4097, 0.0), (500, 1.0)])
+def test_backward_over_a_sample_list_equals_the_backward_over_all_samples(M, dead):
+    """ngp_x_mlp_backward_list: the backward over the list of samples whose output gradients can be non-zero (the fused step:
+    the samples in front of the compositor's early stop) against the backward over all samples with zeros at the others.
+    Per-sample results do not depend on which tile a sample sits in: d enc of the listed samples is the same BITS, in list
+    order; the weight gradients are the same sums in a different order."""
+    from raw_ngp_amd import _lib
+    mb = _lib.mlp_backend
+    W = make_weights(seed=3)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    stride = M + 9
+    enc = torch.randn(16, stride, 2, device="cuda", generator=g) * 0.5
+    dirs = torch.randn(M, 3, device="cuda", generator=g)
+    dsigma = torch.randn(M, device="cuda", generator=g) * 1e-3
+    drgb = torch.randn(M, 3, device="cuda", generator=g) * 1e-3
+    # "rays" of 7..60 samples whose tails are dead (zero output gradients)
+    live = torch.ones(M, dtype=torch.bool, device="cuda")
+    at = 0
+    rng = np.random.default_rng(M)
+    while at < M:
+        n = int(rng.integers(7, 60))
+        k = int(round(n * (1.0 - dead)))
+        live[at + k:at + n] = False
+        at += n
+    dsigma[~live] = 0.0
+    drgb[~live] = 0.0
+    idx = torch.nonzero(live).flatten().to(torch.int32)
+    n_live = int(idx.numel())
+    image = torch.empty(mb.image_bytes(), dtype=torch.uint8, device="cuda")
+    mb.prepare(W, image)
+
+    def run(sample_index, count):
+        denc = torch.full((16, stride, 2), 7.0, device="cuda")
+        dws = [torch.empty_like(w) for w in W]
+        mb.backward(enc, stride, dirs, dsigma, drgb, count, M, image, 1024.0, denc, dws, sample_index=sample_index)
+        return denc, dws
+    full, dw_full = run(None, None)
+    pad = torch.zeros(max(M, 1), dtype=torch.int32, device="cuda")
+    pad[:n_live] = idx
+    listed, dw_list = run(pad, torch.tensor([n_live], dtype=torch.int32, device="cuda"))
+    assert torch.all(full[:, :M][:, ~live] == 0.0)
+    assert torch.equal(listed[:, :n_live], full[:, idx.long()])            # bit for bit, in list order
+    assert torch.all(listed[:, n_live:] == 7.0)                             # nothing is written behind the list
+    for a, b in zip(dw_list, dw_full):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-12, (float((a - b).abs().max()), scale)
