@@ -320,4 +320,4 @@ def test_backward_over_a_sample_list_equals_the_backward_over_all_samples(M, dea
     assert torch.all(listed[:, n_live:] == 7.0)                             # nothing is written behind the list
     for a, b in zip(dw_list, dw_full):
         scale = float(b.abs().max())
-        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-12, (float((a - b).abs().max()), scale)
+        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-12, (float((a - b).abs().max()), scale)   # (measured: 3e-7)
