@@ -982,3 +982,43 @@ def test_table_backward_over_a_sample_list(lib, orc):
     scale_ = np.abs(ref).max()
     np.testing.assert_allclose(full, ref, rtol=1e-4, atol=2e-5 * scale_)
     np.testing.assert_allclose(listed, full, rtol=1e-5, atol=1e-6 * scale_)
+
+
+def test_step_over_the_live_sample_list_equals_the_step_over_all_samples(lib, monkeypatch):
+    """The fused step's backward over the list of samples in front of the compositor's early stop (default) against the
+    same step with the list switched off: identical samples and loss, the same gradient of the table and the MLP weights
+    up to summation order -- on a field trained far enough that rays do stop early."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=1024, iters=400, fused_mlp=True)
+    data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
+    warm = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
+    warm.train(300)
+    torch.cuda.synchronize()
+    state = {k: v.clone() for k, v in warm.model.state_dict().items()}
+    grid, bits, it = warm.model.density_grid.clone(), warm.model.density_bitfield.clone(), warm.model.iter_density
+    res = []
+    for live in ("1", "0"):
+        monkeypatch.setenv("NGP_LIVE_LIST", live)
+        torch.manual_seed(1)
+        # (a high threshold: after 300 steps on this small scene no ray reaches the default 1e-4 yet)
+        o2 = Options(bound=1.0, num_rays=1024, iters=400, fused_mlp=True, capture_graph=False, fuse_adam=False, T_thresh=0.2)
+        model = NeRFNetwork(o2).cuda()
+        model.load_state_dict(state)
+        model.density_grid.copy_(grid)
+        model.density_bitfield.copy_(bits)
+        model.iter_density = it
+        eng = FusedTrainer(o2, model, data, device="cuda", capacity=1024 * 256, seed=5)
+        eng.global_step = 1                                      # (not a refresh step)
+        eng.step_ctr.fill_(1)
+        eng.train_step()
+        torch.cuda.synchronize()
+        res.append((float(eng.loss), int(eng.slots[1].arena.counter[0]), int(eng.live_count[0]), eng.gflat.float().clone()))
+    (la, na, ca, ga), (lb, nb, cb, gb_) = res
+    assert na == nb and abs(la - lb) <= 1e-6 * abs(lb)           # the same batch, the same forward (loss: float atomics)
+    assert 0 < ca < 0.97 * na and cb == 0, (ca, na)              # rays do stop early; the second run made no list
+    assert float(ga.norm()) > 0
+    assert float((ga - gb_).norm()) <= 1e-5 * float(gb_.norm()), float((ga - gb_).norm() / gb_.norm())
