@@ -252,6 +252,15 @@ int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, con
                                      void *workspace, size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
                                      float *adam_exp_avg_sq, const float *adam_hyper, float beta1, float beta2,
                                      float eps, int overwrite, ngp_stream_t stream);
+/* ngp_x_grid_backward_binned_apply over a LIST of samples (see ngp_x_grid_backward_binned_apply_mlp_list) */
+int ngp_x_grid_backward_binned_apply_list(const float *grad, const float *inputs, const int32_t *sample_index,
+                                          const int32_t *offsets, float *grad_embeddings, const int32_t *B_dev, uint32_t B,
+                                          uint32_t grad_stride, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                          uint32_t gridtype, int align_corners, uint32_t interp, uint32_t n_rows_total,
+                                          uint32_t max_level_rows, void *workspace, size_t workspace_bytes,
+                                          float *adam_param, float *adam_exp_avg, float *adam_exp_avg_sq,
+                                          const float *adam_hyper, float beta1, float beta2, float eps, int overwrite,
+                                          ngp_stream_t stream);
 /* ngp_x_grid_backward_binned_apply with ngp_x_mlp_reduce_dw riding along (its arguments, mlp_ prefix, same meaning and
  * checks): the weight-gradient reduction of the fused MLP runs as extra workgroups of the fill kernel instead of as a
  * kernel of its own -- one launch and one dependent-launch gap fewer on the fused step's critical path.  Nothing in the
@@ -381,6 +390,12 @@ int ngp_x_mlp_rf_backward(const float *enc, uint32_t stride, const float *dirs, 
                           const float *dsigma, const float *drgb, const int32_t *M_dev, uint32_t M, const void *image,
                           float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2, float *dw3, float *dw4,
                           float *dw5, float *dw6, void *workspace, size_t workspace_bytes, ngp_stream_t stream);
+/* ... over a LIST of samples (as ngp_x_mlp_backward_list): inputs and ddirs by sample, denc in list order */
+int ngp_x_mlp_rf_backward_list(const float *enc, uint32_t stride, const float *dirs, const float *ldirs, const float *level_w,
+                               const float *dsigma, const float *drgb, const int32_t *M_dev, uint32_t M,
+                               const int32_t *sample_index, const void *image, float loss_scale, float *denc, float *ddirs,
+                               float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6, void *workspace,
+                               size_t workspace_bytes, ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Kernels of the fused training step (csrc/engine_kernels.hip; host side raw_ngp_amd/nerf/engine.py).
@@ -529,6 +544,14 @@ int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_rgb, float 
                                const float *sigmas, const float *rgbs, const float *ts, const int32_t *rays, uint32_t M,
                                uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,
                                float *grad_sigmas, float *grad_rgbs, float *loss_out, ngp_stream_t stream);
+/* ... that also lists the samples in front of the early stop (as ngp_x_composite_mse_train_idx); live_off [N] (optional):
+ * where each ray's entries start in the list.  live_n == NULL: no list. */
+int ngp_x_composite_train_live_idx(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
+                                   const float *weight, float inv_norm, const int32_t *n_live, float lambda_entropy,
+                                   const float *sigmas, const float *rgbs, const float *ts, const int32_t *rays, uint32_t M,
+                                   uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,
+                                   float *grad_sigmas, float *grad_rgbs, float *loss_out, int32_t *live_n,
+                                   int32_t *live_idx, int32_t *live_count, int32_t *live_off, ngp_stream_t stream);
 
 /* ---- pose refinement around the fused step (csrc/pose_kernels.hip) -----------------------------------------------
  * ngp_x_step_window   annealing = float16((step_counter[0] + step_offset) / iters) (train_utils.py:488) -> the BARF level
@@ -558,6 +581,12 @@ int ngp_x_slab_window(float *slab, uint32_t stride, uint32_t L, const float *lev
 int ngp_x_ray_gradients(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound, const float *ddirs,
                         const float *ts, const int32_t *rays, uint32_t N, uint32_t M, float *grad_rays_o,
                         float *grad_rays_d, ngp_stream_t stream);
+/* ... when the backward ran over the list of live samples: denc in list order -- ray n's entries start at live_off[n], the
+ * first live_n[n] samples of the ray have gradients (dydx, ts, ddirs stay in sample order) */
+int ngp_x_ray_gradients_list(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
+                             const float *ddirs, const float *ts, const int32_t *rays, const int32_t *live_n,
+                             const int32_t *live_off, uint32_t N, uint32_t M, float *grad_rays_o, float *grad_rays_d,
+                             ngp_stream_t stream);
 int ngp_x_pose_gradient(const int32_t *index, const float *grad_rays_o, const float *grad_rays_d, uint32_t N, uint32_t V,
                         uint32_t W, float fx, float fy, float cx, float cy, float *grad_pose, ngp_stream_t stream);
 int ngp_x_pose_update(float *xi, const float *base, const float *grad_pose, uint32_t V, const int32_t *flags,

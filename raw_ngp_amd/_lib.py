@@ -47,6 +47,8 @@ _SIGNATURES = {
                                            ctypes.c_size_t],
     "ngp_x_grid_backward_binned_apply": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
                                          ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i],
+    "ngp_x_grid_backward_binned_apply_list": [_p, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
+                                              ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i],
     "ngp_x_grid_backward_binned_apply_mlp": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
                                              ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i,
                                              _u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f,
@@ -67,6 +69,8 @@ _SIGNATURES = {
     "ngp_x_mlp_rf_forward": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_rf_backward": [_p, _u, _p, _p, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                               ctypes.c_size_t],
+    "ngp_x_mlp_rf_backward_list": [_p, _u, _p, _p, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                   ctypes.c_size_t],
     "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
     "ngp_x_grid_encode_forward_slab_jac": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p],
     "ngp_x_composite_hdr_train": [_p, _p, _f, _p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
@@ -75,10 +79,13 @@ _SIGNATURES = {
     "ngp_x_sample_rays_adaptive": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p,
                                    _p, _p, _p, _p, _p, _p, _u, _p, _p],
     "ngp_x_composite_train_live": [_p, _p, _f, _p, _p, _f, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
+    "ngp_x_composite_train_live_idx": [_p, _p, _f, _p, _p, _f, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p,
+                                       _p, _p, _p, _p],
     "ngp_x_step_window": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_step_window_baa": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_slab_window": [_p, _u, _u, _p, _p, _u, _i],
     "ngp_x_ray_gradients": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _u, _p, _p],
+    "ngp_x_ray_gradients_list": [_p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_pose_gradient": [_p, _p, _p, _u, _u, _u, _f, _f, _f, _f, _p],
     "ngp_x_pose_update": [_p, _p, _p, _u, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p],
     "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
@@ -364,8 +371,8 @@ class _GridBackend:
         overwrite: grad_embeddings = sums for every row (no +=); a bfloat16 grad_embeddings selects the 16-bit store.
         mlp_tail = (M, loss_scale, dws, workspace, adam, image), the arguments of mlp_backend.reduce_dw: that reduction
         rides along as extra workgroups of the fill kernel (ngp_x_grid_backward_binned_apply_mlp).
-        sample_index (int32, with mlp_tail): the call runs over a LIST of samples -- `inputs` by sample, `grad` in list order,
-        B_dev[0] entries (ngp_x_grid_backward_binned_apply_mlp_list)."""
+        sample_index (int32): the call runs over a LIST of samples -- `inputs` by sample, `grad` in list order,
+        B_dev[0] entries (ngp_x_grid_backward_binned_apply_mlp_list / ..._apply_list)."""
         n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
         wire16 = grad_embeddings is not None and grad_embeddings.dtype == torch.bfloat16
         if wire16 and not overwrite:
@@ -382,8 +389,10 @@ class _GridBackend:
                 workspace.data_ptr(), workspace.numel(), *extra, 2 if wire16 else int(bool(overwrite))]
         if mlp_tail is None:
             if sample_index is not None:
-                raise RuntimeError("grid_backward_binned_apply: a sample list comes with mlp_tail")
-            _call("ngp_x_grid_backward_binned_apply", grad, *args)
+                _call("ngp_x_grid_backward_binned_apply_list", grad, *args[:2], _ptr(sample_index, "i", "sample_index"), *args[2:],
+                      probe_as="ngp_x_grid_backward_binned_apply", probe_shift=1)
+            else:
+                _call("ngp_x_grid_backward_binned_apply", grad, *args)
             return
         M, loss_scale, dws, mlp_ws, mlp_adam, image = mlp_tail
         mextra = [None, None, None, None, 0, None, 0.0, 0.0, 0.0]
@@ -676,16 +685,22 @@ class _MlpRfBackend:
 
     @staticmethod
     def backward(enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, image, loss_scale, denc, ddirs, dws,
-                 workspace=None):
+                 workspace=None, sample_index=None):
+        """sample_index (int32, optional): run over a LIST of M_dev[0] samples -- inputs and ddirs by sample, denc in list order."""
         nbytes = load().ngp_x_mlp_rf_backward_workspace_bytes(M)
         ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
         if ws.numel() < nbytes or not ws.is_cuda:
             raise RuntimeError("mlp_rf backward: workspace too small")
-        _call("ngp_x_mlp_rf_backward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"),
-              _ptr(ldirs, "f", "ldirs"), _ptr(level_w, "f", "level_w", True), _ptr(dsigma, "f", "dsigma"),
-              _ptr(drgb, "f", "drgb"), _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), float(loss_scale),
-              _ptr(denc, "f", "denc"), _ptr(ddirs, "f", "ddirs", True),
-              *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], ws.data_ptr(), nbytes)
+        head = [_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"),
+                _ptr(ldirs, "f", "ldirs"), _ptr(level_w, "f", "level_w", True), _ptr(dsigma, "f", "dsigma"),
+                _ptr(drgb, "f", "drgb"), _ptr(M_dev, "i", "M_dev", True), M]
+        tail = [image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"), _ptr(ddirs, "f", "ddirs", True),
+                *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], ws.data_ptr(), nbytes]
+        if sample_index is not None:
+            _call("ngp_x_mlp_rf_backward_list", enc, *head, _ptr(sample_index, "i", "sample_index"), *tail,
+                  probe_as="ngp_x_mlp_rf_backward")
+        else:
+            _call("ngp_x_mlp_rf_backward", enc, *head, *tail)
 
 
 class _EngineBackend:
@@ -760,16 +775,24 @@ class _EngineBackend:
 
     @staticmethod
     def composite_train_live(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, n_live, sigmas, rgbs, ts, rays, M, N,
-                             T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out, lambda_entropy=0.0):
+                             T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out, lambda_entropy=0.0,
+                             live=None):
         """composite_mse_train (exposure None) / composite_hdr_train over the first n_live[0] ray slots (None: all), plus
-        lambda_entropy * mean entropy of the rays' accumulated opacity (train_utils.py:554-557)."""
-        _call("ngp_x_composite_train_live", rays, _ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
-              float(bg_const), _ptr(exposure, "f", "exposure", True), _ptr(weight, "f", "weight", True), float(inv_norm),
-              _ptr(n_live, "i", "n_live", True), float(lambda_entropy), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"),
-              _ptr(ts, "f", "ts"),
-              _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
-              _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
-              _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"))
+        lambda_entropy * mean entropy of the rays' accumulated opacity (train_utils.py:554-557).
+        live = (live_n [N], live_idx [M], live_count [1], live_off [N] or None) int32: also list the samples in front of the
+        early stop (and where each ray's entries start)."""
+        args = [_ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
+                float(bg_const), _ptr(exposure, "f", "exposure", True), _ptr(weight, "f", "weight", True), float(inv_norm),
+                _ptr(n_live, "i", "n_live", True), float(lambda_entropy), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"),
+                _ptr(ts, "f", "ts"),
+                _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
+                _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
+                _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out")]
+        if live is None:
+            _call("ngp_x_composite_train_live", rays, *args)
+        else:
+            _call("ngp_x_composite_train_live_idx", rays, *args, _ptr(live[0], "i", "live_n"), _ptr(live[1], "i", "live_idx"),
+                  _ptr(live[2], "i", "live_count"), _ptr(live[3], "i", "live_off", True))
 
     @staticmethod
     def step_window(step_counter, step_offset, iters, start_annealing, end_annealing, L, level_w, flags=None, baa=False):
@@ -786,7 +809,14 @@ class _EngineBackend:
               _ptr(M_dev, "i", "M_dev", True), int(M), 2 if scale_only else int(bool(backward)))
 
     @staticmethod
-    def ray_gradients(denc, dydx, stride, L, bound, ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d):
+    def ray_gradients(denc, dydx, stride, L, bound, ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d, live=None):
+        """live = (live_n, live_off): the backward ran over the list of live samples -- denc in list order."""
+        if live is not None:
+            _call("ngp_x_ray_gradients_list", rays, _ptr(denc, "f", "denc"), _ptr(dydx, "f", "dydx"), stride, L, float(bound),
+                  _ptr(ddirs, "f", "ddirs", True), _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), _ptr(live[0], "i", "live_n"),
+                  _ptr(live[1], "i", "live_off"), N, M, _ptr(grad_rays_o, "f", "grad_rays_o"),
+                  _ptr(grad_rays_d, "f", "grad_rays_d"), probe_as="ngp_x_ray_gradients")
+            return
         _call("ngp_x_ray_gradients", rays, _ptr(denc, "f", "denc"), _ptr(dydx, "f", "dydx"), stride, L, float(bound),
               _ptr(ddirs, "f", "ddirs", True), _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), N, M,
               _ptr(grad_rays_o, "f", "grad_rays_o"), _ptr(grad_rays_d, "f", "grad_rays_d"))

@@ -471,7 +471,8 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
 // its own -- N integers out of L2 -- instead of waiting for its predecessors: no scan kernel, no look-back, any order.
 __global__ __launch_bounds__(1024) void live_index_kernel(const int32_t *__restrict__ rays,
                                                          const int32_t *__restrict__ live_n, uint32_t N, uint32_t M_cap,
-                                                         int32_t *__restrict__ live_idx, int32_t *__restrict__ live_count)
+                                                         int32_t *__restrict__ live_idx, int32_t *__restrict__ live_count,
+                                                         int32_t *__restrict__ live_off)
 {
     __shared__ uint32_t s_part[16], s_mine[16];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, r0 = blockIdx.x * 16u, n = r0 + w;
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(1024) void live_index_kernel(const int32_t *__restr
     if (n < N) {
         const uint32_t off = (uint32_t)rays[(size_t)n * 2];
         for (uint32_t k = lane; k < mine && at + k < M_cap; k += 64u) live_idx[at + k] = (int32_t)(off + k);
+        if (live_off && lane == 0) live_off[n] = (int32_t)at;   // where ray n's entries start (per-ray consumers)
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) live_count[0] = (int32_t)min(total, M_cap);
 }
@@ -858,7 +860,8 @@ extern "C" int ngp_x_composite_mse_train_idx(const float *gt_rgba, const float *
     composite_backward_wave_kernel<2><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
         nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, nullptr, nullptr, nullptr, M,
         N, T_thresh, grad_sigmas, grad_rgbs, loss_out, weights_sum, depth, image, hdr);
-    live_index_kernel<<<dim3(ceil_div(N, 16u)), dim3(1024), 0, as_stream(stream)>>>(rays, live_n, N, M, live_idx, live_count);
+    live_index_kernel<<<dim3(ceil_div(N, 16u)), dim3(1024), 0, as_stream(stream)>>>(rays, live_n, N, M, live_idx, live_count,
+                                                                                    nullptr);
     NGP_CHECK_LAUNCH("composite_mse_train_idx");
     return NGP_OK;
 }
@@ -881,6 +884,21 @@ extern "C" int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_
                                           float *image, float *grad_sigmas, float *grad_rgbs, float *loss_out,
                                           ngp_stream_t stream)
 {
+    return ngp_x_composite_train_live_idx(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, n_live, lambda_entropy, sigmas,
+                                          rgbs, ts, rays, M, N, T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs,
+                                          loss_out, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// ... that also lists the samples in front of the early stop (as ngp_x_composite_mse_train_idx; live_off [N]: where each
+// ray's entries start in the list, for per-ray consumers such as ngp_x_ray_gradients_list).  live_n NULL: no list.
+extern "C" int ngp_x_composite_train_live_idx(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
+                                              const float *weight, float inv_norm, const int32_t *n_live,
+                                              float lambda_entropy, const float *sigmas, const float *rgbs, const float *ts,
+                                              const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                              float *weights_sum, float *depth, float *image, float *grad_sigmas,
+                                              float *grad_rgbs, float *loss_out, int32_t *live_n, int32_t *live_idx,
+                                              int32_t *live_count, int32_t *live_off, ngp_stream_t stream)
+{
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(gt_rgba && rays && weights_sum && depth && image && loss_out, "composite_train_live: null tensor");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && grad_sigmas && grad_rgbs), "composite_train_live: null sample tensor");
@@ -894,9 +912,16 @@ extern "C" int ngp_x_composite_train_live(const float *gt_rgba, const float *bg_
     hdr.n_live = n_live;
     NGP_REQUIRE(lambda_entropy >= 0.0f, "composite_train_live: lambda_entropy must not be negative");
     hdr.lambda_entropy = lambda_entropy;
+    const bool listing = live_n != nullptr;
+    NGP_REQUIRE(listing ? (live_idx && live_count && M > 0) : (!live_idx && !live_count && !live_off),
+                "composite_train_live: live_n, live_idx and live_count go together");
+    hdr.live_out = live_n;
     composite_backward_wave_kernel<2><<<dim3(ceil_div(N, kCompBwdBlock / 64)), dim3(kCompBwdBlock), 0, as_stream(stream)>>>(
         nullptr, nullptr, nullptr, nullptr, gt_rgba, bg_rgb, bg_const, sigmas, rgbs, ts, rays, nullptr, nullptr, nullptr, M,
         N, T_thresh, grad_sigmas, grad_rgbs, loss_out, weights_sum, depth, image, hdr);
+    if (listing)
+        live_index_kernel<<<dim3(ceil_div(N, 16u)), dim3(1024), 0, as_stream(stream)>>>(rays, live_n, N, M, live_idx, live_count,
+                                                                                        live_off);
     NGP_CHECK_LAUNCH("composite_train_live");
     return NGP_OK;
 }

@@ -698,17 +698,17 @@ static bool mlp_backward_lds_ok()
 
 int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
                              const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
-                             float *partial, uint32_t blocks, hipStream_t st)
+                             float *partial, uint32_t blocks, hipStream_t st, const int32_t *sample_index)
 {
     NGP_REQUIRE(mlp_backward_lds_ok(), "mlp_backward_grid: cannot raise the dynamic LDS limit");
     if (level_w)
         mlp_backward_grid_kernel<true><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
                                                                                   d3buf, denc, partial, level_w, t3_base,
-                                                                                  nullptr);
+                                                                                  sample_index);
     else
         mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
                                                                                    d3buf, denc, partial, nullptr, t3_base,
-                                                                                   nullptr);
+                                                                                   sample_index);
     NGP_CHECK_LAUNCH("mlp_backward_grid");
     return NGP_OK;
 }

@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
     const float *__restrict__ enc, uint32_t stride, const float *__restrict__ dirs, const float *__restrict__ ldirs,
     const float *__restrict__ level_w, const float *__restrict__ dsigma, const float *__restrict__ drgb,
     const int32_t *__restrict__ M_dev, uint32_t M_host, const half8 *__restrict__ image, float loss_scale,
-    half8 *__restrict__ d3buf, half8 *__restrict__ scratch, float *__restrict__ ddirs, float *__restrict__ partial)
+    half8 *__restrict__ d3buf, half8 *__restrict__ scratch, float *__restrict__ ddirs, float *__restrict__ partial,
+    const int32_t *__restrict__ live_idx)
 {
     extern __shared__ half8 lds_w[];   // fragments 0..67 (68 KiB); reused as the f32 reduction image at the end
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
@@ -296,8 +297,11 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         asm volatile("" ::: "memory");
-        const uint32_t row = tile * 32u + n;
-        const bool valid = row < M;
+        // live_idx: the kernels run over a LIST of M samples (fused_mlp_backward.hip: the view kernel); inputs and d dirs by
+        // sample (`row`), delta3 and the operands of the second view kernel in list order (`c_idx`)
+        const uint32_t c_idx = tile * 32u + n;
+        const bool valid = c_idx < M;
+        const uint32_t row = (live_idx && valid) ? (uint32_t)live_idx[c_idx] : c_idx;
         float gs = 0.f, gr0 = 0.f, gr1 = 0.f, gr2 = 0.f;
         if (valid) {
             gs = dsigma[row];
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
                 half8 z;
 #pragma unroll
                 for (int t = 0; t < 8; t++) z[t] = (_Float16)0.0f;
-                d3buf[(size_t)row * 2 + h] = z;
+                d3buf[(size_t)c_idx * 2 + h] = z;
                 if (ddirs && h == 0) ddirs[(size_t)row * 3] = ddirs[(size_t)row * 3 + 1] = ddirs[(size_t)row * 3 + 2] = 0.0f;
             }
             continue;
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
         for (int kk = 0; kk < 5; kk++) dx3 = mfma(RF_FRAG(RF_T4 + kk), p4[kk], dx3);
         // delta3 row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp backward)
         if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
-        if (valid) d3buf[(size_t)row * 2 + h] = pack_sat<0>(dx3);
+        if (valid) d3buf[(size_t)c_idx * 2 + h] = pack_sat<0>(dx3);
 
         if (ddirs) {   // d loss / d (un-normalised view direction)
             float dx = 0.f, dy = 0.f, dz = 1.f;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
             }
         }
         if (valid) {   // operands of the second view kernel
-            const size_t at = (size_t)row * 2 + h;
+            const size_t at = (size_t)c_idx * 2 + h;
 #pragma unroll
             for (int kk = 0; kk < 5; kk++) {
                 scratch[(size_t)kk * plane + at] = p4[kk];
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v2_kernel(
     const float *__restrict__ enc, uint32_t stride, const float *__restrict__ dirs, const float *__restrict__ ldirs,
     const float *__restrict__ level_w, const float *__restrict__ dsigma, const float *__restrict__ drgb,
     const int32_t *__restrict__ M_dev, uint32_t M_host, const half8 *__restrict__ image,
-    const half8 *__restrict__ scratch, float *__restrict__ partial)
+    const half8 *__restrict__ scratch, float *__restrict__ partial, const int32_t *__restrict__ live_idx)
 {
     extern __shared__ half8 lds_w[];   // fragments 0..15 (density MLP forward); sized for the 36 KiB reduction image
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
@@ -453,8 +457,9 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v2_kernel(
 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         asm volatile("" ::: "memory");
-        const uint32_t row = tile * 32u + n;
-        const bool valid = row < M;
+        const uint32_t c_idx = tile * 32u + n;   // (list order; `row`: the sample -- see v1)
+        const bool valid = c_idx < M;
+        const uint32_t row = (live_idx && valid) ? (uint32_t)live_idx[c_idx] : c_idx;
         float gs = 0.f, gr0 = 0.f, gr1 = 0.f, gr2 = 0.f;
         if (valid) {
             gs = dsigma[row];
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v2_kernel(
             half8 z;
 #pragma unroll
             for (int t = 0; t < 8; t++) z[t] = (_Float16)0.0f;
-            const size_t at = (size_t)row * 2 + h;
+            const size_t at = (size_t)c_idx * 2 + h;
 #pragma unroll
             for (int kk = 0; kk < 5; kk++) {
                 p4[kk] = valid ? scratch[(size_t)kk * plane + at] : z;
@@ -627,6 +632,18 @@ extern "C" int ngp_x_mlp_rf_backward(const float *enc, uint32_t stride, const fl
                                      float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6,
                                      void *workspace, size_t workspace_bytes, ngp_stream_t stream)
 {
+    return ngp_x_mlp_rf_backward_list(enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, nullptr, image, loss_scale, denc,
+                                      ddirs, dw1, dw2, dw3, dw4, dw5, dw6, workspace, workspace_bytes, stream);
+}
+
+// ... over a LIST of samples (as ngp_x_mlp_backward_list): inputs and ddirs by sample, denc in list order
+extern "C" int ngp_x_mlp_rf_backward_list(const float *enc, uint32_t stride, const float *dirs, const float *ldirs,
+                                          const float *level_w, const float *dsigma, const float *drgb,
+                                          const int32_t *M_dev, uint32_t M, const int32_t *sample_index, const void *image,
+                                          float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2, float *dw3,
+                                          float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
+                                          ngp_stream_t stream)
+{
     NGP_REQUIRE(image && workspace && dw1 && dw2 && dw3 && dw4 && dw5 && dw6, "mlp_rf_backward: null tensor");
     NGP_REQUIRE(M == 0 || (enc && dirs && ldirs && dsigma && drgb && denc), "mlp_rf_backward: null sample tensor");
     NGP_REQUIRE(stride >= M, "mlp_rf_backward: encoder slab stride smaller than M");
@@ -652,11 +669,11 @@ extern "C" int ngp_x_mlp_rf_backward(const float *enc, uint32_t stride, const fl
     float *part_g = part_v2 + (size_t)256 * kRfTilesV * 1024;
     const half8 *img = reinterpret_cast<const half8 *>(image);
     mlp_rf_backward_v1_kernel<<<dim3(blocks), dim3(256), kV1Lds, st>>>(
-        enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, loss_scale, d3buf, scratch, ddirs, part_v1);
+        enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, loss_scale, d3buf, scratch, ddirs, part_v1, sample_index);
     mlp_rf_backward_v2_kernel<<<dim3(blocks), dim3(256), kV2Lds, st>>>(
-        enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, scratch, part_v2);
+        enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, scratch, part_v2, sample_index);
     const int rc = launch_mlp_backward_grid(enc, stride, level_w, M_dev, M, img, RF_T3, 1.0f / loss_scale, d3buf, denc,
-                                            part_g, blocks, st);
+                                            part_g, blocks, st, sample_index);
     if (rc != NGP_OK) return rc;
     mlp_rf_reduce_dw_kernel<<<dim3((2 * kRfTilesV + kRfTilesG) * 1024u / 64u), dim3(256), 0, st>>>(
         part_v1, part_v2, part_g, blocks, 1.0f / loss_scale, RfGrads{dw1, dw2, dw3, dw4, dw5, dw6});

@@ -1105,6 +1105,22 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
                         stream);
 }
 
+// ngp_x_grid_backward_binned_apply over a LIST of samples (see ngp_x_grid_backward_binned_apply_mlp_list)
+extern "C" int ngp_x_grid_backward_binned_apply_list(const float *grad, const float *inputs, const int32_t *sample_index,
+                                                     const int32_t *offsets, float *grad_embeddings, const int32_t *B_dev,
+                                                     uint32_t B, uint32_t grad_stride, uint32_t L, uint32_t max_level, float S,
+                                                     uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                     uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
+                                                     size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
+                                                     float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
+                                                     float beta2, float eps, int overwrite, ngp_stream_t stream)
+{
+    return binned_apply("grid_backward_binned_apply", nullptr, sample_index, grad, inputs, offsets, grad_embeddings, B_dev, B,
+                        grad_stride, L, max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
+                        workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
+                        stream);
+}
+
 // the same launch sequence with ngp_x_mlp_reduce_dw (same arguments, mlp_ prefix) riding along as extra workgroups of the
 // fill kernel: one kernel and one dependent-launch gap fewer on the fused step's critical path
 extern "C" int ngp_x_grid_backward_binned_apply_mlp(

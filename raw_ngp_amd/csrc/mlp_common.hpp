@@ -214,7 +214,7 @@ constexpr size_t flush_lds_bytes(int NT) { return (size_t)4 * ((NT + 1) / 2) * 4
 // NULL (no window); t3_base = first of the 14 transposed fragments (T_W3, T_W2, T_W1) in `image`
 int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
                              const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
-                             float *partial, uint32_t blocks, hipStream_t st);
+                             float *partial, uint32_t blocks, hipStream_t st, const int32_t *sample_index = nullptr);
 
 
 // ---- weight-gradient reduction over the backward kernels' partial slabs ----------------------------------------------

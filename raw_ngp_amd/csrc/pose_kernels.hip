@@ -114,18 +114,25 @@ __global__ __launch_bounds__(256) void ray_gradients_kernel(const float *__restr
                                                             uint32_t stride, uint32_t L, float inv_2bound,
                                                             const float *__restrict__ ddirs, const float *__restrict__ ts,
                                                             const int32_t *__restrict__ rays, uint32_t N, uint32_t M,
-                                                            float *__restrict__ grad_rays_o, float *__restrict__ grad_rays_d)
+                                                            float *__restrict__ grad_rays_o, float *__restrict__ grad_rays_d,
+                                                            const int32_t *__restrict__ live_n,
+                                                            const int32_t *__restrict__ live_off)
 {
     const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (n >= N) return;
     const uint32_t off = (uint32_t)rays[(size_t)n * 2], cnt = (uint32_t)rays[(size_t)n * 2 + 1];
+    // live_n / live_off: the backward ran over the LIST of samples in front of the compositor's early stop (engine_kernels.hip:
+    // live_index_kernel) -- d enc is in list order (this ray's entries start at live_off[n]), only the ray's first live_n[n]
+    // samples have gradients at all (d dirs of the others was not written)
+    const uint32_t take = live_n ? min((uint32_t)live_n[n], cnt) : cnt;
+    const size_t at = live_off ? (size_t)(uint32_t)live_off[n] : (size_t)off;
     float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0};
     if (off + cnt <= M) {
-        for (uint32_t k = lane; k < cnt; k += kWave) {
-            const size_t i = (size_t)off + k;
+        for (uint32_t k = lane; k < take; k += kWave) {
+            const size_t i = (size_t)off + k, ic = at + k;
             float g[3] = {0, 0, 0};
             for (uint32_t l = 0; l < L; l++) {
-                const float2 ge = reinterpret_cast<const float2 *>(denc)[(size_t)l * stride + i];
+                const float2 ge = reinterpret_cast<const float2 *>(denc)[(size_t)l * stride + ic];
                 const float2 *j = reinterpret_cast<const float2 *>(dydx) + ((size_t)l * stride + i) * 3;
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
@@ -430,8 +437,24 @@ extern "C" int ngp_x_ray_gradients(const float *denc, const float *dydx, uint32_
     NGP_REQUIRE(M == 0 || (denc && dydx && ts), "ray_gradients: null sample tensor");
     NGP_REQUIRE(stride >= M && bound > 0.0f && L >= 1, "ray_gradients: bad stride / bound / L");
     ray_gradients_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
-        denc, dydx, stride, L, 1.0f / (2.0f * bound), ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d);
+        denc, dydx, stride, L, 1.0f / (2.0f * bound), ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d, nullptr, nullptr);
     NGP_CHECK_LAUNCH("ray_gradients");
+    return NGP_OK;
+}
+
+// ... when the backward ran over the list of live samples: denc in list order, ray n's entries at live_off[n], live_n[n] of them
+extern "C" int ngp_x_ray_gradients_list(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
+                                        const float *ddirs, const float *ts, const int32_t *rays, const int32_t *live_n,
+                                        const int32_t *live_off, uint32_t N, uint32_t M, float *grad_rays_o,
+                                        float *grad_rays_d, ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays && grad_rays_o && grad_rays_d && live_n && live_off, "ray_gradients_list: null tensor");
+    NGP_REQUIRE(M == 0 || (denc && dydx && ts), "ray_gradients_list: null sample tensor");
+    NGP_REQUIRE(stride >= M && bound > 0.0f && L >= 1, "ray_gradients_list: bad stride / bound / L");
+    ray_gradients_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
+        denc, dydx, stride, L, 1.0f / (2.0f * bound), ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d, live_n, live_off);
+    NGP_CHECK_LAUNCH("ray_gradients_list");
     return NGP_OK;
 }
 

@@ -51,10 +51,6 @@ class _Slot:
         self.head_step = -1                # ... or whose rays are drawn and half marched (in front of a grid refresh)
 
 
-def dev_is_cuda(device):
-    return torch.device(device).type == "cuda"
-
-
 class FusedTrainer:
     """Drop-in for Trainer.train_step / train on models that satisfy NeRFNetwork._fused()."""
 
@@ -290,6 +286,8 @@ class FusedTrainer:
         self.live_n = torch.zeros(N, dtype=torch.int32, device=dev)
         self.live_idx = torch.zeros(cap, dtype=torch.int32, device=dev)
         self.live_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.live_off = torch.zeros(N, dtype=torch.int32, device=dev)    # where each ray's entries start (ray gradients)
+        self.live_list = dev.type == "cuda" and os.environ.get("NGP_LIVE_LIST", "1") != "0"   # (and tile-local records: below)
         self.weights_buf = torch.empty(cap, **f32)
         self.ws, self.depth, self.image = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, 3, **f32)
         self.loss = torch.zeros(1, **f32)
@@ -393,7 +391,7 @@ class FusedTrainer:
                 eb.composite_train_live(gt_rgba, bg_rgb, bg_const, slot.exposure if self.hdr else None, None, 1.0 / (3 * N),
                                         slot.live if self.adaptive else None, self.sigma, self.rgb, ar.ts, ar.rays, cap, N,
                                         opt.T_thresh, self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
-                                        lambda_entropy=lam)
+                                        lambda_entropy=lam, live=live)
                 if self.adaptive:
                     self.rays_seen.add_(slot.live)
                 return
@@ -401,35 +399,43 @@ class FusedTrainer:
                 weight = None
                 if opt.loss_weight == "planck":     # raw_utils.planck_taper_weighting(gt_rgb): pointwise in the target
                     weight = self._planck_weight(gt_rgba, bg_rgb, bg_const)
+                if live is not None:    # (ngp_x_composite_hdr_train is this call without the list)
+                    eb.composite_train_live(gt_rgba, bg_rgb, bg_const, slot.exposure, weight, 1.0 / (3 * N), None, self.sigma,
+                                            self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.ws, self.depth, self.image,
+                                            self.dsigma, self.drgb, self.loss, live=live)
+                    return
                 eb.composite_hdr_train(gt_rgba, bg_rgb, bg_const, slot.exposure, weight, 1.0 / (3 * N), self.sigma, self.rgb,
                                        ar.ts, ar.rays, cap, N, opt.T_thresh, self.ws, self.depth, self.image, self.dsigma,
                                        self.drgb, self.loss)
                 return
+            if live is not None and live[3] is not None:    # (per-ray list offsets: the general entry writes them)
+                eb.composite_train_live(gt_rgba, bg_rgb, bg_const, None, None, 1.0 / (3 * N), None, self.sigma, self.rgb, ar.ts,
+                                        ar.rays, cap, N, opt.T_thresh, self.ws, self.depth, self.image, self.dsigma, self.drgb,
+                                        self.loss, live=live)
+                return
             eb.composite_mse_train(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh,
                                    self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
-                                   live=(self.live_n, self.live_idx, self.live_count) if live_list else None)
+                                   live=live[:3] if live is not None else None)
 
-        # the backward over the list of samples that can have a gradient (see __init__): the step path of the plain field
-        # with the MSE loss, when the weight-gradient reduction rides on the fill launch and the records are tile-local
-        lam_ = float(getattr(opt, "lambda_entropy", 0.0))
-        live_list = bool(fuse_composite and mlp_tail is not None and not (self.rfield or self.pose or self.hdr or self.adaptive)
-                         and lam_ == 0.0 and not self.binned_counts and dev_is_cuda(self.device)
-                         and os.environ.get("NGP_LIVE_LIST", "1") != "0")
+        # the backward over the list of samples that can have a gradient (see __init__): the step path (one-launch compositor
+        # step) with tile-local records
+        live_list = self._lists_live_samples(fuse_composite)
+        live = (self.live_n, self.live_idx, self.live_count, self.live_off if self.pose else None) if live_list else None
         back_n, back_idx = (self.live_count, self.live_idx) if live_list else (cnt, None)
 
         def mlp_backward():
             if self.rfield:         # one call: both view kernels, the density kernel, the weight-gradient reduction
                 self.mb.backward(self.enc, cap, ar.dirs, ar.ldirs, None if self.baa else self.level_w, self.dsigma, self.drgb,
-                                 cnt, cap, self.mlp_image, opt.loss_scale, self.denc, self.ddirs if self.pose else None,
-                                 self.dws, self.ws_mlp)
+                                 back_n, cap, self.mlp_image, opt.loss_scale, self.denc, self.ddirs if self.pose else None,
+                                 self.dws, self.ws_mlp, sample_index=back_idx)
                 if self.baa:        # the blend's adjoint: d enc' -> d enc (what the table backward and the ray gradients read)
-                    eb.slab_window(self.denc, cap, self.L, self.level_w, cnt, cap, backward=True)
+                    eb.slab_window(self.denc, cap, self.L, self.level_w, back_n, cap, backward=True)
             else:
                 self.mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, back_n, cap, self.mlp_image, opt.loss_scale,
                                  self.denc, None if split_weights else self.dws, self.ws_mlp,
                                  ddirs=self.ddirs if self.pose else None, sample_index=back_idx)
                 if self.pose:       # the window's adjoint: d enc' -> d enc
-                    eb.slab_window(self.denc, cap, self.L, self.level_w, cnt, cap, backward=True, scale_only=not self.baa)
+                    eb.slab_window(self.denc, cap, self.L, self.level_w, back_n, cap, backward=True, scale_only=not self.baa)
 
         ops = [
             ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
@@ -458,6 +464,10 @@ class FusedTrainer:
             ops = [("ngp_x_composite_mse_train", composite_train) if o[0] == "ngp_x_composite_mse_backward" else o
                    for o in ops]
         return ops
+
+    def _lists_live_samples(self, fuse_composite=True):
+        """Does the step's backward run over the list of samples in front of the compositor's early stop?"""
+        return bool(self.live_list and fuse_composite and not self.binned_counts)
 
     def _planck_weight(self, gt_rgba, bg_rgb, bg_const):
         """raw_utils.planck_taper_weighting of the target colour (raw/raw_utils.py:46-53: peak 0.5, taper 0.95, max 2)."""
@@ -717,9 +727,10 @@ class FusedTrainer:
         if self.pose:
             ar, d = slot.arena, self.data
             pose_tail = [
-                ("ngp_x_ray_gradients", lambda: eb.ray_gradients(self.denc, self.dydx, self.cap, self.L, self.model.bound,
-                                                                 self.ddirs, ar.ts, ar.rays, self.N, self.cap,
-                                                                 self.g_rays_o, self.g_rays_d)),
+                ("ngp_x_ray_gradients", lambda: eb.ray_gradients(
+                    self.denc, self.dydx, self.cap, self.L, self.model.bound, self.ddirs, ar.ts, ar.rays, self.N, self.cap,
+                    self.g_rays_o, self.g_rays_d,
+                    live=(self.live_n, self.live_off) if self._lists_live_samples() else None)),
                 ("ngp_x_pose_gradient", lambda: eb.pose_gradient(slot.index, self.g_rays_o, self.g_rays_d, self.N, len(d),
                                                                  d.W, d.intrinsics, self.grad_pose)),
                 ("ngp_x_pose_update", lambda: eb.pose_update(self.xi, self.pose_base, self.grad_pose, self.flags, self.pose_m,
