@@ -89,8 +89,12 @@ __device__ __forceinline__ TileIn load_tile(const float *__restrict__ enc, size_
 // PASSENGER: workgroup 0 does the step's one-workgroup bookkeeping (binned_common.hpp: step_begin_block) instead of
 // evaluating the field -- as a kernel of its own it sat on the step's critical path with a dependent-launch gap on top,
 // although nothing consumes its results before the compositor
+#ifndef NGP_FWD_WG_PER_CU
+#define NGP_FWD_WG_PER_CU 3
+#endif
+constexpr uint32_t kFwdWgPerCu = NGP_FWD_WG_PER_CU;   // workgroups (4 waves) per CU the kernel is compiled and launched for
 template <bool PASSENGER>
-__global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const float *__restrict__ enc, uint32_t stride,
+__global__ __launch_bounds__(256, kFwdWgPerCu) void mlp_forward_kernel(const float *__restrict__ enc, uint32_t stride,
                                                             const float *__restrict__ dirs,
                                                             const int32_t *__restrict__ M_dev, uint32_t M_host,
                                                             const half8 *__restrict__ image,
@@ -219,7 +223,7 @@ extern "C" int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float 
     NGP_REQUIRE(rgb == nullptr || dirs != nullptr, "mlp_forward: dirs missing");
     NGP_REQUIRE(stride >= M, "mlp_forward: encoder slab stride smaller than M");
     const uint32_t tiles = ceil_div(M, 32u);
-    const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * 2u);
+    const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * kFwdWgPerCu);
     mlp_forward_kernel<false><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(
         enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, StepBegin{});
     NGP_CHECK_LAUNCH("mlp_forward");
@@ -243,7 +247,7 @@ extern "C" int ngp_x_mlp_forward_step_begin(const float *enc, uint32_t stride, c
                                    samples_seen, sample_counter, binned_workspace, L, n_rows_total, single_segment);
     if (rc != NGP_OK) return rc;
     const uint32_t tiles = ceil_div(M, 32u);
-    const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * 2u);
+    const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * kFwdWgPerCu);
     mlp_forward_kernel<true><<<dim3(blocks + 1), dim3(256), 0, as_stream(stream)>>>(
         enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, a);
     NGP_CHECK_LAUNCH("mlp_forward_step_begin");
