@@ -417,6 +417,16 @@ int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound, const flo
                                        uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
                                        int align_corners, uint32_t interp, void *binned_workspace, uint32_t n_rows_total,
                                        float *dydx, ngp_stream_t stream);
+/* the same with the caller's level -> XCD placement: level_cost (HOST pointer, max_level floats > 0, or NULL) is the
+ * relative cost of one 256-point tile of each level for the caller's points (ray-ordered samples: growing with the
+ * level; scattered points: flat over the hashed levels).  The levels are dealt to the 8 XCDs in runs of equal cost
+ * instead of the fixed pairing (level k with 15 - k) the other two entries use.  Placement only; results identical. */
+int ngp_x_grid_encode_forward_slab_placed(const float *xyzs, float bound, const float *embeddings, const int32_t *offsets,
+                                          float *out, float *inputs01, const int32_t *B_dev, uint32_t B_cap,
+                                          uint32_t stride, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                          uint32_t gridtype, int align_corners, uint32_t interp, void *binned_workspace,
+                                          uint32_t n_rows_total, float *dydx, const float *level_cost,
+                                          ngp_stream_t stream);
 /* binned_workspace != NULL: a workspace of ngp_x_grid_backward_binned_prepare(stage 1) for the same samples; the
  * kernel also counts the records per 4096-row chunk (n_rows_total = rows of the whole table). */
 

@@ -73,6 +73,7 @@ _SIGNATURES = {
                                    ctypes.c_size_t],
     "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
     "ngp_x_grid_encode_forward_slab_jac": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p],
+    "ngp_x_grid_encode_forward_slab_placed": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p, _p],
     "ngp_x_composite_hdr_train": [_p, _p, _f, _p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
     "ngp_x_sample_rays_lit": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p,
                               _p, _p],
@@ -708,14 +709,25 @@ class _EngineBackend:
 
     @staticmethod
     def grid_encode_forward_slab(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L, max_level, S,
-                                 H, gridtype=0, align_corners=False, interp=0, binned_workspace=None, dydx=None):
-        """dydx: optional [L, stride, 3, 2] slab receiving d out / d x01 (pose refinement: ray_gradients)."""
+                                 H, gridtype=0, align_corners=False, interp=0, binned_workspace=None, dydx=None,
+                                 level_cost=None):
+        """dydx: optional [L, stride, 3, 2] slab receiving d out / d x01 (pose refinement: ray_gradients).
+        level_cost: optional sequence of max_level positive floats, the relative cost of a tile of each level for these
+        points -- the level -> XCD placement is balanced on it (placement only)."""
         args = (_ptr(xyzs, "f", "xyzs"), float(bound),
                 _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"), _ptr(out, "f", "out"),
                 _ptr(inputs01, "f", "inputs01", True), _ptr(B_dev, "i", "B_dev", True), B_cap, stride, L, max_level,
                 float(S), H, gridtype, int(bool(align_corners)), interp,
                 binned_workspace.data_ptr() if binned_workspace is not None else None, embeddings.shape[0])
-        if dydx is None:
+        if level_cost is not None:
+            if len(level_cost) != max_level:
+                raise RuntimeError("grid_encode_forward_slab: level_cost must hold max_level floats")
+            if dydx is not None and dydx.numel() < L * stride * 6:
+                raise RuntimeError("grid_encode_forward_slab: dydx must hold L * stride * 3 * 2 floats")
+            cost = (ctypes.c_float * max_level)(*[float(c) for c in level_cost])
+            _call("ngp_x_grid_encode_forward_slab_placed", xyzs, *args, _ptr(dydx, "f", "dydx", True), cost,
+                  probe_as="ngp_x_grid_encode_forward_slab_jac" if dydx is not None else "ngp_x_grid_encode_forward_slab")
+        elif dydx is None:
             _call("ngp_x_grid_encode_forward_slab", xyzs, *args)
         else:
             if dydx.numel() < L * stride * 6:

@@ -29,11 +29,14 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     const float *__restrict__ xyzs, float bound, const float *__restrict__ table, const int32_t *__restrict__ offsets,
     float *__restrict__ out, float *__restrict__ inputs01, const int32_t *__restrict__ B_dev, uint32_t B_cap,
     uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w,
-    float *__restrict__ dydx = nullptr, uint32_t snake_levels = 0)
+    float *__restrict__ dydx = nullptr, uint32_t snake_levels = 0, uint32_t placed_levels = 0, LevelPlacement place = {})
 {
     extern __shared__ uint32_t hist[];
     uint32_t level, tile_;
-    if (snake_levels) {
+    if (placed_levels) {
+        placed_level_tile(place, blockIdx.x, nchunks, placed_levels, level, tile_);
+        if (level == kNoLevel) return;
+    } else if (snake_levels) {
         snake_level_tile(blockIdx.x, nchunks, snake_levels, level, tile_);
         if (level == kNoLevel) return;
     } else {
@@ -736,6 +739,19 @@ extern "C" int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound
                                                   int align_corners, uint32_t interp, void *binned_workspace,
                                                   uint32_t n_rows_total, float *dydx, ngp_stream_t stream)
 {
+    return ngp_x_grid_encode_forward_slab_placed(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L,
+                                                 max_level, S, H, gridtype, align_corners, interp, binned_workspace,
+                                                 n_rows_total, dydx, nullptr, stream);
+}
+
+extern "C" int ngp_x_grid_encode_forward_slab_placed(const float *xyzs, float bound, const float *embeddings,
+                                                     const int32_t *offsets, float *out, float *inputs01,
+                                                     const int32_t *B_dev, uint32_t B_cap, uint32_t stride, uint32_t L,
+                                                     uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                                     int align_corners, uint32_t interp, void *binned_workspace,
+                                                     uint32_t n_rows_total, float *dydx, const float *level_cost,
+                                                     ngp_stream_t stream)
+{
     if (B_cap == 0 || max_level == 0) return NGP_OK;
     NGP_REQUIRE(xyzs && embeddings && offsets && out, "grid_encode_forward_slab: null tensor");
     NGP_REQUIRE(stride >= B_cap, "grid_encode_forward_slab: stride smaller than B_cap");
@@ -749,7 +765,30 @@ extern "C" int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound
     // kernel ends) -- 61 -> 46 us in the step; NGP_SNAKE=0 restores the contiguous split (fewer than 8 levels always take it)
     static const bool snake_on = !(getenv("NGP_SNAKE") && getenv("NGP_SNAKE")[0] == '0');
     const uint32_t snake_levels = (snake_on && max_level >= 8) ? max_level : 0u;
-    const dim3 grid(snake_levels ? snake_blocks(max_level, nchunks) : nchunks * max_level);
+    dim3 grid(snake_levels ? snake_blocks(max_level, nchunks) : nchunks * max_level);
+    // level_cost (host, max_level floats > 0): the caller's measured cost of one tile of each level for ITS points -- the
+    // levels are then dealt to the XCDs in runs of equal cost (ngp_common.hpp: place_levels) instead of by the snake
+    LevelPlacement place = {};
+    uint32_t placed_levels = 0;
+    if (level_cost && max_level >= 8 && max_level <= kPlacedLevels) {
+        for (uint32_t l = 0; l < max_level; l++)
+            NGP_REQUIRE(level_cost[l] > 0.0f && level_cost[l] < 1e30f, "grid_encode_forward_slab: level_cost[%u] must be positive", l);
+        placed_levels = max_level;
+        grid = dim3(place_levels(place, level_cost, max_level, nchunks));
+        if (const char *only = getenv("NGP_PLACE_ONLY_LEVEL")) {   // diagnostic (tools/level_costs.py): ONE level, on XCD 0
+            const uint32_t l = (uint32_t)atoi(only);
+            NGP_REQUIRE(l < max_level, "NGP_PLACE_ONLY_LEVEL out of range");
+            place = LevelPlacement{};
+            place.own[0][l] = 0xff;
+            grid = dim3(8u * nchunks);
+        }
+        if (getenv("NGP_PLACE_SPREAD")) {   // diagnostic: every XCD works on an eighth of every level, level by level
+            place = LevelPlacement{};
+            for (uint32_t k = 0; k < 8; k++)
+                for (uint32_t l = 0; l < max_level; l++) place.own[k][l] = (uint8_t)(1u << k);
+            grid = dim3(8u * max_level * ceil_div(nchunks, 8u));
+        }
+    }
     if (binned_workspace) {
         // the workspace of ngp_x_grid_backward_binned_* for the same samples, planned (mode 2 of prepare): count here
         NGP_REQUIRE(max_level == L && ((uintptr_t)binned_workspace & 15u) == 0 && n_rows_total > 0,
@@ -760,19 +799,19 @@ extern "C" int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound
         if (dydx)
             grid_forward_slab_kernel<true, true><<<grid, dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
                 xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-                align_corners != 0, interp, w, dydx, snake_levels);
+                align_corners != 0, interp, w, dydx, snake_levels, placed_levels, place);
         else
             grid_forward_slab_kernel<true><<<grid, dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
                 xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-                align_corners != 0, interp, w, nullptr, snake_levels);
+                align_corners != 0, interp, w, nullptr, snake_levels, placed_levels, place);
     } else if (dydx) {
         grid_forward_slab_kernel<false, true><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-            align_corners != 0, interp, WsLayout{}, dydx, snake_levels);
+            align_corners != 0, interp, WsLayout{}, dydx, snake_levels, placed_levels, place);
     } else {
         grid_forward_slab_kernel<false><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-            align_corners != 0, interp, WsLayout{}, nullptr, snake_levels);
+            align_corners != 0, interp, WsLayout{}, nullptr, snake_levels, placed_levels, place);
     }
     NGP_CHECK_LAUNCH("grid_encode_forward_slab");
     return NGP_OK;

@@ -77,4 +77,73 @@ __device__ __forceinline__ void snake_level_tile(uint32_t bid, uint32_t per_leve
     if (level >= n_levels) level = kNoLevel;
 }
 
+// Placement by measured cost.  The snake balances the XCDs only when cost grows with the level the way it does for
+// ray-ordered samples; for scattered points (the density-grid refresh) every hashed level costs the same 4 lines per
+// point and the snake leaves three XCDs with two hashed levels and five with one.  Here a level is cut into 8 slots
+// (tile % 8) and XCD k works on the slots own[k][level] of each level: the 8 * n_levels slots, level-major, are dealt
+// out in 8 contiguous runs of equal cost, so a level lives in at most two or three L2s and every XCD ends together.
+constexpr uint32_t kPlacedLevels = 16;
+struct alignas(16) LevelPlacement {
+    uint8_t own[8][kPlacedLevels];
+};
+
+static inline uint32_t placed_tiles(uint32_t mask, uint32_t per_level)
+{
+    return (per_level >> 3) * (uint32_t)__builtin_popcount(mask) +
+           (uint32_t)__builtin_popcount(mask & ((1u << (per_level & 7u)) - 1u));
+}
+
+// cost[l] > 0: relative cost of one tile of level l.  Returns the workgroups to launch (8 x the longest XCD's list).
+static inline uint32_t place_levels(LevelPlacement &p, const float *cost, uint32_t n_levels, uint32_t per_level)
+{
+    double total = 0.0, acc = 0.0;
+    for (uint32_t l = 0; l < n_levels; l++) total += cost[l];
+    for (uint32_t k = 0; k < 8; k++)
+        for (uint32_t l = 0; l < kPlacedLevels; l++) p.own[k][l] = 0;
+    uint32_t k = 0;
+    for (uint32_t l = 0; l < n_levels; l++)
+        for (uint32_t s = 0; s < 8; s++) {
+            const double c = cost[l] / 8.0;
+            while (k < 7 && acc + 0.5 * c > total * (k + 1) / 8.0) k++;   // the slot goes where most of it falls
+            p.own[k][l] |= (uint8_t)(1u << s);
+            acc += c;
+        }
+    uint32_t longest = 0;
+    for (k = 0; k < 8; k++) {
+        uint32_t n = 0;
+        for (uint32_t l = 0; l < n_levels; l++) n += placed_tiles(p.own[k][l], per_level);
+        longest = n > longest ? n : longest;
+    }
+    return 8u * longest;
+}
+
+__device__ __forceinline__ void placed_level_tile(const LevelPlacement &p, uint32_t bid, uint32_t per_level,
+                                                  uint32_t n_levels, uint32_t &level, uint32_t &tile)
+{
+    const uint32_t k = bid & 7u;
+    uint32_t i = bid >> 3;
+    level = kNoLevel;
+    tile = 0;
+    // this XCD's row in ONE 16-byte scalar load (a load per level would be a chain of 16 latencies in front of every tile)
+    static_assert(kPlacedLevels == 16, "one uint4 per XCD");
+    const uint4 row = reinterpret_cast<const uint4 *>(&p.own[0][0])[k];
+    const uint32_t words[4] = {row.x, row.y, row.z, row.w};
+#pragma unroll
+    for (uint32_t l = 0; l < kPlacedLevels; l++) {
+        const uint32_t m = l < n_levels ? (words[l >> 2] >> ((l & 3u) * 8u)) & 0xffu : 0u;
+        if (!m) continue;
+        const uint32_t c = (uint32_t)__popc(m);
+        const uint32_t n = (per_level >> 3) * c + (uint32_t)__popc(m & ((1u << (per_level & 7u)) - 1u));
+        if (i < n) {
+            const uint32_t q = i / c;
+            uint32_t r = i - q * c, bits = m;
+            while (r--) bits &= bits - 1u;            // drop the r lowest owned slots
+            level = l;
+            tile = q * 8u + (uint32_t)__ffs(bits) - 1u;
+            return;
+        }
+        i -= n;
+    }
+}
+
 }  // namespace ngp

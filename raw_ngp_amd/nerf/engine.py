@@ -33,6 +33,18 @@ from .._lib import mlp_rf_backend as _mlp_rf
 from .._lib import raymarching_backend as rb
 
 
+def _level_cost(env, L):
+    """Per-level tile costs for the slab encoder's level -> XCD placement: `env` = "c0,c1,..." (L positive numbers).  Unset
+    (the default) or "0": the fixed pairing of levels, which measures best for both callers."""
+    text = os.environ.get(env, "").strip()
+    if text in ("", "0"):
+        return None
+    cost = [float(t) for t in text.split(",")]
+    if len(cost) != L or min(cost) <= 0:
+        raise ValueError(f"{env}: expected {L} positive numbers")
+    return cost
+
+
 class _Slot:
     """One ray batch and everything derived from it before the field is evaluated."""
 
@@ -288,6 +300,10 @@ class FusedTrainer:
         self.live_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.live_off = torch.zeros(N, dtype=torch.int32, device=dev)    # where each ray's entries start (ray gradients)
         self.live_list = dev.type == "cuda" and os.environ.get("NGP_LIVE_LIST", "1") != "0"   # (and tile-local records: below)
+        # level -> XCD placement of the slab encoder by per-level costs, per caller (ray-ordered samples in the step,
+        # scattered cell draws in the refresh): an experiment's knob, None = the fixed pairing
+        self.level_cost_step = _level_cost("NGP_LEVEL_COST_STEP", self.L)
+        self.level_cost_refresh = _level_cost("NGP_LEVEL_COST_REFRESH", self.L)
         self.weights_buf = torch.empty(cap, **f32)
         self.ws, self.depth, self.image = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, 3, **f32)
         self.loss = torch.zeros(1, **f32)
@@ -440,7 +456,8 @@ class FusedTrainer:
         ops = [
             ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
                 ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt, cap, cap, self.L, self.L, self.S, self.H,
-                binned_workspace=slot.ws_grid if self.binned_counts else None, dydx=self.dydx if self.pose else None)),
+                binned_workspace=slot.ws_grid if self.binned_counts else None, dydx=self.dydx if self.pose else None,
+                level_cost=self.level_cost_step)),
             ("ngp_x_grid_backward_binned_prepare", lambda: gb.grid_backward_binned_prepare(
                 None, 0.0, offsets, self.rows, cnt, cap, self.L, self.L, self.S, self.H, slot.ws_grid,
                 single_segment=fused_adam or overwrite, stage=2)),
@@ -542,7 +559,7 @@ class FusedTrainer:
             for s in range(0, total, cap):
                 k = min(cap, total - s)
                 eb.grid_encode_forward_slab(self.dg_xyzs[s:s + k], m.bound, self.table, offsets, self.enc, None, None, k,
-                                            cap, self.L, self.L, self.S, self.H)
+                                            cap, self.L, self.L, self.S, self.H, level_cost=self.level_cost_refresh)
                 self._mlp_forward(cap, None, None, None, k, self.dg_sigma[s:s + k], None)
             eb.density_grid_scatter(self.dg_indices[:total], self.dg_sigma[:total], total, self.dg_tmp[cas])
         eb.density_grid_update(m.density_grid, self.dg_tmp, decay, self.dg_stats)

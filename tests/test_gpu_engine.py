@@ -58,6 +58,31 @@ def test_grid_forward_slab_matches_oracle(lib, orc):
     assert torch.all(out[:, B:] == 7.0) and torch.all(inp[B:] == 7.0)
 
 
+@pytest.mark.parametrize("costs", ["flat", "growing", "random", "one heavy level"])
+@pytest.mark.parametrize("B", [5000, 6500, 1])
+def test_grid_forward_slab_placement_by_cost_changes_no_bit(lib, orc, costs, B):
+    """level_cost only moves (level, tile) work items between XCDs: every item still runs exactly once."""
+    rng = np.random.default_rng(3)
+    cap, L, H, bound = 6500, 16, 16, 1.0           # 26 tiles: 3 per slot and 2 left over; B = 1: a single live tile
+    offsets, scale = orc.grid_offsets(desired_resolution=2048 * bound)
+    S = float(np.log2(scale))
+    table = dev(rng.uniform(-1, 1, (offsets[-1], 2)).astype(np.float32))
+    xyz = dev(rng.uniform(-bound, bound, (cap, 3)).astype(np.float32))
+    cnt = torch.tensor([B, 0], dtype=torch.int32, device="cuda")
+    cost = {"flat": [1.0] * L, "growing": [1.0 + 0.3 * l for l in range(L)],
+            "random": list(rng.uniform(0.05, 20.0, L)), "one heavy level": [1.0] * 9 + [1000.0] + [1.0] * 6}[costs]
+    outs = []
+    for c in (None, cost):
+        out, inp = torch.full((L, cap, 2), 7.0, device="cuda"), torch.full((cap, 3), 7.0, device="cuda")
+        lib.engine_backend.grid_encode_forward_slab(xyz, bound, table, dev(offsets), out, inp, cnt, cap, cap, L, L, S, H,
+                                                    level_cost=c)
+        outs.append((out, inp))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    with pytest.raises(RuntimeError, match="level_cost"):
+        lib.engine_backend.grid_encode_forward_slab(xyz, bound, table, dev(offsets), out, inp, cnt, cap, cap, L, L, S, H,
+                                                    level_cost=[1.0] * 15 + [0.0])
+
+
 @pytest.mark.parametrize("T_thresh", [0.0, 1e-8, 1e-4])
 def test_wave_compositing_matches_oracle(lib, orc, T_thresh):
     rng = np.random.default_rng(11)
