@@ -356,6 +356,11 @@ int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const float *dirs
                             const void *image, float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2,
                             float *dw3, float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
                             ngp_stream_t stream);
+/* d h0 / d enc for samples 0 .. M - 1 (level-major slab like `enc`), h0 = the density network's first output, sigma =
+ * trunc_exp(h0) (nerf/network.py:111-118): the MLP's part of torch.autograd.grad(sigma, pos) in the orientation term
+ * (nerf/renderer.py:558-566).  The f16 chain of the backward's density kernel with delta = e_0; no weight gradients. */
+int ngp_x_mlp_density_gradient(const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M, const void *image,
+                               float *denc, ngp_stream_t stream);
 int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
                         float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
                         const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,
@@ -562,6 +567,25 @@ int ngp_x_composite_train_live_idx(const float *gt_rgba, const float *bg_rgb, fl
                                    uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,
                                    float *grad_sigmas, float *grad_rgbs, float *loss_out, int32_t *live_n,
                                    int32_t *live_idx, int32_t *live_count, int32_t *live_off, ngp_stream_t stream);
+/* ... plus a term over the samples' compositing weights (nerf/renderer.py:571, train_utils.py:546-548 with
+ * sample_term = ngp_x_orientation_term's output): loss += lambda_sample * sum_i weights[i] * sample_term[i] -- a SUM over
+ * all samples (the reference takes torch.mean of a scalar).  The gradient is the one the reference's compositor backward
+ * gives grad_weights (raymarching.cu:694: added to grad_weights_sum at the sample itself); sample_term itself is a
+ * constant (the reference's autograd.grad runs without create_graph).  sample_term == NULL: none. */
+int ngp_x_composite_train_terms(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
+                                const float *weight, float inv_norm, const int32_t *n_live, float lambda_entropy,
+                                const float *sample_term, float lambda_sample, const float *sigmas, const float *rgbs,
+                                const float *ts, const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                float *weights_sum, float *depth, float *image, float *grad_sigmas, float *grad_rgbs,
+                                float *loss_out, int32_t *live_n, int32_t *live_idx, int32_t *live_count, int32_t *live_off,
+                                ngp_stream_t stream);
+/* The per-sample factor of the orientation term (nerf/renderer.py:558-571): g = d sigma / d xyz = clamp(sigma, e^-80, e^80)
+ * (trunc_exp's backward, activation.py:20) * sum_l dh_denc_l . dydx_l / (2 bound) from the level-major slabs of
+ * ngp_x_mlp_density_gradient and ngp_x_grid_encode_forward_slab_jac; normal = (-g / max(|g|, 1e-12) + 1) / 2;
+ * term[i] = min(0, sum_d normal_d * -(dirs / |dirs|)_d)^2.  One thread per sample, samples 0 .. min(*M_dev, M) - 1. */
+int ngp_x_orientation_term(const float *dh_denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
+                           const float *sigmas, const float *dirs, const int32_t *M_dev, uint32_t M, float *term,
+                           ngp_stream_t stream);
 
 /* ---- pose refinement around the fused step (csrc/pose_kernels.hip) -----------------------------------------------
  * ngp_x_step_window   annealing = float16((step_counter[0] + step_offset) / iters) (train_utils.py:488) -> the BARF level

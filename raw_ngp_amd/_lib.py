@@ -82,6 +82,10 @@ _SIGNATURES = {
     "ngp_x_composite_train_live": [_p, _p, _f, _p, _p, _f, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
     "ngp_x_composite_train_live_idx": [_p, _p, _f, _p, _p, _f, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p,
                                        _p, _p, _p, _p],
+    "ngp_x_composite_train_terms": [_p, _p, _f, _p, _p, _f, _p, _f, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p,
+                                    _p, _p, _p, _p, _p],
+    "ngp_x_orientation_term": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _p],
+    "ngp_x_mlp_density_gradient": [_p, _u, _p, _u, _p, _p],
     "ngp_x_step_window": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_step_window_baa": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_slab_window": [_p, _u, _u, _p, _p, _u, _i],
@@ -646,6 +650,13 @@ class _MlpBackend:
             _call("ngp_x_mlp_backward", enc, *head, *grads, ws.data_ptr(), nbytes)
 
     @staticmethod
+    def density_gradient(enc, stride, M_dev, M, image, denc):
+        """denc [L, stride, 2] <- d h0 / d enc per sample, h0 = the density network's first output (sigma = trunc_exp(h0)):
+        the MLP's part of autograd.grad(sigma, pos) in the orientation term (nerf/renderer.py:558-566)."""
+        _call("ngp_x_mlp_density_gradient", enc, _ptr(enc, "f", "enc"), stride, _ptr(M_dev, "i", "M_dev", True), M,
+              image.data_ptr(), _ptr(denc, "f", "denc"))
+
+    @staticmethod
     def reduce_dw(M, loss_scale, dws, workspace, adam=None, image=None):
         """Second half of backward(..., dws=None): weight gradients from the partial sums left in `workspace`.
         adam = (param, grad, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps) with dws views of the flat `grad`: also
@@ -788,11 +799,24 @@ class _EngineBackend:
     @staticmethod
     def composite_train_live(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, n_live, sigmas, rgbs, ts, rays, M, N,
                              T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out, lambda_entropy=0.0,
-                             live=None):
+                             live=None, sample_term=None, lambda_sample=0.0):
         """composite_mse_train (exposure None) / composite_hdr_train over the first n_live[0] ray slots (None: all), plus
         lambda_entropy * mean entropy of the rays' accumulated opacity (train_utils.py:554-557).
         live = (live_n [N], live_idx [M], live_count [1], live_off [N] or None) int32: also list the samples in front of the
-        early stop (and where each ray's entries start)."""
+        early stop (and where each ray's entries start).
+        sample_term [M]: loss += lambda_sample * sum_i weights[i] * sample_term[i] (the orientation term)."""
+        if sample_term is not None:
+            lv = live if live is not None else (None, None, None, None)
+            _call("ngp_x_composite_train_terms", rays, _ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
+                  float(bg_const), _ptr(exposure, "f", "exposure", True), _ptr(weight, "f", "weight", True), float(inv_norm),
+                  _ptr(n_live, "i", "n_live", True), float(lambda_entropy), _ptr(sample_term, "f", "sample_term"),
+                  float(lambda_sample), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"), _ptr(ts, "f", "ts"),
+                  _ptr(rays, "i", "rays"), M, N, float(T_thresh), _ptr(weights_sum, "f", "weights_sum"),
+                  _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
+                  _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"), _ptr(lv[0], "i", "live_n", True),
+                  _ptr(lv[1], "i", "live_idx", True), _ptr(lv[2], "i", "live_count", True),
+                  _ptr(lv[3], "i", "live_off", True), probe_as="ngp_x_composite_train_live")
+            return
         args = [_ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
                 float(bg_const), _ptr(exposure, "f", "exposure", True), _ptr(weight, "f", "weight", True), float(inv_norm),
                 _ptr(n_live, "i", "n_live", True), float(lambda_entropy), _ptr(sigmas, "f", "sigmas"), _ptr(rgbs, "f", "rgbs"),
@@ -819,6 +843,13 @@ class _EngineBackend:
         scale_only: the BARF window f'_l = w_l f_l (self-adjoint)."""
         _call("ngp_x_slab_window", slab, _ptr(slab, "f", "slab"), int(stride), int(L), _ptr(level_w, "f", "level_w"),
               _ptr(M_dev, "i", "M_dev", True), int(M), 2 if scale_only else int(bool(backward)))
+
+    @staticmethod
+    def orientation_term(dh_denc, dydx, stride, L, bound, sigmas, dirs, M_dev, M, term):
+        """term [M] <- min(0, n . -v)^2 per sample with n = (-normalize(d sigma / d xyz) + 1) / 2 (nerf/renderer.py:558-571);
+        dh_denc: mlp_backend.density_gradient's slab, dydx: the Jacobian slab of grid_encode_forward_slab."""
+        _call("ngp_x_orientation_term", term, _ptr(dh_denc, "f", "dh_denc"), _ptr(dydx, "f", "dydx"), stride, L, float(bound),
+              _ptr(sigmas, "f", "sigmas"), _ptr(dirs, "f", "dirs"), _ptr(M_dev, "i", "M_dev", True), M, _ptr(term, "f", "term"))
 
     @staticmethod
     def ray_gradients(denc, dydx, stride, L, bound, ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d, live=None):

@@ -275,6 +275,12 @@ struct HdrLoss {
     // MODE 2: the number of samples in front of (and including) the compositor's early stop, per ray slot -- the samples
     // that can have a gradient at all (live_index_kernel turns the counts into a compact list for the backward kernels)
     int32_t *live_out = nullptr;
+    // MODE 2: a term over the samples' compositing weights, loss += lambda_sample * sum_i w_i sample_term[i] (the
+    // orientation term, renderer.py:571: `weights` reach the loss directly).  Its gradient is the reference's, i.e. what
+    // kernel_composite_rays_train_backward does with grad_weights (raymarching.cu:694): added to grad_weights_sum at the
+    // sample itself
+    const float *sample_term = nullptr;
+    float lambda_sample = 0.0f;
 };
 
 template <int MODE>
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
     const uint32_t nn = in_range ? n : 0u;
     const uint32_t off = (uint32_t)rays[(size_t)nn * 2], cnt = (uint32_t)rays[(size_t)nn * 2 + 1];
     const bool live = in_range && cnt != 0 && off + cnt <= M;
-    float rF, gF, bF, wsF, dF;
+    float rF, gF, bF, wsF, dF, term_sum = 0.0f;
     if (MODE == 2) {
         float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0;
         uint32_t used = live ? cnt : 0u;   // samples up to and including the early stop
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
             for (uint32_t base = 0; base < cnt; base += 64u) {
                 const uint32_t i = off + base + lane;
                 const bool have = base + lane < cnt;
-                float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f;
+                float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f, term = 0.f;
                 if (have) {
                     const float2 tt = reinterpret_cast<const float2 *>(ts)[i];
                     alpha = 1.0f - __expf(-sigmas[i] * tt.y);
@@ -313,6 +319,7 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
                     c0 = rgbs[(size_t)i * 3];
                     c1 = rgbs[(size_t)i * 3 + 1];
                     c2 = rgbs[(size_t)i * 3 + 2];
+                    if (hdr.sample_term) term = hdr.sample_term[i];
                 }
                 const float Tb = T * wave_excl_prod(1.0f - alpha, lane);
                 const float Ta = Tb * (1.0f - alpha);
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
                 b += wave_sum(w * c2);
                 ws += wave_sum(w);
                 d += wave_sum(w * t);
+                if (hdr.sample_term) term_sum += wave_sum(w * term);
                 T = __shfl(Ta, min(last, 63u), 64);
                 if (hit != 0ull) {   // wave-uniform
                     used = base + last + 1u;
@@ -387,6 +395,7 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
             // (torch.clamp passes the gradient on [min, max], ends included)
             if (wsF >= 1e-5f && wsF <= 1.0f - 1e-5f) gws += kk * (log2f(1.0f - wcl) - log2f(wcl));
         }
+        if (MODE == 2) ray_loss += hdr.lambda_sample * term_sum;   // (a SUM over the samples: torch.mean of a scalar)
         if (lane == 0 && in_range) ray_err[threadIdx.x >> 6] = ray_loss;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -425,6 +434,7 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
             c1 = rgbs[(size_t)i * 3 + 1];
             c2 = rgbs[(size_t)i * 3 + 2];
             if (MODE == 0) gw = grad_weights[i];
+            if (MODE == 2 && hdr.sample_term) gw = hdr.lambda_sample * hdr.sample_term[i];
         }
         const float Tb = T * wave_excl_prod(1.0f - alpha, lane);
         const float Ta = Tb * (1.0f - alpha);
@@ -938,6 +948,21 @@ extern "C" int ngp_x_composite_train_live_idx(const float *gt_rgba, const float 
                                               float *grad_rgbs, float *loss_out, int32_t *live_n, int32_t *live_idx,
                                               int32_t *live_count, int32_t *live_off, ngp_stream_t stream)
 {
+    return ngp_x_composite_train_terms(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, n_live, lambda_entropy, nullptr,
+                                       0.0f, sigmas, rgbs, ts, rays, M, N, T_thresh, weights_sum, depth, image, grad_sigmas,
+                                       grad_rgbs, loss_out, live_n, live_idx, live_count, live_off, stream);
+}
+
+// ... plus a term over the samples' compositing weights: loss += lambda_sample * sum_i weights[i] * sample_term[i]
+// (sample_term [M], e.g. ngp_x_orientation_term; NULL: none)
+extern "C" int ngp_x_composite_train_terms(const float *gt_rgba, const float *bg_rgb, float bg_const, const float *exposure,
+                                           const float *weight, float inv_norm, const int32_t *n_live, float lambda_entropy,
+                                           const float *sample_term, float lambda_sample, const float *sigmas,
+                                           const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
+                                           float T_thresh, float *weights_sum, float *depth, float *image,
+                                           float *grad_sigmas, float *grad_rgbs, float *loss_out, int32_t *live_n,
+                                           int32_t *live_idx, int32_t *live_count, int32_t *live_off, ngp_stream_t stream)
+{
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(gt_rgba && rays && weights_sum && depth && image && loss_out, "composite_train_live: null tensor");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && ts && grad_sigmas && grad_rgbs), "composite_train_live: null sample tensor");
@@ -951,6 +976,10 @@ extern "C" int ngp_x_composite_train_live_idx(const float *gt_rgba, const float 
     hdr.n_live = n_live;
     NGP_REQUIRE(lambda_entropy >= 0.0f, "composite_train_live: lambda_entropy must not be negative");
     hdr.lambda_entropy = lambda_entropy;
+    NGP_REQUIRE(sample_term ? lambda_sample >= 0.0f : lambda_sample == 0.0f,
+                "composite_train_terms: lambda_sample needs sample_term and must not be negative");
+    hdr.sample_term = sample_term;
+    hdr.lambda_sample = lambda_sample;
     const bool listing = live_n != nullptr;
     NGP_REQUIRE(listing ? (live_idx && live_count && M > 0) : (!live_idx && !live_count && !live_off),
                 "composite_train_live: live_n, live_idx and live_count go together");

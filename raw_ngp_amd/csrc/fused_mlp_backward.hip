@@ -114,7 +114,7 @@ __device__ __forceinline__ RawTile fetch_raw(const float *__restrict__ enc, size
             r.gr[0] = drgb[(size_t)row * 3];
             r.gr[1] = drgb[(size_t)row * 3 + 1];
             r.gr[2] = drgb[(size_t)row * 3 + 2];
-        } else {
+        } else if (d3buf) {
             r.p3 = d3buf[(size_t)c * 2 + h];
         }
     }
@@ -476,7 +476,9 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 // ---- grid kernel ---------------------------------------------------------------------------------
 // WINDOW: the encoder features are multiplied by a per-level weight before the MLP (BARF, network.py:99-109); the same
 // weight then scales d enc
-template <bool WINDOW>
+// UNIT: delta3 = e_0 for every sample instead of the view kernel's (d3buf NULL) and no weight gradients: d enc is then
+// d h0 / d enc, the gradient of the density network's first output (sigma = trunc_exp(h0)) -- ngp_x_mlp_density_gradient
+template <bool WINDOW, bool UNIT = false>
 __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
     const float *__restrict__ enc, uint32_t stride, const int32_t *__restrict__ M_dev, uint32_t M_host,
     const half8 *__restrict__ image, float inv_loss_scale, const half8 *__restrict__ d3buf,
@@ -518,7 +520,10 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
             nxt = fetch_raw<false>(enc, stride, nullptr, nullptr, nullptr, d3buf, row_nxt, nc, tile + n_waves < n_tiles && nc < M, h);
             row_nxt = sample_of(tile + 2u * n_waves);
         }
-        const half8 p3 = cur.p3;
+        half8 p3 = cur.p3;
+        if constexpr (UNIT) {
+            if (valid && h == 0) p3[0] = (_Float16)1.0f;
+        }
         {   // all-zero deltas (see the view kernel): the tile's encoder gradient is zero, nothing else changes
             typedef short short8 __attribute__((ext_vector_type(8)));
             const short8 bits = __builtin_bit_cast(short8, p3) & (short8)0x7fff;   // -0 counts as zero
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
 
         half8 aT[2], bT[2];
         // ---------------- layer 3: dW3 = delta3 x H2^T ; delta2 = W3^T delta3 (masked)
-        {
+        if constexpr (!UNIT) {
             const f32x16 t3 = mfma(p3, I0, zero16());
             aT[0] = pack<0, false>(t3);
             aT[1] = pack<1, false>(t3);
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
             p2[rb][1] = pack_masked<1>(dh, h2[rb][1]);
         }
         // ---------------- layer 2: dW2 = delta2 x H1^T ; delta1 = W2^T delta2 (masked)
-        {
+        if constexpr (!UNIT) {
             half8 a2[2][2];
 #pragma unroll
             for (int rb = 0; rb < 2; rb++) {
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
             p1[rb][1] = pack_masked<1>(dh, h1[rb][1]);
         }
         // ---------------- layer 1: dW1 = delta1 x X0^T ; d enc = W1^T delta1
-        {
+        if constexpr (!UNIT) {
             const f32x16 tx = transpose_tile(in.x0[0], in.x0[1], I0, I1);
             bT[0] = pack<0, false>(tx);
             bT[1] = pack<1, false>(tx);
@@ -665,7 +670,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
             }
         }
     }
-    flush_tiles_parallel<8>(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kAccFloats);
+    if constexpr (!UNIT)
+        flush_tiles_parallel<8>(reinterpret_cast<float *>(lds_w), g, lane, partial + (size_t)blockIdx.x * kAccFloats);
 }
 
 // ---- partial-slab reduction -----------------------------------------------------------------------
@@ -690,6 +696,8 @@ static bool mlp_backward_lds_ok()
         r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
         r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
+        r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<false, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
         return r;
     }();
@@ -820,6 +828,22 @@ extern "C" int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const 
         mlp_reduce_dw_kernel<<<dim3(kDwGroups), dim3(256), 0, st>>>(
             MlpDwReduce{part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, MlpAdam{}});
     NGP_CHECK_LAUNCH("mlp_backward");
+    return NGP_OK;
+}
+
+// d h0 / d enc for every sample, h0 = the density network's first output (sigma = trunc_exp(h0), network.py:111-118): what
+// torch.autograd.grad(sigma, pos) of the orientation term (renderer.py:558-566) needs from the MLP, up to the factor
+// d sigma / d h0 the caller knows from sigma itself.  Same f16 chain as the backward's density kernel, delta3 = e_0.
+extern "C" int ngp_x_mlp_density_gradient(const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M,
+                                          const void *image, float *denc, ngp_stream_t stream)
+{
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(enc && image && denc, "mlp_density_gradient: null tensor");
+    NGP_REQUIRE(stride >= M, "mlp_density_gradient: encoder slab stride smaller than M");
+    NGP_REQUIRE(mlp_backward_lds_ok(), "mlp_density_gradient: cannot raise the dynamic LDS limit");
+    mlp_backward_grid_kernel<false, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, as_stream(stream)>>>(
+        enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, nullptr, T_W3, nullptr);
+    NGP_CHECK_LAUNCH("mlp_density_gradient");
     return NGP_OK;
 }
 

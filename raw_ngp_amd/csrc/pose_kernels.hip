@@ -167,6 +167,41 @@ __global__ __launch_bounds__(256) void ray_gradients_kernel(const float *__restr
     }
 }
 
+// ------------------------------------------------------------------ orientation term, per sample
+// renderer.py:558-571: normals = -normalize(d sigma / d xyz) mapped to [0, 1], n_dot_v against the (normalised) view
+// direction, min(0, .)^2.  d sigma / d xyz = trunc_exp'(h0) * sum_l (d h0 / d enc_l) . (d enc_l / d x01) / (2 bound); the
+// first factor only matters against normalize's eps.  One thread per sample.
+__global__ __launch_bounds__(256) void orientation_term_kernel(const float *__restrict__ dh_denc, const float *__restrict__ dydx,
+                                                               uint32_t stride, uint32_t L, float inv_2bound,
+                                                               const float *__restrict__ sigmas, const float *__restrict__ dirs,
+                                                               const int32_t *__restrict__ M_dev, uint32_t M_cap,
+                                                               float *__restrict__ term)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_cap) : M_cap;
+    if (i >= M) return;
+    float g[3] = {0, 0, 0};
+    for (uint32_t l = 0; l < L; l++) {
+        const float2 ge = reinterpret_cast<const float2 *>(dh_denc)[(size_t)l * stride + i];
+        const float2 *j = reinterpret_cast<const float2 *>(dydx) + ((size_t)l * stride + i) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float2 jj = j[d];
+            g[d] = fmaf(ge.x, jj.x, g[d]);
+            g[d] = fmaf(ge.y, jj.y, g[d]);
+        }
+    }
+    // exp(clamp(h0, -80, 80)) (activation.py:20) from sigma = exp(h0)
+    const float k = fminf(fmaxf(sigmas[i], 1.8048513878454153e-35f), 5.5406223843935098e+34f) * inv_2bound;
+    const float v0 = g[0] * k, v1 = g[1] * k, v2 = g[2] * k;
+    const float inv = 1.0f / fmaxf(sqrtf(v0 * v0 + v1 * v1 + v2 * v2), 1e-12f);      // F.normalize
+    const float d0 = dirs[(size_t)i * 3], d1 = dirs[(size_t)i * 3 + 1], d2 = dirs[(size_t)i * 3 + 2];
+    const float dn = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    const float n0 = (-(v0 * inv) + 1.0f) * 0.5f, n1 = (-(v1 * inv) + 1.0f) * 0.5f, n2 = (-(v2 * inv) + 1.0f) * 0.5f;
+    const float ndv = fminf(n0 * -(d0 * dn) + n1 * -(d1 * dn) + n2 * -(d2 * dn), 0.0f);
+    term[i] = ndv * ndv;
+}
+
 // ------------------------------------------------------------------ d loss / d pose per camera
 // rays_o = P[:, 3], rays_d[k] = sum_j dir_cam[j] P[k][j] with dir_cam = ((i + .5 - cx) / fx, -(j + .5 - cy) / fy, -1)
 // (train_utils.py:150-160).  One workgroup per camera scans the batch's (view, pixel) list: a fixed summation order.
@@ -455,6 +490,19 @@ extern "C" int ngp_x_ray_gradients_list(const float *denc, const float *dydx, ui
     ray_gradients_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
         denc, dydx, stride, L, 1.0f / (2.0f * bound), ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d, live_n, live_off);
     NGP_CHECK_LAUNCH("ray_gradients_list");
+    return NGP_OK;
+}
+
+extern "C" int ngp_x_orientation_term(const float *dh_denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
+                                      const float *sigmas, const float *dirs, const int32_t *M_dev, uint32_t M, float *term,
+                                      ngp_stream_t stream)
+{
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(dh_denc && dydx && sigmas && dirs && term, "orientation_term: null tensor");
+    NGP_REQUIRE(stride >= M && bound > 0.0f && L >= 1, "orientation_term: bad stride / bound / L");
+    orientation_term_kernel<<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
+        dh_denc, dydx, stride, L, 1.0f / (2.0f * bound), sigmas, dirs, M_dev, M, term);
+    NGP_CHECK_LAUNCH("orientation_term");
     return NGP_OK;
 }
 

@@ -83,10 +83,13 @@ class FusedTrainer:
             "fused step: HDR loss_weight gaussian / hanning need batch statistics -- use Trainer"
         assert not (getattr(opt, "lambda_entropy", 0) > 0 and getattr(opt, "loss_weight", "none") == "planck"), \
             "fused step: the entropy term and a planck loss weight are not combined"
-        # terms of the reference's train_step (train_utils.py:544-564) this step does not compute: refuse them instead of
-        # silently training a different objective than the per-op Trainer would with the same Options
-        unsupported = [k for k in ("lambda_orientation", "lambda_distort") if getattr(opt, k, 0) > 0]
-        assert not unsupported, f"fused step: {unsupported} not implemented here -- use nerf.trainer.Trainer"
+        # the orientation term (renderer.py:558-571, train_utils.py:546-548): per sample, from d sigma / d xyz -- one more
+        # pass through the density network and the encoder's Jacobian slab in front of the compositor.  (lambda_distort
+        # needs no code: only the renderer WITHOUT the density grid returns a distort_loss, renderer.py:504-505 -- on this
+        # path the reference's train_step never sees one, train_utils.py:550.)
+        self.orient = float(getattr(opt, "lambda_orientation", 0.0)) > 0
+        assert not (self.orient and (self.rfield or self.pose)), \
+            "fused step: the orientation term with the light-conditioned field / pose refinement -- use nerf.trainer.Trainer"
         assert not getattr(opt, "fp16", False) or opt.loss_scale > 0, "fused step: --fp16 maps to the static loss scale"
         self.opt, self.model, self.data, self.device = opt, model.to(device), dataset, torch.device(device)
         opt.fused_mlp = True
@@ -282,12 +285,15 @@ class FusedTrainer:
             self.pose_gamma = 1e-2 ** (1.0 / opt.iters)                   # ExponentialLR of camera_optimizers.py:44-50
             eb.pose_update(self.xi, self.pose_base, None, None, None, None, self.pose_lr0, self.pose_gamma, 0.9, 0.999, 1e-8,
                            self.poses_refined)
-            self.dydx = torch.empty(self.L, cap, 3, 2, **f32)
             self.ddirs = torch.empty(cap, 3, **f32)
             # before the first step the reference's annealing value is 0.0 (train_utils.py:411): the first density-grid
             # refresh sees that window (level 0 only)
             eb.step_window(self.step_ctr, 0, float(opt.iters), opt.start_annealing, opt.end_annealing, self.L, self.level_w,
                            self.flags, baa=self.baa)
+        if self.pose or self.orient:                   # d enc / d x01, written by the encoder's forward
+            self.dydx = torch.empty(self.L, cap, 3, 2, **f32)
+        if self.orient:
+            self.orient_term = torch.zeros(cap, **f32)
         self.enc = torch.empty(self.L, cap, 2, **f32)
         self.denc = torch.empty(self.L, cap, 2, **f32)
         self.x01 = torch.empty(cap, 3, **f32)
@@ -379,7 +385,8 @@ class FusedTrainer:
         self.field_forward_backward(slot, gt_rgba, bg_rgb, bg_const)
 
     def field_forward_backward(self, slot, gt_rgba, bg_rgb=None, bg_const=0.0):
-        for _, op in self._field_ops(slot, gt_rgba, bg_rgb, bg_const):
+        # (the orientation term lives in the one-launch compositor step)
+        for _, op in self._field_ops(slot, gt_rgba, bg_rgb, bg_const, fuse_composite=self.orient):
             op()
 
     def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False, split_weights=False,
@@ -402,6 +409,16 @@ class FusedTrainer:
             if zero_loss:
                 self.loss.zero_()
             lam = float(getattr(opt, "lambda_entropy", 0.0))
+            if self.orient:         # the general entry: any of the above + the term over the samples' weights
+                weight = self._planck_weight(gt_rgba, bg_rgb, bg_const) if self.hdr and opt.loss_weight == "planck" else None
+                eb.composite_train_live(gt_rgba, bg_rgb, bg_const, slot.exposure if self.hdr else None, weight, 1.0 / (3 * N),
+                                        slot.live if self.adaptive else None, self.sigma, self.rgb, ar.ts, ar.rays, cap, N,
+                                        opt.T_thresh, self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
+                                        lambda_entropy=lam, live=live, sample_term=self.orient_term,
+                                        lambda_sample=float(opt.lambda_orientation))
+                if self.adaptive:
+                    self.rays_seen.add_(slot.live)
+                return
             if self.adaptive or (lam > 0 and not (self.hdr and opt.loss_weight == "planck")):
                 # loss over the rays the batch really carries (adaptive), + the entropy of the accumulated opacity
                 eb.composite_train_live(gt_rgba, bg_rgb, bg_const, slot.exposure if self.hdr else None, None, 1.0 / (3 * N),
@@ -439,6 +456,10 @@ class FusedTrainer:
         live = (self.live_n, self.live_idx, self.live_count, self.live_off if self.pose else None) if live_list else None
         back_n, back_idx = (self.live_count, self.live_idx) if live_list else (cnt, None)
 
+        def orientation_term():     # min(0, n . -v)^2 per sample; d enc is free until the backward writes it
+            self.mb.density_gradient(self.enc, cap, cnt, cap, self.mlp_image, self.denc)
+            eb.orientation_term(self.denc, self.dydx, cap, self.L, m.bound, self.sigma, ar.dirs, cnt, cap, self.orient_term)
+
         def mlp_backward():
             if self.rfield:         # one call: both view kernels, the density kernel, the weight-gradient reduction
                 self.mb.backward(self.enc, cap, ar.dirs, ar.ldirs, None if self.baa else self.level_w, self.dsigma, self.drgb,
@@ -456,13 +477,14 @@ class FusedTrainer:
         ops = [
             ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
                 ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt, cap, cap, self.L, self.L, self.S, self.H,
-                binned_workspace=slot.ws_grid if self.binned_counts else None, dydx=self.dydx if self.pose else None,
-                level_cost=self.level_cost_step)),
+                binned_workspace=slot.ws_grid if self.binned_counts else None,
+                dydx=self.dydx if self.pose or self.orient else None, level_cost=self.level_cost_step)),
             ("ngp_x_grid_backward_binned_prepare", lambda: gb.grid_backward_binned_prepare(
                 None, 0.0, offsets, self.rows, cnt, cap, self.L, self.L, self.S, self.H, slot.ws_grid,
                 single_segment=fused_adam or overwrite, stage=2)),
             ("ngp_x_mlp_prepare", self._mlp_prepare),
             ("ngp_x_mlp_forward", lambda: self._mlp_forward(cap, ar.dirs, ar.ldirs, cnt, cap, self.sigma, self.rgb)),
+            *([("ngp_x_orientation_term", orientation_term)] if self.orient else []),
             ("ngp_x_composite_rays_train_forward", lambda: eb.composite_rays_train_forward(
                 self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.weights_buf, self.ws, self.depth,
                 self.image)),
@@ -475,7 +497,7 @@ class FusedTrainer:
         ]
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
-        assert fuse_composite or not self.hdr, "the HDR loss lives in the fused compositor step"
+        assert fuse_composite or not (self.hdr or self.orient), "the HDR loss / the orientation term live in the fused compositor step"
         if fuse_composite:
             ops = [o for o in ops if o[0] != "ngp_x_composite_rays_train_forward"]
             ops = [("ngp_x_composite_mse_train", composite_train) if o[0] == "ngp_x_composite_mse_backward" else o

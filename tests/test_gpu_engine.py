@@ -255,6 +255,114 @@ def test_fused_step_matches_autograd_path(lib):
     assert torch.all(eng.table_grad == 0)
 
 
+def test_sample_weight_term_of_the_fused_compositor_step_matches_the_per_op_backward(lib):
+    """loss += lambda * sum_i weights[i] * term[i] (the shape of the orientation term, renderer.py:571) inside the one-launch
+    compositor step: loss value and d sigma / d rgb against torch autograd over the per-op compositor, whose backward gives
+    grad_weights the reference's treatment (raymarching.cu:694)."""
+    rng = np.random.default_rng(17)
+    N, lam = 1200, 0.3
+    sig, rgb, ts, rays, M = synth_samples(rng, N)
+    term = (rng.uniform(0, 1, M) ** 2).astype(np.float32)
+    gt = rng.uniform(0, 1, (N, 4)).astype(np.float32)
+    e = lib.engine_backend
+    from raw_ngp_amd import raymarching
+    tsig, trgb = dev(sig).requires_grad_(True), dev(rgb).requires_grad_(True)
+    w, ws, dep, img = raymarching.composite_rays_train(tsig, trgb, dev(ts), dev(rays), 1e-4)
+    tgt = dev(gt)[:, :3] * dev(gt)[:, 3:]
+    extra = torch.mean((w * dev(term)).sum(dim=-1))
+    loss = ((img - tgt) ** 2).mean(-1).mean() + lam * extra
+    loss.backward()
+    gs, gc = torch.empty(M, device="cuda"), torch.empty(M, 3, device="cuda")
+    lo = torch.zeros(1, device="cuda")
+    ws2, dep2, img2 = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 3, device="cuda")
+    live = (torch.empty(N, dtype=torch.int32, device="cuda"), torch.empty(M, dtype=torch.int32, device="cuda"),
+            torch.empty(1, dtype=torch.int32, device="cuda"), None)
+    for lv in (None, live):
+        lo.zero_()
+        e.composite_train_live(dev(gt), None, 0.0, None, None, 1.0 / (3 * N), None, tsig.detach(), trgb.detach(), dev(ts),
+                               dev(rays), M, N, 1e-4, ws2, dep2, img2, gs, gc, lo, live=lv, sample_term=dev(term),
+                               lambda_sample=lam)
+        np.testing.assert_allclose(float(lo), float(loss.detach()), rtol=2e-5)
+        assert float(extra.detach()) > 1.0                                  # a sum over the samples, not a mean over the rays
+        covered = np.zeros(M, bool)
+        for n in range(N):
+            covered[rays[n, 0]:rays[n, 0] + rays[n, 1]] = True
+        np.testing.assert_allclose(host(gc)[covered], host(trgb.grad)[covered], rtol=1e-3, atol=1e-8)
+        ref = host(tsig.grad)[covered]
+        assert np.all(np.abs(host(gs)[covered] - ref) <= 3e-3 * np.abs(ref) + 1e-6)
+    gs0 = torch.empty(M, device="cuda")
+    e.composite_train_live(dev(gt), None, 0.0, None, None, 1.0 / (3 * N), None, tsig.detach(), trgb.detach(), dev(ts), dev(rays),
+                           M, N, 1e-4, ws2, dep2, img2, gs0, gc, torch.zeros(1, device="cuda"))
+    assert float((gs - gs0).abs().max()) > 1e-3
+    with pytest.raises(RuntimeError, match="lambda_sample"):
+        e.composite_train_live(dev(gt), None, 0.0, None, None, 1.0 / (3 * N), None, tsig.detach(), trgb.detach(), dev(ts),
+                               dev(rays), M, N, 1e-4, ws2, dep2, img2, gs0, gc, lo, sample_term=dev(term), lambda_sample=-1.0)
+
+
+def test_fused_step_with_the_orientation_term_matches_the_per_op_path(lib):
+    """lambda_orientation > 0 (renderer.py:558-571, train_utils.py:546-548): the per-sample term, the loss and the gradients
+    of the fused step against the per-op path over the same rays (fused MLP on both sides), and the term itself against torch
+    autograd through fp32 nn.Linear MLPs."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    torch.manual_seed(0)
+    lam = 1e-2
+    opt = Options(bound=1.0, num_rays=1024, iters=100, fused_mlp=True, lambda_orientation=lam, lambda_distort=1e-3)
+    data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=4, H=64, W=64)
+    model = NeRFNetwork(opt).cuda()
+    with torch.no_grad():                                     # make the field non-trivial
+        model.grid_encoder.embeddings.uniform_(-0.5, 0.5)
+    eng = FusedTrainer(opt, model, data, device="cuda", capacity=1024 * 256)     # (lambda_distort: no term on this path)
+    assert eng.orient
+    model.train()
+    model.update_extra_state()
+    batch = data.sample_rays(opt.num_rays, torch.Generator(device="cuda").manual_seed(1))
+    gt = batch["images"]
+    eng.forward_backward(batch["rays_o"].contiguous(), batch["rays_d"].contiguous(), gt.contiguous(),
+                         torch.zeros(opt.num_rays, device="cuda"))
+    M = int(eng.arena.counter[0])
+    assert 0 < M <= eng.cap
+    term = eng.orient_term[:M].clone()
+
+    model.zero_grad()
+    out = model.render(batch["rays_o"], batch["rays_d"], bg_color=0, perturb=False)
+    assert out["num_points"] == M
+    tgt = gt[:, :3] * gt[:, 3:]
+    mse = ((out["image"] - tgt) ** 2).mean(-1).mean()
+    loss = mse + lam * out["orientation_loss"]
+    assert float(lam * out["orientation_loss"].detach()) > 0.05 * float(mse.detach())     # the term matters here
+    loss.backward()
+    np.testing.assert_allclose(float(eng.loss), float(loss.detach()), rtol=1e-3)
+    ref_t = model.grid_encoder.embeddings.grad
+    ref_w = torch.cat([l.weight.grad.reshape(-1) for l in list(model.grid_mlp.net) + list(model.view_mlp.net)])
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-30))
+    assert rel(eng.table_grad, ref_t) < 5e-3
+    assert rel(eng.w_grad, ref_w) < 5e-3
+
+    # the per-sample term: torch autograd through the same positions, fused MLP and fp32 nn.Linear
+    ar = eng.arena
+    xyzs, dirs = ar.xyzs[:M].clone(), ar.dirs[:M] / ar.dirs[:M].norm(dim=-1, keepdim=True)
+
+    def torch_term():
+        pos = xyzs.clone().requires_grad_(True)
+        sigma = model(pos, dirs, None)["sigma"]
+        n = torch.autograd.grad(sigma, pos, grad_outputs=torch.ones_like(sigma))[0]
+        n = (-torch.nn.functional.normalize(n, dim=-1) + 1) / 2
+        return torch.clamp((n * -dirs).sum(-1), max=0.0) ** 2
+    same = torch_term()
+    assert float(same.mean()) > 1e-3 and float((same > 0).float().mean()) > 0.03
+    assert float((term - same).abs().max()) < 2e-2 and float((term - same).abs().mean()) < 1e-3
+    opt.fused_mlp = False
+    exact = torch_term()
+    opt.fused_mlp = True
+    err = (term - exact).abs()
+    assert float(err.mean()) < 5e-3 and float(err.quantile(0.99)) < 5e-2, (float(err.mean()), float(err.quantile(0.99)))
+
+
 def test_sample_rays_matches_oracle(lib, orc):
     rng = np.random.default_rng(3)
     V, H, W, N = 7, 40, 52, 5000
@@ -329,6 +437,30 @@ def test_graph_replay_matches_eager_steps(lib):
     np.testing.assert_allclose(la[:16], lb[:16], rtol=5e-2)          # ... and that difference grows step by step
     np.testing.assert_allclose(la, lb, rtol=0.1)
     assert abs(sa - sb) <= 0.02 * sb
+
+
+def test_orientation_term_in_the_replayed_step(lib):
+    """The step path with lambda_orientation > 0 (the term's two launches sit between the MLP forward and the compositor
+    step): replayed from graphs vs launched one by one, and it is not the step without the term."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    res = {}
+    for graph, lam in ((True, 1e-2), (False, 1e-2), (True, 0.0)):
+        torch.manual_seed(0)
+        opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True, capture_graph=graph, lambda_orientation=lam)
+        data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
+        eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
+        assert eng.use_graph == graph and eng.orient == (lam > 0)
+        losses = [eng.train_step().clone() for _ in range(40)]
+        torch.cuda.synchronize()
+        res[(graph, lam)] = torch.cat(losses).cpu().numpy()
+    a, b, plain = res[(True, 1e-2)], res[(False, 1e-2)], res[(True, 0.0)]
+    assert np.all(np.isfinite(a)) and a[-1] < a[0]
+    np.testing.assert_allclose(a[:6], b[:6], rtol=2e-3)
+    np.testing.assert_allclose(a, b, rtol=0.1)
+    assert np.max(np.abs(a[:6] - plain[:6]) / plain[:6]) > 1e-3, (a[:6], plain[:6])
 
 
 @pytest.mark.parametrize("full", [False, True], ids=["partial", "full-sweep"])
