@@ -361,6 +361,9 @@ int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const float *dirs
  * (nerf/renderer.py:558-566).  The f16 chain of the backward's density kernel with delta = e_0; no weight gradients. */
 int ngp_x_mlp_density_gradient(const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M, const void *image,
                                float *denc, ngp_stream_t stream);
+/* ... for the light-conditioned field (`image` from ngp_x_mlp_rf_prepare; the density network is the same) */
+int ngp_x_mlp_rf_density_gradient(const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M, const void *image,
+                                  float *denc, ngp_stream_t stream);
 int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
                         float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
                         const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,

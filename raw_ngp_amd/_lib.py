@@ -86,6 +86,7 @@ _SIGNATURES = {
                                     _p, _p, _p, _p, _p],
     "ngp_x_orientation_term": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _p],
     "ngp_x_mlp_density_gradient": [_p, _u, _p, _u, _p, _p],
+    "ngp_x_mlp_rf_density_gradient": [_p, _u, _p, _u, _p, _p],
     "ngp_x_step_window": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_step_window_baa": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_slab_window": [_p, _u, _u, _p, _p, _u, _i],
@@ -690,6 +691,12 @@ class _MlpRfBackend:
         _call("ngp_x_mlp_rf_forward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs", True),
               _ptr(ldirs, "f", "ldirs", True), _ptr(level_w, "f", "level_w", True), _ptr(M_dev, "i", "M_dev", True), M,
               image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb", True))
+
+    @staticmethod
+    def density_gradient(enc, stride, M_dev, M, image, denc):
+        """As mlp_backend.density_gradient, for this field's operand image (the density network is the same)."""
+        _call("ngp_x_mlp_rf_density_gradient", enc, _ptr(enc, "f", "enc"), stride, _ptr(M_dev, "i", "M_dev", True), M,
+              image.data_ptr(), _ptr(denc, "f", "denc"))
 
     @staticmethod
     def backward_workspace_bytes(M):

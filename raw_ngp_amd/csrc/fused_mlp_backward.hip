@@ -834,17 +834,25 @@ extern "C" int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const 
 // d h0 / d enc for every sample, h0 = the density network's first output (sigma = trunc_exp(h0), network.py:111-118): what
 // torch.autograd.grad(sigma, pos) of the orientation term (renderer.py:558-566) needs from the MLP, up to the factor
 // d sigma / d h0 the caller knows from sigma itself.  Same f16 chain as the backward's density kernel, delta3 = e_0.
+namespace ngp {
+int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M,
+                                const void *image, uint32_t t3_base, float *denc, hipStream_t st)
+{
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(enc && image && denc, "%s: null tensor", who);
+    NGP_REQUIRE(stride >= M, "%s: encoder slab stride smaller than M", who);
+    NGP_REQUIRE(mlp_backward_lds_ok(), "%s: cannot raise the dynamic LDS limit", who);
+    mlp_backward_grid_kernel<false, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, st>>>(
+        enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, nullptr, t3_base, nullptr);
+    NGP_CHECK_LAUNCH(who);
+    return NGP_OK;
+}
+}  // namespace ngp
+
 extern "C" int ngp_x_mlp_density_gradient(const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M,
                                           const void *image, float *denc, ngp_stream_t stream)
 {
-    if (M == 0) return NGP_OK;
-    NGP_REQUIRE(enc && image && denc, "mlp_density_gradient: null tensor");
-    NGP_REQUIRE(stride >= M, "mlp_density_gradient: encoder slab stride smaller than M");
-    NGP_REQUIRE(mlp_backward_lds_ok(), "mlp_density_gradient: cannot raise the dynamic LDS limit");
-    mlp_backward_grid_kernel<false, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, as_stream(stream)>>>(
-        enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, nullptr, T_W3, nullptr);
-    NGP_CHECK_LAUNCH("mlp_density_gradient");
-    return NGP_OK;
+    return launch_mlp_density_gradient("mlp_density_gradient", enc, stride, M_dev, M, image, T_W3, denc, as_stream(stream));
 }
 
 // second half of ngp_x_mlp_backward when it was called without weight-gradient tensors: sum the per-workgroup

@@ -88,8 +88,9 @@ class FusedTrainer:
         # needs no code: only the renderer WITHOUT the density grid returns a distort_loss, renderer.py:504-505 -- on this
         # path the reference's train_step never sees one, train_utils.py:550.)
         self.orient = float(getattr(opt, "lambda_orientation", 0.0)) > 0
-        assert not (self.orient and (self.rfield or self.pose)), \
-            "fused step: the orientation term with the light-conditioned field / pose refinement -- use nerf.trainer.Trainer"
+        # (with pose refinement the term also reaches the cameras through the view directions, and the level window's
+        # adjoint enters d sigma / d xyz: not built)
+        assert not (self.orient and self.pose), "fused step: the orientation term with pose refinement -- use nerf.trainer.Trainer"
         assert not getattr(opt, "fp16", False) or opt.loss_scale > 0, "fused step: --fp16 maps to the static loss scale"
         self.opt, self.model, self.data, self.device = opt, model.to(device), dataset, torch.device(device)
         opt.fused_mlp = True

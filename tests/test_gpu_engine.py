@@ -439,6 +439,48 @@ def test_graph_replay_matches_eager_steps(lib):
     assert abs(sa - sb) <= 0.02 * sb
 
 
+@pytest.mark.parametrize("rfield", [False, True], ids=["plain", "light-conditioned"])
+def test_orientation_term_of_a_train_step_matches_autograd(lib, rfield):
+    """The per-sample term a train_step leaves behind (graphs, march ahead on the side stream) against torch autograd through
+    the model at the same samples -- learning rate 0, so the weights are the ones the step saw; both fields."""
+    from raw_ngp_amd.nerf import pose as P
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True, lambda_orientation=1e-2, rfield=rfield, lr=0.0)
+    data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
+    if rfield:
+        data.ldirs = torch.from_numpy(P.synthetic_light_dirs(6)).cuda()
+    model = NeRFNetwork(opt).cuda()
+    with torch.no_grad():
+        model.grid_encoder.embeddings.uniform_(-0.5, 0.5)
+    eng = FusedTrainer(opt, model, data, device="cuda", capacity=1024 * 256)
+    table0 = eng.table.clone()
+    for _ in range(5):
+        eng.train_step()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.table, table0)
+    slot = eng.slots[(eng.global_step - 1) % len(eng.slots)]
+    M = int(slot.arena.counter[0])
+    assert 0 < M <= eng.cap
+    term = eng.orient_term[:M].clone()
+    xyzs = slot.arena.xyzs[:M].clone()
+    dirs = slot.arena.dirs[:M] / slot.arena.dirs[:M].norm(dim=-1, keepdim=True)
+    ldirs = slot.arena.ldirs[:M].clone() if rfield else None
+    model.train()
+    pos = xyzs.clone().requires_grad_(True)
+    sigma = model(pos, dirs, ldirs)["sigma"]
+    n = torch.autograd.grad(sigma, pos, grad_outputs=torch.ones_like(sigma))[0]
+    n = (-torch.nn.functional.normalize(n, dim=-1) + 1) / 2
+    want = torch.clamp((n * -dirs).sum(-1), max=0.0) ** 2
+    assert float((want > 0).float().mean()) > 0.03
+    err = (term - want).abs()
+    # (a nearly flat density leaves the direction of its gradient to the f16 rounding of either chain: a few samples may differ)
+    assert float((err > 2e-2).float().mean()) < 1e-3 and float(err.mean()) < 1e-3, (float(err.max()), float(err.mean()))
+
+
 def test_orientation_term_in_the_replayed_step(lib):
     """The step path with lambda_orientation > 0 (the term's two launches sit between the MLP forward and the compositor
     step): replayed from graphs vs launched one by one, and it is not the step without the term."""
