@@ -361,9 +361,11 @@ int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const float *dirs
  * (nerf/renderer.py:558-566).  The f16 chain of the backward's density kernel with delta = e_0; no weight gradients. */
 int ngp_x_mlp_density_gradient(const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M, const void *image,
                                float *denc, ngp_stream_t stream);
-/* ... for the light-conditioned field (`image` from ngp_x_mlp_rf_prepare; the density network is the same) */
-int ngp_x_mlp_rf_density_gradient(const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M, const void *image,
-                                  float *denc, ngp_stream_t stream);
+/* ... for the light-conditioned field (`image` from ngp_x_mlp_rf_prepare; the density network is the same); level_w
+ * (optional, [16]): the level window its kernels apply to the features (as ngp_x_mlp_rf_forward) -- d enc is then the
+ * gradient with respect to the un-windowed features */
+int ngp_x_mlp_rf_density_gradient(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
+                                  const void *image, float *denc, ngp_stream_t stream);
 int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5,
                         float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
                         const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,
@@ -581,14 +583,18 @@ int ngp_x_composite_train_terms(const float *gt_rgba, const float *bg_rgb, float
                                 const float *ts, const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
                                 float *weights_sum, float *depth, float *image, float *grad_sigmas, float *grad_rgbs,
                                 float *loss_out, int32_t *live_n, int32_t *live_idx, int32_t *live_count, int32_t *live_off,
-                                ngp_stream_t stream);
+                                float *term_weight, ngp_stream_t stream);
+/* term_weight (optional, [M]) <- lambda_sample * weights[i]: what a consumer of the term's other inputs multiplies its own
+ * derivative with (pose refinement: the orientation term also depends on the view direction, ngp_x_ray_gradients_terms) */
 /* The per-sample factor of the orientation term (nerf/renderer.py:558-571): g = d sigma / d xyz = clamp(sigma, e^-80, e^80)
  * (trunc_exp's backward, activation.py:20) * sum_l dh_denc_l . dydx_l / (2 bound) from the level-major slabs of
  * ngp_x_mlp_density_gradient and ngp_x_grid_encode_forward_slab_jac; normal = (-g / max(|g|, 1e-12) + 1) / 2;
  * term[i] = min(0, sum_d normal_d * -(dirs / |dirs|)_d)^2.  One thread per sample, samples 0 .. min(*M_dev, M) - 1. */
 int ngp_x_orientation_term(const float *dh_denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
                            const float *sigmas, const float *dirs, const int32_t *M_dev, uint32_t M, float *term,
-                           ngp_stream_t stream);
+                           float *dterm_ddirs, ngp_stream_t stream);
+/* dterm_ddirs (optional, [M,3]) <- d term[i] / d dirs[i] (un-normalised direction; the normal is a constant, as in the
+ * reference, whose autograd.grad runs without create_graph) */
 
 /* ---- pose refinement around the fused step (csrc/pose_kernels.hip) -----------------------------------------------
  * ngp_x_step_window   annealing = float16((step_counter[0] + step_offset) / iters) (train_utils.py:488) -> the BARF level
@@ -618,6 +624,12 @@ int ngp_x_slab_window(float *slab, uint32_t stride, uint32_t L, const float *lev
 int ngp_x_ray_gradients(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound, const float *ddirs,
                         const float *ts, const int32_t *rays, uint32_t N, uint32_t M, float *grad_rays_o,
                         float *grad_rays_d, ngp_stream_t stream);
+/* ... plus, per sample, term_weight[i] * dterm_ddirs[i] added to the direction gradient (both NULL: none) -- the orientation
+ * term's path to the cameras through the view direction; live_n / live_off as ngp_x_ray_gradients_list or both NULL */
+int ngp_x_ray_gradients_terms(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
+                              const float *ddirs, const float *ts, const int32_t *rays, const int32_t *live_n,
+                              const int32_t *live_off, const float *term_weight, const float *dterm_ddirs, uint32_t N,
+                              uint32_t M, float *grad_rays_o, float *grad_rays_d, ngp_stream_t stream);
 /* ... when the backward ran over the list of live samples: denc in list order -- ray n's entries start at live_off[n], the
  * first live_n[n] samples of the ray have gradients (dydx, ts, ddirs stay in sample order) */
 int ngp_x_ray_gradients_list(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound,

@@ -83,10 +83,11 @@ _SIGNATURES = {
     "ngp_x_composite_train_live_idx": [_p, _p, _f, _p, _p, _f, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p,
                                        _p, _p, _p, _p],
     "ngp_x_composite_train_terms": [_p, _p, _f, _p, _p, _f, _p, _f, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p,
-                                    _p, _p, _p, _p, _p],
-    "ngp_x_orientation_term": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _p],
+                                    _p, _p, _p, _p, _p, _p],
+    "ngp_x_orientation_term": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _p, _p],
+    "ngp_x_ray_gradients_terms": [_p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_mlp_density_gradient": [_p, _u, _p, _u, _p, _p],
-    "ngp_x_mlp_rf_density_gradient": [_p, _u, _p, _u, _p, _p],
+    "ngp_x_mlp_rf_density_gradient": [_p, _u, _p, _p, _u, _p, _p],
     "ngp_x_step_window": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_step_window_baa": [_p, _u, _d, _f, _f, _u, _p, _p],
     "ngp_x_slab_window": [_p, _u, _u, _p, _p, _u, _i],
@@ -693,10 +694,11 @@ class _MlpRfBackend:
               image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb", True))
 
     @staticmethod
-    def density_gradient(enc, stride, M_dev, M, image, denc):
-        """As mlp_backend.density_gradient, for this field's operand image (the density network is the same)."""
-        _call("ngp_x_mlp_rf_density_gradient", enc, _ptr(enc, "f", "enc"), stride, _ptr(M_dev, "i", "M_dev", True), M,
-              image.data_ptr(), _ptr(denc, "f", "denc"))
+    def density_gradient(enc, stride, M_dev, M, image, denc, level_w=None):
+        """As mlp_backend.density_gradient, for this field's operand image (the density network is the same); level_w: the
+        level window the field's kernels apply."""
+        _call("ngp_x_mlp_rf_density_gradient", enc, _ptr(enc, "f", "enc"), stride, _ptr(level_w, "f", "level_w", True),
+              _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), _ptr(denc, "f", "denc"))
 
     @staticmethod
     def backward_workspace_bytes(M):
@@ -806,12 +808,13 @@ class _EngineBackend:
     @staticmethod
     def composite_train_live(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, n_live, sigmas, rgbs, ts, rays, M, N,
                              T_thresh, weights_sum, depth, image, grad_sigmas, grad_rgbs, loss_out, lambda_entropy=0.0,
-                             live=None, sample_term=None, lambda_sample=0.0):
+                             live=None, sample_term=None, lambda_sample=0.0, term_weight=None):
         """composite_mse_train (exposure None) / composite_hdr_train over the first n_live[0] ray slots (None: all), plus
         lambda_entropy * mean entropy of the rays' accumulated opacity (train_utils.py:554-557).
         live = (live_n [N], live_idx [M], live_count [1], live_off [N] or None) int32: also list the samples in front of the
         early stop (and where each ray's entries start).
-        sample_term [M]: loss += lambda_sample * sum_i weights[i] * sample_term[i] (the orientation term)."""
+        sample_term [M]: loss += lambda_sample * sum_i weights[i] * sample_term[i] (the orientation term); term_weight [M]
+        (optional) <- lambda_sample * weights."""
         if sample_term is not None:
             lv = live if live is not None else (None, None, None, None)
             _call("ngp_x_composite_train_terms", rays, _ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
@@ -822,7 +825,8 @@ class _EngineBackend:
                   _ptr(depth, "f", "depth"), _ptr(image, "f", "image"), _ptr(grad_sigmas, "f", "grad_sigmas"),
                   _ptr(grad_rgbs, "f", "grad_rgbs"), _ptr(loss_out, "f", "loss_out"), _ptr(lv[0], "i", "live_n", True),
                   _ptr(lv[1], "i", "live_idx", True), _ptr(lv[2], "i", "live_count", True),
-                  _ptr(lv[3], "i", "live_off", True), probe_as="ngp_x_composite_train_live")
+                  _ptr(lv[3], "i", "live_off", True), _ptr(term_weight, "f", "term_weight", True),
+                  probe_as="ngp_x_composite_train_live")
             return
         args = [_ptr(gt_rgba, "f", "gt_rgba"), _ptr(bg_rgb, "f", "bg_rgb", True),
                 float(bg_const), _ptr(exposure, "f", "exposure", True), _ptr(weight, "f", "weight", True), float(inv_norm),
@@ -852,15 +856,26 @@ class _EngineBackend:
               _ptr(M_dev, "i", "M_dev", True), int(M), 2 if scale_only else int(bool(backward)))
 
     @staticmethod
-    def orientation_term(dh_denc, dydx, stride, L, bound, sigmas, dirs, M_dev, M, term):
+    def orientation_term(dh_denc, dydx, stride, L, bound, sigmas, dirs, M_dev, M, term, dterm_ddirs=None):
         """term [M] <- min(0, n . -v)^2 per sample with n = (-normalize(d sigma / d xyz) + 1) / 2 (nerf/renderer.py:558-571);
-        dh_denc: mlp_backend.density_gradient's slab, dydx: the Jacobian slab of grid_encode_forward_slab."""
+        dh_denc: mlp_backend.density_gradient's slab, dydx: the Jacobian slab of grid_encode_forward_slab.
+        dterm_ddirs [M,3] (optional) <- d term / d dirs."""
         _call("ngp_x_orientation_term", term, _ptr(dh_denc, "f", "dh_denc"), _ptr(dydx, "f", "dydx"), stride, L, float(bound),
-              _ptr(sigmas, "f", "sigmas"), _ptr(dirs, "f", "dirs"), _ptr(M_dev, "i", "M_dev", True), M, _ptr(term, "f", "term"))
+              _ptr(sigmas, "f", "sigmas"), _ptr(dirs, "f", "dirs"), _ptr(M_dev, "i", "M_dev", True), M, _ptr(term, "f", "term"),
+              _ptr(dterm_ddirs, "f", "dterm_ddirs", True))
 
     @staticmethod
-    def ray_gradients(denc, dydx, stride, L, bound, ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d, live=None):
-        """live = (live_n, live_off): the backward ran over the list of live samples -- denc in list order."""
+    def ray_gradients(denc, dydx, stride, L, bound, ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d, live=None, terms=None):
+        """live = (live_n, live_off): the backward ran over the list of live samples -- denc in list order.
+        terms = (term_weight [M], dterm_ddirs [M,3]): per sample their product joins the direction gradient."""
+        if terms is not None:
+            lv = live if live is not None else (None, None)
+            _call("ngp_x_ray_gradients_terms", rays, _ptr(denc, "f", "denc"), _ptr(dydx, "f", "dydx"), stride, L, float(bound),
+                  _ptr(ddirs, "f", "ddirs", True), _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), _ptr(lv[0], "i", "live_n", True),
+                  _ptr(lv[1], "i", "live_off", True), _ptr(terms[0], "f", "term_weight"), _ptr(terms[1], "f", "dterm_ddirs"),
+                  N, M, _ptr(grad_rays_o, "f", "grad_rays_o"), _ptr(grad_rays_d, "f", "grad_rays_d"),
+                  probe_as="ngp_x_ray_gradients")
+            return
         if live is not None:
             _call("ngp_x_ray_gradients_list", rays, _ptr(denc, "f", "denc"), _ptr(dydx, "f", "dydx"), stride, L, float(bound),
                   _ptr(ddirs, "f", "ddirs", True), _ptr(ts, "f", "ts"), _ptr(rays, "i", "rays"), _ptr(live[0], "i", "live_n"),

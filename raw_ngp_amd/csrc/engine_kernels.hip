@@ -281,6 +281,8 @@ struct HdrLoss {
     // sample itself
     const float *sample_term = nullptr;
     float lambda_sample = 0.0f;
+    float *term_weight_out = nullptr;   // optional [M]: lambda_sample * weights[i] (0 behind the early stop), for consumers of
+                                        // the term's other inputs (ngp_x_ray_gradients_terms: the view direction)
 };
 
 template <int MODE>
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
             if (have) {
                 grad_sigmas[i] = 0.0f;
                 grad_rgbs[(size_t)i * 3] = grad_rgbs[(size_t)i * 3 + 1] = grad_rgbs[(size_t)i * 3 + 2] = 0.0f;
+                if (MODE == 2 && hdr.term_weight_out) hdr.term_weight_out[i] = 0.0f;
             }
             continue;
         }
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(kCompBwdBlock) void composite_backward_wave_kernel(
                 s *= dt;
             }
             grad_sigmas[i] = s;
+            if (MODE == 2 && hdr.term_weight_out) hdr.term_weight_out[i] = hdr.lambda_sample * w;
             grad_rgbs[(size_t)i * 3] = q0;
             grad_rgbs[(size_t)i * 3 + 1] = q1;
             grad_rgbs[(size_t)i * 3 + 2] = q2;
@@ -950,7 +954,7 @@ extern "C" int ngp_x_composite_train_live_idx(const float *gt_rgba, const float 
 {
     return ngp_x_composite_train_terms(gt_rgba, bg_rgb, bg_const, exposure, weight, inv_norm, n_live, lambda_entropy, nullptr,
                                        0.0f, sigmas, rgbs, ts, rays, M, N, T_thresh, weights_sum, depth, image, grad_sigmas,
-                                       grad_rgbs, loss_out, live_n, live_idx, live_count, live_off, stream);
+                                       grad_rgbs, loss_out, live_n, live_idx, live_count, live_off, nullptr, stream);
 }
 
 // ... plus a term over the samples' compositing weights: loss += lambda_sample * sum_i weights[i] * sample_term[i]
@@ -961,7 +965,8 @@ extern "C" int ngp_x_composite_train_terms(const float *gt_rgba, const float *bg
                                            const float *rgbs, const float *ts, const int32_t *rays, uint32_t M, uint32_t N,
                                            float T_thresh, float *weights_sum, float *depth, float *image,
                                            float *grad_sigmas, float *grad_rgbs, float *loss_out, int32_t *live_n,
-                                           int32_t *live_idx, int32_t *live_count, int32_t *live_off, ngp_stream_t stream)
+                                           int32_t *live_idx, int32_t *live_count, int32_t *live_off, float *term_weight,
+                                           ngp_stream_t stream)
 {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(gt_rgba && rays && weights_sum && depth && image && loss_out, "composite_train_live: null tensor");
@@ -978,8 +983,10 @@ extern "C" int ngp_x_composite_train_terms(const float *gt_rgba, const float *bg
     hdr.lambda_entropy = lambda_entropy;
     NGP_REQUIRE(sample_term ? lambda_sample >= 0.0f : lambda_sample == 0.0f,
                 "composite_train_terms: lambda_sample needs sample_term and must not be negative");
+    NGP_REQUIRE(!term_weight || sample_term, "composite_train_terms: term_weight needs sample_term");
     hdr.sample_term = sample_term;
     hdr.lambda_sample = lambda_sample;
+    hdr.term_weight_out = term_weight;
     const bool listing = live_n != nullptr;
     NGP_REQUIRE(listing ? (live_idx && live_count && M > 0) : (!live_idx && !live_count && !live_off),
                 "composite_train_live: live_n, live_idx and live_count go together");

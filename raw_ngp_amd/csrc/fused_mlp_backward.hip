@@ -699,6 +699,8 @@ static bool mlp_backward_lds_ok()
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
         r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<false, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
+        r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
         return r;
     }();
     return ok;
@@ -835,15 +837,21 @@ extern "C" int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const 
 // torch.autograd.grad(sigma, pos) of the orientation term (renderer.py:558-566) needs from the MLP, up to the factor
 // d sigma / d h0 the caller knows from sigma itself.  Same f16 chain as the backward's density kernel, delta3 = e_0.
 namespace ngp {
-int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M,
-                                const void *image, uint32_t t3_base, float *denc, hipStream_t st)
+int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev,
+                                uint32_t M, const void *image, uint32_t t3_base, float *denc, hipStream_t st)
 {
     if (M == 0) return NGP_OK;
     NGP_REQUIRE(enc && image && denc, "%s: null tensor", who);
     NGP_REQUIRE(stride >= M, "%s: encoder slab stride smaller than M", who);
     NGP_REQUIRE(mlp_backward_lds_ok(), "%s: cannot raise the dynamic LDS limit", who);
-    mlp_backward_grid_kernel<false, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, st>>>(
-        enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, nullptr, t3_base, nullptr);
+    if (level_w)    // the window scales the features in front of the network and, as its adjoint, d enc behind it
+        mlp_backward_grid_kernel<true, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, st>>>(
+            enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, level_w, t3_base,
+            nullptr);
+    else
+        mlp_backward_grid_kernel<false, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, st>>>(
+            enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, nullptr, t3_base,
+            nullptr);
     NGP_CHECK_LAUNCH(who);
     return NGP_OK;
 }
@@ -852,7 +860,8 @@ int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stri
 extern "C" int ngp_x_mlp_density_gradient(const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M,
                                           const void *image, float *denc, ngp_stream_t stream)
 {
-    return launch_mlp_density_gradient("mlp_density_gradient", enc, stride, M_dev, M, image, T_W3, denc, as_stream(stream));
+    return launch_mlp_density_gradient("mlp_density_gradient", enc, stride, nullptr, M_dev, M, image, T_W3, denc,
+                                       as_stream(stream));
 }
 
 // second half of ngp_x_mlp_backward when it was called without weight-gradient tensors: sum the per-workgroup

@@ -683,8 +683,9 @@ extern "C" int ngp_x_mlp_rf_backward_list(const float *enc, uint32_t stride, con
 
 // ngp_x_mlp_density_gradient for the light-conditioned field's operand image (the density network is the same, its
 // transposed fragments sit at RF_T3)
-extern "C" int ngp_x_mlp_rf_density_gradient(const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M,
-                                             const void *image, float *denc, ngp_stream_t stream)
+extern "C" int ngp_x_mlp_rf_density_gradient(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev,
+                                             uint32_t M, const void *image, float *denc, ngp_stream_t stream)
 {
-    return launch_mlp_density_gradient("mlp_rf_density_gradient", enc, stride, M_dev, M, image, RF_T3, denc, as_stream(stream));
+    return launch_mlp_density_gradient("mlp_rf_density_gradient", enc, stride, level_w, M_dev, M, image, RF_T3, denc,
+                                       as_stream(stream));
 }

@@ -216,8 +216,8 @@ int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *lev
                              const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
                              float *partial, uint32_t blocks, hipStream_t st, const int32_t *sample_index = nullptr);
 // ... with a unit delta on the first output and no weight gradients: denc <- d h0 / d enc (ngp_x_mlp_density_gradient)
-int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stride, const int32_t *M_dev, uint32_t M,
-                                const void *image, uint32_t t3_base, float *denc, hipStream_t st);
+int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev,
+                                uint32_t M, const void *image, uint32_t t3_base, float *denc, hipStream_t st);
 
 
 // ---- weight-gradient reduction over the backward kernels' partial slabs ----------------------------------------------

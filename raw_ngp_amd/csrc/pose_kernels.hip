@@ -116,7 +116,9 @@ __global__ __launch_bounds__(256) void ray_gradients_kernel(const float *__restr
                                                             const int32_t *__restrict__ rays, uint32_t N, uint32_t M,
                                                             float *__restrict__ grad_rays_o, float *__restrict__ grad_rays_d,
                                                             const int32_t *__restrict__ live_n,
-                                                            const int32_t *__restrict__ live_off)
+                                                            const int32_t *__restrict__ live_off,
+                                                            const float *__restrict__ term_weight = nullptr,
+                                                            const float *__restrict__ dterm_ddirs = nullptr)
 {
     const uint32_t n = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (n >= N) return;
@@ -142,11 +144,14 @@ __global__ __launch_bounds__(256) void ray_gradients_kernel(const float *__restr
                 }
             }
             const float t = ts[i * 2];      // the reference multiplies by ts[:, 0] (raymarching.py:297,328)
+            // a loss term over the samples' weights that depends on the view direction (the orientation term):
+            // term_weight[i] = lambda * weights[i] from the compositor step, dterm_ddirs from ngp_x_orientation_term
+            const float tw = term_weight ? term_weight[i] : 0.0f;
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 const float gx = g[d] * inv_2bound;
                 so[d] += gx;
-                sd[d] += gx * t + (ddirs ? ddirs[i * 3 + d] : 0.0f);
+                sd[d] += gx * t + (ddirs ? ddirs[i * 3 + d] : 0.0f) + (term_weight ? tw * dterm_ddirs[i * 3 + d] : 0.0f);
             }
         }
     }
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) void orientation_term_kernel(const float *__re
                                                                uint32_t stride, uint32_t L, float inv_2bound,
                                                                const float *__restrict__ sigmas, const float *__restrict__ dirs,
                                                                const int32_t *__restrict__ M_dev, uint32_t M_cap,
-                                                               float *__restrict__ term)
+                                                               float *__restrict__ term, float *__restrict__ dterm_ddirs)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_cap) : M_cap;
@@ -198,8 +203,16 @@ __global__ __launch_bounds__(256) void orientation_term_kernel(const float *__re
     const float d0 = dirs[(size_t)i * 3], d1 = dirs[(size_t)i * 3 + 1], d2 = dirs[(size_t)i * 3 + 2];
     const float dn = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
     const float n0 = (-(v0 * inv) + 1.0f) * 0.5f, n1 = (-(v1 * inv) + 1.0f) * 0.5f, n2 = (-(v2 * inv) + 1.0f) * 0.5f;
-    const float ndv = fminf(n0 * -(d0 * dn) + n1 * -(d1 * dn) + n2 * -(d2 * dn), 0.0f);
+    const float u0 = d0 * dn, u1 = d1 * dn, u2 = d2 * dn;
+    const float ndv = fminf(n0 * -u0 + n1 * -u1 + n2 * -u2, 0.0f);
     term[i] = ndv * ndv;
+    if (dterm_ddirs) {   // the normals are constants; through u = d / |d|: (g - u (u . g)) / |d| with g = d term / d u
+        const float g0 = -2.0f * ndv * n0, g1 = -2.0f * ndv * n1, g2 = -2.0f * ndv * n2;
+        const float dot = g0 * u0 + g1 * u1 + g2 * u2;
+        dterm_ddirs[(size_t)i * 3] = (g0 - u0 * dot) * dn;
+        dterm_ddirs[(size_t)i * 3 + 1] = (g1 - u1 * dot) * dn;
+        dterm_ddirs[(size_t)i * 3 + 2] = (g2 - u2 * dot) * dn;
+    }
 }
 
 // ------------------------------------------------------------------ d loss / d pose per camera
@@ -477,6 +490,26 @@ extern "C" int ngp_x_ray_gradients(const float *denc, const float *dydx, uint32_
     return NGP_OK;
 }
 
+// ... plus a loss term over the samples' weights that depends on the view direction: sd += term_weight[i] * dterm_ddirs[i]
+// (both by sample; NULL: none; live_n / live_off NULL: denc in sample order)
+extern "C" int ngp_x_ray_gradients_terms(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
+                                         const float *ddirs, const float *ts, const int32_t *rays, const int32_t *live_n,
+                                         const int32_t *live_off, const float *term_weight, const float *dterm_ddirs,
+                                         uint32_t N, uint32_t M, float *grad_rays_o, float *grad_rays_d, ngp_stream_t stream)
+{
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays && grad_rays_o && grad_rays_d, "ray_gradients_terms: null tensor");
+    NGP_REQUIRE(M == 0 || (denc && dydx && ts), "ray_gradients_terms: null sample tensor");
+    NGP_REQUIRE(stride >= M && bound > 0.0f && L >= 1, "ray_gradients_terms: bad stride / bound / L");
+    NGP_REQUIRE(!live_n == !live_off, "ray_gradients_terms: live_n and live_off go together");
+    NGP_REQUIRE(!term_weight == !dterm_ddirs, "ray_gradients_terms: term_weight and dterm_ddirs go together");
+    ray_gradients_kernel<<<dim3(ceil_div(N, 4u)), dim3(256), 0, as_stream(stream)>>>(
+        denc, dydx, stride, L, 1.0f / (2.0f * bound), ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d, live_n, live_off,
+        term_weight, dterm_ddirs);
+    NGP_CHECK_LAUNCH("ray_gradients_terms");
+    return NGP_OK;
+}
+
 // ... when the backward ran over the list of live samples: denc in list order, ray n's entries at live_off[n], live_n[n] of them
 extern "C" int ngp_x_ray_gradients_list(const float *denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
                                         const float *ddirs, const float *ts, const int32_t *rays, const int32_t *live_n,
@@ -495,13 +528,13 @@ extern "C" int ngp_x_ray_gradients_list(const float *denc, const float *dydx, ui
 
 extern "C" int ngp_x_orientation_term(const float *dh_denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
                                       const float *sigmas, const float *dirs, const int32_t *M_dev, uint32_t M, float *term,
-                                      ngp_stream_t stream)
+                                      float *dterm_ddirs, ngp_stream_t stream)
 {
     if (M == 0) return NGP_OK;
     NGP_REQUIRE(dh_denc && dydx && sigmas && dirs && term, "orientation_term: null tensor");
     NGP_REQUIRE(stride >= M && bound > 0.0f && L >= 1, "orientation_term: bad stride / bound / L");
     orientation_term_kernel<<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
-        dh_denc, dydx, stride, L, 1.0f / (2.0f * bound), sigmas, dirs, M_dev, M, term);
+        dh_denc, dydx, stride, L, 1.0f / (2.0f * bound), sigmas, dirs, M_dev, M, term, dterm_ddirs);
     NGP_CHECK_LAUNCH("orientation_term");
     return NGP_OK;
 }

@@ -88,9 +88,8 @@ class FusedTrainer:
         # needs no code: only the renderer WITHOUT the density grid returns a distort_loss, renderer.py:504-505 -- on this
         # path the reference's train_step never sees one, train_utils.py:550.)
         self.orient = float(getattr(opt, "lambda_orientation", 0.0)) > 0
-        # (with pose refinement the term also reaches the cameras through the view directions, and the level window's
-        # adjoint enters d sigma / d xyz: not built)
-        assert not (self.orient and self.pose), "fused step: the orientation term with pose refinement -- use nerf.trainer.Trainer"
+        # (with pose refinement the term also reaches the cameras through the view directions -- ray_gradients takes that
+        # part -- and the level window's adjoint enters d sigma / d xyz)
         assert not getattr(opt, "fp16", False) or opt.loss_scale > 0, "fused step: --fp16 maps to the static loss scale"
         self.opt, self.model, self.data, self.device = opt, model.to(device), dataset, torch.device(device)
         opt.fused_mlp = True
@@ -295,6 +294,8 @@ class FusedTrainer:
             self.dydx = torch.empty(self.L, cap, 3, 2, **f32)
         if self.orient:
             self.orient_term = torch.zeros(cap, **f32)
+            if self.pose:       # d term / d dirs per sample, and lambda * weights from the compositor step
+                self.orient_ddirs, self.orient_weight = torch.zeros(cap, 3, **f32), torch.zeros(cap, **f32)
         self.enc = torch.empty(self.L, cap, 2, **f32)
         self.denc = torch.empty(self.L, cap, 2, **f32)
         self.x01 = torch.empty(cap, 3, **f32)
@@ -416,7 +417,8 @@ class FusedTrainer:
                                         slot.live if self.adaptive else None, self.sigma, self.rgb, ar.ts, ar.rays, cap, N,
                                         opt.T_thresh, self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
                                         lambda_entropy=lam, live=live, sample_term=self.orient_term,
-                                        lambda_sample=float(opt.lambda_orientation))
+                                        lambda_sample=float(opt.lambda_orientation),
+                                        term_weight=self.orient_weight if self.pose else None)
                 if self.adaptive:
                     self.rays_seen.add_(slot.live)
                 return
@@ -458,8 +460,16 @@ class FusedTrainer:
         back_n, back_idx = (self.live_count, self.live_idx) if live_list else (cnt, None)
 
         def orientation_term():     # min(0, n . -v)^2 per sample; d enc is free until the backward writes it
-            self.mb.density_gradient(self.enc, cap, cnt, cap, self.mlp_image, self.denc)
-            eb.orientation_term(self.denc, self.dydx, cap, self.L, m.bound, self.sigma, ar.dirs, cnt, cap, self.orient_term)
+            if self.rfield:         # (its kernels apply BARF's window themselves; BAA-NGP's blend is on the slab already)
+                self.mb.density_gradient(self.enc, cap, cnt, cap, self.mlp_image, self.denc,
+                                         level_w=self.level_w if self.pose and not self.baa else None)
+            else:
+                self.mb.density_gradient(self.enc, cap, cnt, cap, self.mlp_image, self.denc)
+            if self.pose and (self.baa or not self.rfield):     # the window's adjoint: d enc' -> d enc, as in the backward
+                eb.slab_window(self.denc, cap, self.L, self.level_w, cnt, cap, backward=True,
+                               scale_only=not self.baa and not self.rfield)
+            eb.orientation_term(self.denc, self.dydx, cap, self.L, m.bound, self.sigma, ar.dirs, cnt, cap, self.orient_term,
+                                dterm_ddirs=self.orient_ddirs if self.pose else None)
 
         def mlp_backward():
             if self.rfield:         # one call: both view kernels, the density kernel, the weight-gradient reduction
@@ -770,7 +780,8 @@ class FusedTrainer:
                 ("ngp_x_ray_gradients", lambda: eb.ray_gradients(
                     self.denc, self.dydx, self.cap, self.L, self.model.bound, self.ddirs, ar.ts, ar.rays, self.N, self.cap,
                     self.g_rays_o, self.g_rays_d,
-                    live=(self.live_n, self.live_off) if self._lists_live_samples() else None)),
+                    live=(self.live_n, self.live_off) if self._lists_live_samples() else None,
+                    terms=(self.orient_weight, self.orient_ddirs) if self.orient else None)),
                 ("ngp_x_pose_gradient", lambda: eb.pose_gradient(slot.index, self.g_rays_o, self.g_rays_d, self.N, len(d),
                                                                  d.W, d.intrinsics, self.grad_pose)),
                 ("ngp_x_pose_update", lambda: eb.pose_update(self.xi, self.pose_base, self.grad_pose, self.flags, self.pose_m,

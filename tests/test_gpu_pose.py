@@ -111,13 +111,16 @@ def _fused_setup(pose_opt, iters, views=24, noise=0.03, rays=2048, image_mode="L
     return P, data, FusedTrainer(opt, NeRFNetwork(opt), data, device=dev, seed=seed, capacity=rays * 200)
 
 
+@pytest.mark.parametrize("orient", [0.0, 3e-2], ids=["", "orientation-term"])
 @pytest.mark.parametrize("pose_opt,rfield", [("barf", True), ("baangp", True), ("barf", False), ("baangp", False)])
-def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield):
+def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield, orient):
     """One batch through the fused light-conditioned + BARF (or BAA-NGP) step and through the per-op autograd path (torch
     MLPs in fp32, the reference's call sequence over the `_backend` shims) with the same weights, rays and sample jitter: the
-    se(3) gradient, the MLP weight gradients and the loss must agree to what f16 MFMA operands allow."""
+    se(3) gradient, the MLP weight gradients and the loss must agree to what f16 MFMA operands allow.
+    orientation-term: with lambda_orientation > 0 (renderer.py:558-571) -- the term reaches the cameras through the weights
+    and through the view directions; its normals are constants."""
     from raw_ngp_amd.nerf import pose as Pm
-    P, data, ft = _fused_setup(pose_opt, iters=300, views=6, noise=0.05, rays=1024, rfield=rfield)
+    P, data, ft = _fused_setup(pose_opt, iters=300, views=6, noise=0.05, rays=1024, rfield=rfield, lambda_orientation=orient)
     model, opt = ft.model, ft.opt
     for _ in range(40):                                  # a few steps so that the field is not flat any more
         ft.train_step()
@@ -153,6 +156,9 @@ def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield):
     ro, rd = Pn[:, :, 3], (dirs_cam[:, None, :] * Pn[:, :, :3]).sum(-1)
     np.testing.assert_allclose(ro.detach().cpu().numpy(), rays_o.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rd.detach().cpu().numpy(), rays_d.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # the fused step's own rays, bit for bit (a last-bit difference can move a sample across a cell wall and change the
+    # count), with the derivative of the torch expression
+    ro, rd = rays_o + (ro - ro.detach()), rays_d + (rd - rd.detach())
     model.train()
     opt.fused_mlp = False                                 # torch MLPs, autograd ops
     model.update_annealing(np.clip((step + 1) / opt.iters, 0, 1).astype(np.float16))      # train_utils.py:887-888, :488
@@ -170,9 +176,19 @@ def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield):
     xyzs, dirs, ts, ldirs = xyzs[:M], dirs[:M], ts[:M], (ldirs[:M] if rfield else None)
     dirs = dirs / dirs.norm(dim=-1, keepdim=True)
     out = model(xyzs, dirs, ldirs)
-    _, ws, _, image = raymarching.composite_rays_train(out["sigma"], out["color"], ts, rays, opt.T_thresh)
+    weights, ws, _, image = raymarching.composite_rays_train(out["sigma"], out["color"], ts, rays, opt.T_thresh)
     gt_rgb = gt[:, :3] * gt[:, 3:]                       # black background
     loss = ((image + (1 - ws[:, None]) * 0.0 - gt_rgb) ** 2).mean()
+    if orient:                                           # renderer.py:558-571, train_utils.py:546-548
+        mse = float(loss.detach())
+        pos = xyzs.clone().requires_grad_(True)
+        nrm = torch.autograd.grad(model(pos, dirs, ldirs)["sigma"], pos, grad_outputs=torch.ones_like(out["sigma"]),
+                                  retain_graph=True)[0]
+        nrm = (-torch.nn.functional.normalize(nrm, dim=-1) + 1) / 2
+        n_dot_v = (nrm * -dirs).sum(dim=-1)
+        term = torch.mean((weights * torch.clamp(n_dot_v, max=0.0) ** 2).sum(dim=-1))
+        loss = loss + orient * term
+        assert float(term.detach()) > 0, mse
     params = [l.weight for l in model.grid_mlp.net] + [l.weight for l in model.view_mlp.net]
     grads = torch.autograd.grad(loss, [xi] + params)
     np.testing.assert_allclose(loss_fused, float(loss), rtol=2e-2)

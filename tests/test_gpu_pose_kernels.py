@@ -135,6 +135,53 @@ def test_slab_jacobian_and_ray_gradients_match_oracle(lib, orc):
     np.testing.assert_allclose(host(gd), ref_d2, rtol=1e-4, atol=1e-5 * scale_d)
 
 
+def test_orientation_term_and_its_direction_gradient_match_autograd(lib, orc):
+    """ngp_x_orientation_term on random slabs against the expression of renderer.py:558-571 in torch (float64): the term,
+    d term / d dirs with the normal held constant, the tiny-gradient case of F.normalize, and the term's path to the ray
+    directions in ngp_x_ray_gradients_terms (term_weight[i] * dterm_ddirs[i] joins d dirs)."""
+    rng = np.random.default_rng(5)
+    e = lib.engine_backend
+    N, L, bound = 300, 16, 2.0
+    sig, rgb, ts, rays, M = synth_samples(rng, N, max_cnt=60)
+    cap = M + 7
+    dh = rng.normal(size=(L, cap, 2)).astype(np.float32)
+    jac = rng.normal(size=(L, cap, 3, 2)).astype(np.float32)
+    dirs = (rng.normal(size=(cap, 3)) * rng.uniform(0.5, 2.0, (cap, 1))).astype(np.float32)      # un-normalised
+    sigma = np.exp(rng.uniform(-20, 5, cap)).astype(np.float32)
+    dh[:, 5] = 0.0                                           # a flat density: normalize(0) = 0, the normal is (.5, .5, .5)
+    sigma[6] = 1e-30                                         # |d sigma / d xyz| below normalize's eps
+    cnt = torch.tensor([M, 0], dtype=torch.int32, device="cuda")
+    term, dterm = torch.full((cap,), 7.0, device="cuda"), torch.full((cap, 3), 7.0, device="cuda")
+    e.orientation_term(dev(dh), dev(jac), cap, L, bound, dev(sigma), dev(dirs), cnt, cap, term, dterm_ddirs=dterm)
+    assert torch.all(term[M:] == 7.0) and torch.all(dterm[M:] == 7.0)
+    d = torch.from_numpy(dirs[:M].astype(np.float64)).requires_grad_(True)
+    g = torch.einsum("lmc,lmdc->md", torch.from_numpy(dh[:, :M].astype(np.float64)), torch.from_numpy(jac[:, :M].astype(np.float64)))
+    g = g * torch.from_numpy(sigma[:M].astype(np.float64)).clamp(np.exp(-80.0), np.exp(80.0))[:, None] / (2 * bound)
+    nrm = (-(g / g.norm(dim=-1, keepdim=True).clamp_min(1e-12)) + 1) / 2
+    u = d / d.norm(dim=-1, keepdim=True)
+    want = torch.clamp((nrm * -u).sum(-1), max=0.0) ** 2
+    want.sum().backward()
+    np.testing.assert_allclose(host(term)[:M], want.detach().numpy(), rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(host(dterm)[:M], d.grad.numpy(), rtol=2e-3, atol=2e-5)
+    assert float(want[5]) == pytest.approx(min(0.0, float((0.5 * -u[5]).sum())) ** 2, abs=1e-12)
+    assert 0.2 < float((want > 0).double().mean()) < 0.9
+
+    # the term's way to the ray directions
+    denc = rng.normal(size=(L, cap, 2)).astype(np.float32)
+    ddirs = rng.normal(size=(cap, 3)).astype(np.float32)
+    tw = rng.uniform(0, 1, cap).astype(np.float32)
+    go, gd = torch.empty(N, 3, device="cuda"), torch.empty(N, 3, device="cuda")
+    go2, gd2 = torch.empty(N, 3, device="cuda"), torch.empty(N, 3, device="cuda")
+    e.ray_gradients(dev(denc), dev(jac), cap, L, bound, dev(ddirs), dev(ts), dev(rays), N, M, go, gd, terms=(dev(tw), dterm))
+    both = ddirs.copy()
+    both[:M] += tw[:M, None] * host(dterm)[:M]
+    e.ray_gradients(dev(denc), dev(jac), cap, L, bound, dev(both), dev(ts), dev(rays), N, M, go2, gd2)
+    assert torch.equal(go, go2)
+    np.testing.assert_allclose(host(gd), host(gd2), rtol=1e-5, atol=1e-5 * float(gd2.abs().max()))
+    e.ray_gradients(dev(denc), dev(jac), cap, L, bound, dev(ddirs), dev(ts), dev(rays), N, M, go2, gd2)      # without the term
+    assert float((gd - gd2).abs().max()) > 1e-2 * float(gd2.abs().max())
+
+
 @pytest.mark.parametrize("T_thresh,random_bg,weighted", [(1e-4, True, False), (1e-8, False, True)])
 def test_hdr_loss_step_matches_restatement(lib, orc, T_thresh, random_bg, weighted):
     rng = np.random.default_rng(21)
