@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 from .. import parallel, raymarching
+from . import utils
 from .._lib import engine_backend as eb
 from .._lib import gridencoder_backend as gb
 from .._lib import mlp_backend as _mlp_plain
@@ -79,10 +80,7 @@ class FusedTrainer:
         self.baa = opt.pose_opt == "baangp"
         assert not (getattr(opt, "adaptive_num_rays", False) and getattr(opt, "loss_weight", "none") != "none"), \
             "fused step: adaptive ray batches and a loss weight are not combined"
-        assert not self.hdr or getattr(opt, "loss_weight", "none") in ("none", "planck"), \
-            "fused step: HDR loss_weight gaussian / hanning need batch statistics -- use Trainer"
-        assert not (getattr(opt, "lambda_entropy", 0) > 0 and getattr(opt, "loss_weight", "none") == "planck"), \
-            "fused step: the entropy term and a planck loss weight are not combined"
+        assert getattr(opt, "loss_weight", "none") in ("none", "planck", "gaussian", "hanning"), opt.loss_weight
         # the orientation term (renderer.py:558-571, train_utils.py:546-548): per sample, from d sigma / d xyz -- one more
         # pass through the density network and the encoder's Jacobian slab in front of the compositor.  (lambda_distort
         # needs no code: only the renderer WITHOUT the density grid returns a distort_loss, renderer.py:504-505 -- on this
@@ -387,8 +385,8 @@ class FusedTrainer:
         self.field_forward_backward(slot, gt_rgba, bg_rgb, bg_const)
 
     def field_forward_backward(self, slot, gt_rgba, bg_rgb=None, bg_const=0.0):
-        # (the orientation term lives in the one-launch compositor step)
-        for _, op in self._field_ops(slot, gt_rgba, bg_rgb, bg_const, fuse_composite=self.orient):
+        # (the orientation term and the HDR loss live in the one-launch compositor step)
+        for _, op in self._field_ops(slot, gt_rgba, bg_rgb, bg_const, fuse_composite=self.orient or self.hdr):
             op()
 
     def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False, split_weights=False,
@@ -411,47 +409,29 @@ class FusedTrainer:
             if zero_loss:
                 self.loss.zero_()
             lam = float(getattr(opt, "lambda_entropy", 0.0))
-            if self.orient:         # the general entry: any of the above + the term over the samples' weights
-                weight = self._planck_weight(gt_rgba, bg_rgb, bg_const) if self.hdr and opt.loss_weight == "planck" else None
-                eb.composite_train_live(gt_rgba, bg_rgb, bg_const, slot.exposure if self.hdr else None, weight, 1.0 / (3 * N),
+            exposure = slot.exposure if self.hdr else None      # exposure-scaled, clipped loss of train_utils.py:512-536
+            weight = utils.hdr_loss_weight(opt.loss_weight, self._target(gt_rgba, bg_rgb, bg_const)) if self.hdr else None
+            if weight is not None:
+                weight = weight.contiguous()
+            if self.orient or self.adaptive or lam > 0 or (live is not None and (self.hdr or live[3] is not None)):
+                # the general entry: the loss over the rays the batch really carries (adaptive), the entropy of the accumulated
+                # opacity, the term over the samples' weights, the HDR loss -- and the list with its per-ray offsets
+                eb.composite_train_live(gt_rgba, bg_rgb, bg_const, exposure, weight, 1.0 / (3 * N),
                                         slot.live if self.adaptive else None, self.sigma, self.rgb, ar.ts, ar.rays, cap, N,
                                         opt.T_thresh, self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
-                                        lambda_entropy=lam, live=live, sample_term=self.orient_term,
-                                        lambda_sample=float(opt.lambda_orientation),
-                                        term_weight=self.orient_weight if self.pose else None)
+                                        lambda_entropy=lam, live=live, sample_term=self.orient_term if self.orient else None,
+                                        lambda_sample=float(opt.lambda_orientation) if self.orient else 0.0,
+                                        term_weight=self.orient_weight if self.orient and self.pose else None)
                 if self.adaptive:
                     self.rays_seen.add_(slot.live)
-                return
-            if self.adaptive or (lam > 0 and not (self.hdr and opt.loss_weight == "planck")):
-                # loss over the rays the batch really carries (adaptive), + the entropy of the accumulated opacity
-                eb.composite_train_live(gt_rgba, bg_rgb, bg_const, slot.exposure if self.hdr else None, None, 1.0 / (3 * N),
-                                        slot.live if self.adaptive else None, self.sigma, self.rgb, ar.ts, ar.rays, cap, N,
-                                        opt.T_thresh, self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
-                                        lambda_entropy=lam, live=live)
-                if self.adaptive:
-                    self.rays_seen.add_(slot.live)
-                return
-            if self.hdr:            # exposure-scaled, clipped loss of train_utils.py:512-536
-                weight = None
-                if opt.loss_weight == "planck":     # raw_utils.planck_taper_weighting(gt_rgb): pointwise in the target
-                    weight = self._planck_weight(gt_rgba, bg_rgb, bg_const)
-                if live is not None:    # (ngp_x_composite_hdr_train is this call without the list)
-                    eb.composite_train_live(gt_rgba, bg_rgb, bg_const, slot.exposure, weight, 1.0 / (3 * N), None, self.sigma,
-                                            self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh, self.ws, self.depth, self.image,
-                                            self.dsigma, self.drgb, self.loss, live=live)
-                    return
-                eb.composite_hdr_train(gt_rgba, bg_rgb, bg_const, slot.exposure, weight, 1.0 / (3 * N), self.sigma, self.rgb,
+            elif self.hdr:
+                eb.composite_hdr_train(gt_rgba, bg_rgb, bg_const, exposure, weight, 1.0 / (3 * N), self.sigma, self.rgb,
                                        ar.ts, ar.rays, cap, N, opt.T_thresh, self.ws, self.depth, self.image, self.dsigma,
                                        self.drgb, self.loss)
-                return
-            if live is not None and live[3] is not None:    # (per-ray list offsets: the general entry writes them)
-                eb.composite_train_live(gt_rgba, bg_rgb, bg_const, None, None, 1.0 / (3 * N), None, self.sigma, self.rgb, ar.ts,
-                                        ar.rays, cap, N, opt.T_thresh, self.ws, self.depth, self.image, self.dsigma, self.drgb,
-                                        self.loss, live=live)
-                return
-            eb.composite_mse_train(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh,
-                                   self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
-                                   live=live[:3] if live is not None else None)
+            else:
+                eb.composite_mse_train(gt_rgba, bg_rgb, bg_const, self.sigma, self.rgb, ar.ts, ar.rays, cap, N, opt.T_thresh,
+                                       self.ws, self.depth, self.image, self.dsigma, self.drgb, self.loss,
+                                       live=live[:3] if live is not None else None)
 
         # the backward over the list of samples that can have a gradient (see __init__): the step path (one-launch compositor
         # step) with tile-local records
@@ -519,13 +499,11 @@ class FusedTrainer:
         """Does the step's backward run over the list of samples in front of the compositor's early stop?"""
         return bool(self.live_list and fuse_composite and not self.binned_counts)
 
-    def _planck_weight(self, gt_rgba, bg_rgb, bg_const):
-        """raw_utils.planck_taper_weighting of the target colour (raw/raw_utils.py:46-53: peak 0.5, taper 0.95, max 2)."""
+    @staticmethod
+    def _target(gt_rgba, bg_rgb, bg_const):
+        """The target colour the loss compares with: the pixel over the step's background (train_utils.py:500-505)."""
         a = gt_rgba[:, 3:]
-        bg = bg_rgb if bg_rgb is not None else bg_const
-        gt = gt_rgba[:, :3] * a + bg * (1 - a)
-        w = 2.0 * (0.5 + 0.5 * torch.cos((gt - 0.5) * (math.pi / (2 * 0.95))))
-        return torch.where((gt >= 0.5 - 0.95) & (gt <= 0.5 + 0.95), w, torch.zeros_like(w)).contiguous()
+        return gt_rgba[:, :3] * a + (bg_rgb if bg_rgb is not None else bg_const) * (1 - a)
 
     @torch.no_grad()
     def refined_poses(self):

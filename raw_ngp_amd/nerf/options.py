@@ -53,7 +53,7 @@ class Options:
     beta: float = 2.0
     compute_normals: bool = False
     image_mode: str = "LDR"      # HDR: exposure-scaled, clipped RawNeRF loss (main.py:86, train_utils.py:512-536)
-    loss_weight: str = "none"    # HDR loss weighting (main.py:118): none | planck (gaussian / hanning: per-op Trainer only)
+    loss_weight: str = "none"    # HDR loss weighting (main.py:118): none | planck | gaussian | hanning
     # training (main.py:16,40-41)
     fp16: bool = False
     iters: int = 20000

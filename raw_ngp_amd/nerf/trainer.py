@@ -78,7 +78,13 @@ class Trainer:
         if pose_step:
             self.pose_optimizer.optimizer.zero_grad(set_to_none=True)
         out = model.render(data["rays_o"], data["rays_d"], rays_ldir=data.get("rays_ldir"), bg_color=bg, perturb=True)
-        loss = self.criterion(out["image"], gt).mean(-1).mean()
+        if getattr(opt, "image_mode", "LDR") == "HDR":      # train_utils.py:512-536
+            exposures = getattr(self.data, "exposures", None)
+            exposure = (torch.as_tensor(exposures, dtype=torch.float32, device=gt.device)[data["index"]]
+                        if exposures is not None else torch.ones(gt.shape[0], device=gt.device))
+            loss = utils.hdr_loss(out["image"], gt, exposure, getattr(opt, "loss_weight", "none"))
+        else:
+            loss = self.criterion(out["image"], gt).mean(-1).mean()
         if "proposal_loss" in out and opt.lambda_proposal > 0:
             loss = loss + opt.lambda_proposal * out["proposal_loss"]
         if "orientation_loss" in out and opt.lambda_orientation > 0:

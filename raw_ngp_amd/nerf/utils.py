@@ -2,6 +2,7 @@
 
 `get_rays` follows the reference's nerf/train_utils.py:96-172 (pixel centre +0.5, camera looks
 down -z, y flipped, directions NOT normalised); `PSNRMeter` follows :203-248."""
+import math
 import os
 import random
 
@@ -75,3 +76,37 @@ class PSNRMeter:
 
     def report(self):
         return f"PSNR = {self.measure():.6f}"
+
+
+# ---- HDR loss of the reference's train_step (train_utils.py:512-536) and its target-dependent weights (raw/raw_utils.py:30-53)
+def hdr_loss_weight(kind, gt_rgb):
+    """[N,3] weight of the squared residuals (a constant: the reference detaches it), or None for "none".
+    gaussian: exp(-(v - peak^2) / (2 sigma^2)) with peak 1, sigma 0.5 (no square on the difference, as the reference has it),
+    scaled so that the largest weight in the batch is 1.  hanning: a Hann window over the POSITION of the ray in the
+    batch, peak 2, the same for the three channels.  planck: cosine taper around 0.5, zero outside 0.5 +- 0.95, peak 2."""
+    if kind == "none":
+        return None
+    if kind == "gaussian":
+        w = torch.exp((1.0 - gt_rgb) / (2 * 0.5 ** 2))
+        return (w / w.max()).detach()
+    if kind == "hanning":
+        n = gt_rgb.shape[0]
+        w = 0.5 - 0.5 * torch.cos(2 * math.pi * torch.arange(n, device=gt_rgb.device, dtype=torch.float32) / (n - 1))
+        return (2.0 * w / w.max())[:, None].expand(-1, 3).detach()
+    if kind == "planck":
+        inside = (gt_rgb >= 0.5 - 0.95) & (gt_rgb <= 0.5 + 0.95)
+        w = 2.0 * (0.5 + 0.5 * torch.cos((gt_rgb - 0.5) * (math.pi / (2 * 0.95))))
+        return torch.where(inside, w, torch.zeros_like(w))
+    raise ValueError(f"loss_weight {kind!r}")
+
+
+def hdr_loss(pred_rgb, gt_rgb, exposure, loss_weight="none", lossmult=None):
+    """RawNeRF's clipped, tone-curve-weighted squared error: the prediction is scaled by the ray's exposure and clipped at
+    white, the residual weighted by the squared gradient of log(1e-3 + x) at the (detached) clipped value; mean over the
+    entries lossmult selects (None: all)."""
+    clip = torch.clamp(pred_rgb * exposure[:, None], max=1.0)
+    data = (clip - gt_rgb) ** 2 / (1e-3 + clip.detach()) ** 2
+    mult = torch.ones_like(gt_rgb) if lossmult is None else torch.broadcast_to(lossmult, gt_rgb.shape)
+    w = hdr_loss_weight(loss_weight, gt_rgb)
+    return (data * mult * (1.0 if w is None else w)).sum() / mult.sum()
+

@@ -439,6 +439,52 @@ def test_graph_replay_matches_eager_steps(lib):
     assert abs(sa - sb) <= 0.02 * sb
 
 
+@pytest.mark.parametrize("loss_weight,lam", [("none", 0.0), ("planck", 0.0), ("gaussian", 0.0), ("hanning", 0.0), ("gaussian", 0.05)])
+def test_fused_step_with_the_hdr_loss_matches_the_per_op_path(lib, loss_weight, lam):
+    """image_mode HDR (train_utils.py:512-536) with each loss weight of raw_utils.py:30-53 (and with the entropy term on top):
+    loss and gradients of the fused step against torch autograd over the per-op renderer and nerf.utils.hdr_loss."""
+    from raw_ngp_amd.nerf import utils
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=1024, iters=100, fused_mlp=True, image_mode="HDR", loss_weight=loss_weight,
+                  lambda_entropy=lam)
+    data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=4, H=64, W=64)
+    data.exposures = torch.tensor([50.0, 200.0, 400.0, 800.0], device="cuda")    # (the untrained field renders ~ 0.003)
+    model = NeRFNetwork(opt).cuda()
+    with torch.no_grad():
+        model.grid_encoder.embeddings.uniform_(-0.5, 0.5)
+    eng = FusedTrainer(opt, model, data, device="cuda", capacity=1024 * 256)
+    model.train()
+    model.update_extra_state()
+    batch = data.sample_rays(opt.num_rays, torch.Generator(device="cuda").manual_seed(1))
+    gt = batch["images"]
+    exposure = data.exposures[batch["index"]]
+    eng.slots[0].exposure.copy_(exposure)
+    eng.forward_backward(batch["rays_o"].contiguous(), batch["rays_d"].contiguous(), gt.contiguous(),
+                         torch.zeros(opt.num_rays, device="cuda"))
+    model.zero_grad()
+    out = model.render(batch["rays_o"], batch["rays_d"], bg_color=0, perturb=False)
+    tgt = gt[:, :3] * gt[:, 3:]
+    loss = utils.hdr_loss(out["image"], tgt, exposure, loss_weight)
+    if lam > 0:
+        w = out["weights_sum"].clamp(1e-5, 1 - 1e-5)
+        loss = loss + lam * (-w * torch.log2(w) - (1 - w) * torch.log2(1 - w)).mean()
+    loss.backward()
+    np.testing.assert_allclose(float(eng.loss), float(loss.detach()), rtol=1e-3)
+    clipped = float((out["image"].detach() * exposure[:, None] > 1).float().mean())
+    assert 0.02 < clipped < 0.98, clipped                       # predictions on both sides of the clip at white
+    ref_t = model.grid_encoder.embeddings.grad
+    ref_w = torch.cat([l.weight.grad.reshape(-1) for l in list(model.grid_mlp.net) + list(model.view_mlp.net)])
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-30))
+    assert rel(eng.table_grad, ref_t) < 5e-3, rel(eng.table_grad, ref_t)
+    assert rel(eng.w_grad, ref_w) < 5e-3, rel(eng.w_grad, ref_w)
+
+
 @pytest.mark.parametrize("rfield", [False, True], ids=["plain", "light-conditioned"])
 def test_orientation_term_of_a_train_step_matches_autograd(lib, rfield):
     """The per-sample term a train_step leaves behind (graphs, march ahead on the side stream) against torch autograd through
