@@ -274,20 +274,6 @@ int ngp_x_grid_backward_binned_apply_mlp(
     const void *mlp_workspace, size_t mlp_workspace_bytes, float *mlp_adam_param, const float *mlp_adam_grad,
     float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq, uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1,
     float mlp_beta2, float mlp_eps, void *mlp_adam_image, ngp_stream_t stream);
-/* ngp_x_grid_backward_binned_apply_mlp_list in parts (tile-local layout only): fill != 0 runs the fill kernel (with the MLP
- * passenger when mlp_workspace != NULL) first; then chunks chunk_first .. chunk_first + chunk_count - 1 are reduced (with the
- * fused Adam).  A chunk is ngp_x_grid_backward_binned_geometry()'s rows-per-chunk consecutive rows of ONE level, a level's
- * chunks are consecutive, so a level range is a chunk range.  Every chunk must be covered exactly once per fill. */
-int ngp_x_grid_backward_binned_apply_part(
-    const float *grad, const float *inputs, const int32_t *sample_index, const int32_t *offsets, float *grad_embeddings,
-    const int32_t *B_dev, uint32_t B, uint32_t grad_stride, uint32_t L, uint32_t max_level, float S, uint32_t H,
-    uint32_t gridtype, int align_corners, uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
-    size_t workspace_bytes, float *adam_param, float *adam_exp_avg, float *adam_exp_avg_sq, const float *adam_hyper,
-    float beta1, float beta2, float eps, int overwrite, uint32_t mlp_M, float mlp_loss_scale, float *dw1, float *dw2,
-    float *dw3, float *dw4, float *dw5, float *dw6, const void *mlp_workspace, size_t mlp_workspace_bytes,
-    float *mlp_adam_param, const float *mlp_adam_grad, float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq,
-    uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1, float mlp_beta2, float mlp_eps, void *mlp_adam_image,
-    int fill, uint32_t chunk_first, uint32_t chunk_count, ngp_stream_t stream);
 /* ngp_x_grid_backward_binned_apply_mlp over a LIST of samples (tile-local layout only): entry b of the call is sample
  * sample_index[b] -- `inputs` is addressed by sample, the gradient slab `grad` is in list order (as ngp_x_mlp_backward_list
  * writes it), *B_dev entries are used.  NULL: samples 0 .. B - 1. */
@@ -451,16 +437,6 @@ int ngp_x_grid_encode_forward_slab_placed(const float *xyzs, float bound, const 
                                           uint32_t gridtype, int align_corners, uint32_t interp, void *binned_workspace,
                                           uint32_t n_rows_total, float *dydx, const float *level_cost,
                                           ngp_stream_t stream);
-/* ... for levels first_level .. first_level + n_levels - 1 only: the other levels' rows of `out` (and of dydx) are not
- * touched, inputs01 is written by the call that covers level 0; level_cost (optional) has n_levels entries.  With
- * ngp_x_grid_backward_binned_apply_part a step can encode the levels whose table rows are final while the optimiser is
- * still working on the others. */
-int ngp_x_grid_encode_forward_slab_levels(const float *xyzs, float bound, const float *embeddings, const int32_t *offsets,
-                                          float *out, float *inputs01, const int32_t *B_dev, uint32_t B_cap,
-                                          uint32_t stride, uint32_t L, uint32_t first_level, uint32_t n_levels, float S,
-                                          uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
-                                          void *binned_workspace, uint32_t n_rows_total, float *dydx,
-                                          const float *level_cost, ngp_stream_t stream);
 /* binned_workspace != NULL: a workspace of ngp_x_grid_backward_binned_prepare(stage 1) for the same samples; the
  * kernel also counts the records per 4096-row chunk (n_rows_total = rows of the whole table). */
 

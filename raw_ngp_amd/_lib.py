@@ -57,10 +57,6 @@ _SIGNATURES = {
                                                   ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i,
                                                   _u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p,
                                                   _f, _f, _f, _p],
-    "ngp_x_grid_backward_binned_apply_part": [_p, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
-                                                  ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i,
-                                                  _u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p,
-                                                  _f, _f, _f, _p, _i, _u, _u],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u, _i],
     "ngp_x_grid_encode_forward_jac": [_p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _p, _u, _i, _u, _i],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
@@ -78,8 +74,6 @@ _SIGNATURES = {
     "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
     "ngp_x_grid_encode_forward_slab_jac": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p],
     "ngp_x_grid_encode_forward_slab_placed": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p, _p],
-    "ngp_x_grid_encode_forward_slab_levels": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p,
-                                              _p],
     "ngp_x_composite_hdr_train": [_p, _p, _f, _p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
     "ngp_x_sample_rays_lit": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p,
                               _p, _p],
@@ -378,16 +372,14 @@ class _GridBackend:
     @staticmethod
     def grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
                                    workspace, gridtype=0, align_corners=False, interp=0, adam=None, overwrite=False,
-                                   mlp_tail=None, sample_index=None, part=None):
+                                   mlp_tail=None, sample_index=None):
         """Fill + reduce on a workspace prepared for the same positions.  adam = (param, exp_avg, exp_avg_sq, hyper,
         beta1, beta2, eps): apply the optimiser inside the reduce kernel instead of writing grad_embeddings.
         overwrite: grad_embeddings = sums for every row (no +=); a bfloat16 grad_embeddings selects the 16-bit store.
         mlp_tail = (M, loss_scale, dws, workspace, adam, image), the arguments of mlp_backend.reduce_dw: that reduction
         rides along as extra workgroups of the fill kernel (ngp_x_grid_backward_binned_apply_mlp).
         sample_index (int32): the call runs over a LIST of samples -- `inputs` by sample, `grad` in list order,
-        B_dev[0] entries (ngp_x_grid_backward_binned_apply_mlp_list / ..._apply_list).
-        part = (fill: bool, chunk_first, chunk_count): the call in parts (ngp_x_grid_backward_binned_apply_part) -- the fill
-        (with the passenger) if `fill`, then the reduce of that range of chunks only."""
+        B_dev[0] entries (ngp_x_grid_backward_binned_apply_mlp_list / ..._apply_list)."""
         n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
         wire16 = grad_embeddings is not None and grad_embeddings.dtype == torch.bfloat16
         if wire16 and not overwrite:
@@ -402,22 +394,6 @@ class _GridBackend:
                 _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
                 int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets),
                 workspace.data_ptr(), workspace.numel(), *extra, 2 if wire16 else int(bool(overwrite))]
-        if part is not None:
-            fill, chunk_first, chunk_count = part
-            tail = [0, 0.0, *[None] * 6, None, 0, None, None, None, None, 0, None, 0.0, 0.0, 0.0, None]
-            if mlp_tail is not None and fill:
-                M, loss_scale, dws, mlp_ws, mlp_adam, image = mlp_tail
-                mextra = [None, None, None, None, 0, None, 0.0, 0.0, 0.0]
-                if mlp_adam is not None:
-                    p_, g_, m_, v_, hyper, b1, b2, eps = mlp_adam
-                    mextra = [_ptr(p_, "f", "mlp_adam_param"), _ptr(g_, "f", "mlp_adam_grad"), _ptr(m_, "f", "mlp_adam_exp_avg"),
-                              _ptr(v_, "f", "mlp_adam_exp_avg_sq"), g_.numel(), _ptr(hyper, "f", "mlp_adam_hyper"), float(b1),
-                              float(b2), float(eps)]
-                tail = [M, float(loss_scale), *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], mlp_ws.data_ptr(),
-                        mlp_ws.numel(), *mextra, image.data_ptr() if image is not None else None]
-            _call("ngp_x_grid_backward_binned_apply_part", grad, *args[:2], _ptr(sample_index, "i", "sample_index", True),
-                  *args[2:], *tail, int(bool(fill)), int(chunk_first), int(chunk_count))
-            return
         if mlp_tail is None:
             if sample_index is not None:
                 _call("ngp_x_grid_backward_binned_apply_list", grad, *args[:2], _ptr(sample_index, "i", "sample_index"), *args[2:],
@@ -754,25 +730,10 @@ class _EngineBackend:
     @staticmethod
     def grid_encode_forward_slab(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L, max_level, S,
                                  H, gridtype=0, align_corners=False, interp=0, binned_workspace=None, dydx=None,
-                                 level_cost=None, levels=None):
+                                 level_cost=None):
         """dydx: optional [L, stride, 3, 2] slab receiving d out / d x01 (pose refinement: ray_gradients).
         level_cost: optional sequence of max_level positive floats, the relative cost of a tile of each level for these
-        points -- the level -> XCD placement is balanced on it (placement only).
-        levels = (first_level, n_levels): encode those levels only (max_level is ignored; level_cost: n_levels entries)."""
-        if levels is not None:
-            first, n = levels
-            if level_cost is not None and len(level_cost) != n:
-                raise RuntimeError("grid_encode_forward_slab: level_cost must hold n_levels floats")
-            if dydx is not None and dydx.numel() < L * stride * 6:
-                raise RuntimeError("grid_encode_forward_slab: dydx must hold L * stride * 3 * 2 floats")
-            cost = (ctypes.c_float * n)(*[float(c) for c in level_cost]) if level_cost is not None else None
-            _call("ngp_x_grid_encode_forward_slab_levels", xyzs, _ptr(xyzs, "f", "xyzs"), float(bound),
-                  _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"), _ptr(out, "f", "out"),
-                  _ptr(inputs01, "f", "inputs01", True), _ptr(B_dev, "i", "B_dev", True), B_cap, stride, L, int(first), int(n),
-                  float(S), H, gridtype, int(bool(align_corners)), interp,
-                  binned_workspace.data_ptr() if binned_workspace is not None else None, embeddings.shape[0],
-                  _ptr(dydx, "f", "dydx", True), cost, probe_as="ngp_x_grid_encode_forward_slab")
-            return
+        points -- the level -> XCD placement is balanced on it (placement only)."""
         args = (_ptr(xyzs, "f", "xyzs"), float(bound),
                 _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"), _ptr(out, "f", "out"),
                 _ptr(inputs01, "f", "inputs01", True), _ptr(B_dev, "i", "B_dev", True), B_cap, stride, L, max_level,

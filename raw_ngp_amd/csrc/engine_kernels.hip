@@ -29,8 +29,7 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     const float *__restrict__ xyzs, float bound, const float *__restrict__ table, const int32_t *__restrict__ offsets,
     float *__restrict__ out, float *__restrict__ inputs01, const int32_t *__restrict__ B_dev, uint32_t B_cap,
     uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w,
-    float *__restrict__ dydx = nullptr, uint32_t snake_levels = 0, uint32_t placed_levels = 0, LevelPlacement place = {},
-    uint32_t first_level = 0)
+    float *__restrict__ dydx = nullptr, uint32_t snake_levels = 0, uint32_t placed_levels = 0, LevelPlacement place = {})
 {
     extern __shared__ uint32_t hist[];
     uint32_t level, tile_;
@@ -45,7 +44,6 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
         level = item / nchunks;
         tile_ = item - level * nchunks;
     }
-    level += first_level;   // (the launch covers levels first_level .. first_level + n - 1: the mappings above count from 0)
     const uint32_t b0 = tile_ * kBlock, b = b0 + threadIdx.x;
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
     if (b0 >= B) return;   // whole workgroup
@@ -768,30 +766,13 @@ extern "C" int ngp_x_grid_encode_forward_slab_placed(const float *xyzs, float bo
                                                      uint32_t n_rows_total, float *dydx, const float *level_cost,
                                                      ngp_stream_t stream)
 {
-    return ngp_x_grid_encode_forward_slab_levels(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L, 0,
-                                                 max_level, S, H, gridtype, align_corners, interp, binned_workspace,
-                                                 n_rows_total, dydx, level_cost, stream);
-}
-
-// levels first_level .. first_level + n_levels - 1 only (the other levels' slab rows are not touched; inputs01 is written by
-// the call that covers level 0).  level_cost: n_levels entries.  A caller that knows which levels of the table are final
-// -- the table backward reduced in two parts, ngp_x_grid_backward_binned_apply_part -- encodes those first.
-extern "C" int ngp_x_grid_encode_forward_slab_levels(const float *xyzs, float bound, const float *embeddings,
-                                                     const int32_t *offsets, float *out, float *inputs01,
-                                                     const int32_t *B_dev, uint32_t B_cap, uint32_t stride, uint32_t L,
-                                                     uint32_t first_level, uint32_t n_levels, float S, uint32_t H,
-                                                     uint32_t gridtype, int align_corners, uint32_t interp,
-                                                     void *binned_workspace, uint32_t n_rows_total, float *dydx,
-                                                     const float *level_cost, ngp_stream_t stream)
-{
-    const uint32_t max_level = n_levels;      // (below: the number of levels this launch covers)
     if (B_cap == 0 || max_level == 0) return NGP_OK;
     NGP_REQUIRE(xyzs && embeddings && offsets && out, "grid_encode_forward_slab: null tensor");
     NGP_REQUIRE(stride >= B_cap, "grid_encode_forward_slab: stride smaller than B_cap");
     NGP_REQUIRE(bound > 0.0f, "grid_encode_forward_slab: bound must be positive");
     LevelRes lv;
     NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_forward_slab: L must be in [1, %u]", kMaxLevels);
-    NGP_REQUIRE(first_level <= L && max_level <= L - first_level, "grid_encode_forward_slab: levels beyond L");
+    NGP_REQUIRE(max_level <= L, "grid_encode_forward_slab: max_level > L");
     const uint32_t nchunks = ceil_div(B_cap, kBlock);
     // level -> XCD placement: snake (XCD k takes levels k and 15 - k: a cheap coarse level paired with an expensive fine one)
     // instead of the contiguous split (levels 2k, 2k + 1: XCD 7 gets the two most expensive levels and decides when the
@@ -803,7 +784,7 @@ extern "C" int ngp_x_grid_encode_forward_slab_levels(const float *xyzs, float bo
     // levels are then dealt to the XCDs in runs of equal cost (ngp_common.hpp: place_levels) instead of by the snake
     LevelPlacement place = {};
     uint32_t placed_levels = 0;
-    if (level_cost && max_level <= kPlacedLevels) {
+    if (level_cost && max_level >= 8 && max_level <= kPlacedLevels) {
         for (uint32_t l = 0; l < max_level; l++)
             NGP_REQUIRE(level_cost[l] > 0.0f && level_cost[l] < 1e30f, "grid_encode_forward_slab: level_cost[%u] must be positive", l);
         placed_levels = max_level;
@@ -824,7 +805,7 @@ extern "C" int ngp_x_grid_encode_forward_slab_levels(const float *xyzs, float bo
     }
     if (binned_workspace) {
         // the workspace of ngp_x_grid_backward_binned_* for the same samples, planned (mode 2 of prepare): count here
-        NGP_REQUIRE(max_level == L && first_level == 0 && ((uintptr_t)binned_workspace & 15u) == 0 && n_rows_total > 0,
+        NGP_REQUIRE(max_level == L && ((uintptr_t)binned_workspace & 15u) == 0 && n_rows_total > 0,
                     "grid_encode_forward_slab: counting needs max_level == L and an aligned binned workspace");
         const uint32_t n_chunks_max = n_rows_total / kChunkRows + L + 1;
         NGP_REQUIRE(n_chunks_max <= kMaxChunks, "grid_encode_forward_slab: table too large for the binned backward");
@@ -832,19 +813,19 @@ extern "C" int ngp_x_grid_encode_forward_slab_levels(const float *xyzs, float bo
         if (dydx)
             grid_forward_slab_kernel<true, true><<<grid, dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
                 xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-                align_corners != 0, interp, w, dydx, snake_levels, placed_levels, place, first_level);
+                align_corners != 0, interp, w, dydx, snake_levels, placed_levels, place);
         else
             grid_forward_slab_kernel<true><<<grid, dim3(kBlock), n_chunks_max * 4, as_stream(stream)>>>(
                 xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-                align_corners != 0, interp, w, nullptr, snake_levels, placed_levels, place, first_level);
+                align_corners != 0, interp, w, nullptr, snake_levels, placed_levels, place);
     } else if (dydx) {
         grid_forward_slab_kernel<false, true><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-            align_corners != 0, interp, WsLayout{}, dydx, snake_levels, placed_levels, place, first_level);
+            align_corners != 0, interp, WsLayout{}, dydx, snake_levels, placed_levels, place);
     } else {
         grid_forward_slab_kernel<false><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-            align_corners != 0, interp, WsLayout{}, nullptr, snake_levels, placed_levels, place, first_level);
+            align_corners != 0, interp, WsLayout{}, nullptr, snake_levels, placed_levels, place);
     }
     NGP_CHECK_LAUNCH("grid_encode_forward_slab");
     return NGP_OK;

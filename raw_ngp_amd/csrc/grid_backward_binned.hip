@@ -577,7 +577,6 @@ struct LocalRecords {
     const uint32_t *dir = nullptr;    // [n_chunks][ntiles]: first slot | count << 16
     const int32_t *B_dev = nullptr;
     uint32_t B_cap = 0, ntiles = 0;
-    uint32_t chunk_first = 0;         // the launch covers chunks chunk_first .. chunk_first + gridDim.x - 1
 };
 
 template <int MODE, bool LOCAL = false>
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(kR
     for (uint32_t i = threadIdx.x; i < kChunkRows * 2; i += kReduceBlock) acc[i] = 0ull;
     __syncthreads();
     const uint32_t n_chunks = s_base[L];
-    const uint32_t item = blockIdx.x + (LOCAL ? loc.chunk_first : 0u);
+    const uint32_t item = blockIdx.x;
     if (ALL) {   // one segment per chunk: the work item IS the chunk
         if (item >= n_chunks) return;
     } else {
@@ -1019,8 +1018,7 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
                                                 uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
                                                 size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
                                                 float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
-                                                float beta2, float eps, int overwrite, ngp_stream_t stream,
-                                                int do_fill = 1, uint32_t chunk_first = 0, uint32_t chunk_count = 0xffffffffu)
+                                                float beta2, float eps, int overwrite, ngp_stream_t stream)
 {
     (void)who;
     if (B == 0 || max_level == 0) return NGP_OK;
@@ -1053,38 +1051,28 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
         static const bool snake = !(getenv("NGP_SNAKE") && getenv("NGP_SNAKE")[0] == '0') &&
                                   !(getenv("NGP_SNAKE_FILL") && getenv("NGP_SNAKE_FILL")[0] == '0');   // (as the slab forward)
         const bool sn = snake && max_level >= 8;
-        if (do_fill)
-            bin_fill_local_kernel<<<(sn ? snake_blocks(max_level, ft) : ft * max_level) + n_tail, kFillBlock, lds, st>>>(
-                grad, inputs, offsets, B_dev, B, grad_stride, ft, c.nbins_cap, c.lv, gridtype, align_corners != 0, interp, wl, dir,
-                n_tail, tail ? *tail : MlpDwReduce{}, sn ? max_level : 0u, sample_index);
+        bin_fill_local_kernel<<<(sn ? snake_blocks(max_level, ft) : ft * max_level) + n_tail, kFillBlock, lds, st>>>(
+            grad, inputs, offsets, B_dev, B, grad_stride, ft, c.nbins_cap, c.lv, gridtype, align_corners != 0, interp, wl, dir,
+            n_tail, tail ? *tail : MlpDwReduce{}, sn ? max_level : 0u, sample_index);
         LocalRecords loc;
         loc.dir = dir;
         loc.B_dev = B_dev;
         loc.B_cap = B;
         loc.ntiles = ft;
-        // the reduce of a RANGE of chunks (ngp_x_grid_backward_binned_apply_part: the chunks of some levels now, the others
-        // in a second call); chunks past the table's last one leave at once
-        NGP_REQUIRE(chunk_first <= c.n_chunks_max, "grid_backward_binned_apply: chunk_first beyond the table");
-        loc.chunk_first = chunk_first;
-        const uint32_t left = c.n_chunks_max - chunk_first;
-        const uint32_t n_launch = chunk_count < left ? chunk_count : left;      // (host min() is the int overload)
         // (levels >= max_level have no records: their directory columns are not read -- the reduce walks L levels only when
         // every level was filled, otherwise max_level of them)
         const uint32_t Lr = max_level;
-        if (n_launch == 0) {
-        } else if (fused)
-            bin_reduce_kernel<1, true><<<n_launch, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+        if (fused)
+            bin_reduce_kernel<1, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
         else if (overwrite == 2)
-            bin_reduce_kernel<3, true><<<n_launch, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+            bin_reduce_kernel<3, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
         else if (overwrite)
-            bin_reduce_kernel<2, true><<<n_launch, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+            bin_reduce_kernel<2, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
         else
-            bin_reduce_kernel<0, true><<<n_launch, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+            bin_reduce_kernel<0, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
         NGP_CHECK_LAUNCH("grid_backward_binned_apply");
         return NGP_OK;
     }
-    NGP_REQUIRE(do_fill && chunk_first == 0 && chunk_count >= c.n_chunks_max,
-                "grid_backward_binned_apply: a chunk range needs the tile-local layout (see ..._binned_counts)");
     NGP_REQUIRE(!sample_index, "grid_backward_binned_apply: a sample list needs the tile-local layout (see ..._binned_counts)");
     bin_fill_kernel<<<ft * max_level + n_tail, kFillBlock, c.fill_lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft,
                                                                             c.nbins_cap, c.lv, gridtype, align_corners != 0,
@@ -1177,38 +1165,6 @@ extern "C" int ngp_x_grid_backward_binned_apply_mlp_list(
                         grad_stride, L, max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
                         workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
                         stream);
-}
-
-// ngp_x_grid_backward_binned_apply_mlp_list in two calls: `fill` != 0 runs the fill (with its passenger) first; then the
-// reduce (+ Adam) of chunks chunk_first .. chunk_first + chunk_count - 1 only.  A level's chunks are consecutive
-// (ngp_x_grid_backward_binned_geometry: rows per chunk), so "the coarse levels now, the fine ones in a second call" lets a
-// caller start the next forward pass on the levels that are final while the others are still being reduced.  Every chunk
-// must be covered exactly once per fill (the fused Adam also steps rows without records).
-extern "C" int ngp_x_grid_backward_binned_apply_part(
-    const float *grad, const float *inputs, const int32_t *sample_index, const int32_t *offsets, float *grad_embeddings,
-    const int32_t *B_dev, uint32_t B, uint32_t grad_stride, uint32_t L, uint32_t max_level, float S, uint32_t H,
-    uint32_t gridtype, int align_corners, uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
-    size_t workspace_bytes, float *adam_param, float *adam_exp_avg, float *adam_exp_avg_sq, const float *adam_hyper,
-    float beta1, float beta2, float eps, int overwrite, uint32_t mlp_M, float mlp_loss_scale, float *dw1, float *dw2,
-    float *dw3, float *dw4, float *dw5, float *dw6, const void *mlp_workspace, size_t mlp_workspace_bytes,
-    float *mlp_adam_param, const float *mlp_adam_grad, float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq,
-    uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1, float mlp_beta2, float mlp_eps, void *mlp_adam_image,
-    int fill, uint32_t chunk_first, uint32_t chunk_count, ngp_stream_t stream)
-{
-    NGP_REQUIRE(B != 0 && max_level != 0, "grid_backward_binned_apply_part: nothing to launch");
-    MlpDwReduce r;
-    const bool ride = fill && mlp_workspace != nullptr;      // the MLP's weight-gradient reduction rides with the fill
-    if (ride) {
-        const int rc = mlp_dw_reduce_args(r, "grid_backward_binned_apply_part", mlp_M, mlp_loss_scale, dw1, dw2, dw3, dw4, dw5,
-                                          dw6, mlp_workspace, mlp_workspace_bytes, mlp_adam_param, mlp_adam_grad,
-                                          mlp_adam_exp_avg, mlp_adam_exp_avg_sq, mlp_adam_n, mlp_adam_hyper, mlp_beta1,
-                                          mlp_beta2, mlp_eps, mlp_adam_image);
-        if (rc != NGP_OK) return rc;
-    }
-    return binned_apply("grid_backward_binned_apply_part", ride ? &r : nullptr, sample_index, grad, inputs, offsets,
-                        grad_embeddings, B_dev, B, grad_stride, L, max_level, S, H, gridtype, align_corners, interp, n_rows_total,
-                        max_level_rows, workspace, workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1,
-                        beta2, eps, overwrite, stream, fill, chunk_first, chunk_count);
 }
 
 extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,

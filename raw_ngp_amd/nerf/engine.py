@@ -203,7 +203,6 @@ class FusedTrainer:
             self.rays_seen = torch.zeros(1, dtype=torch.int64, device=dev)
         self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
         self.aux = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self.early = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None     # next step's coarse levels (_level_split)
         # compressed occupancy bitfield the march keeps in LDS (rebuilt after every density-grid refresh)
         self.occ_index = None
         # (chain mode with dt_gamma == 0: the constant-step march kernel stages the same index in LDS when it fits)
@@ -320,19 +319,6 @@ class FusedTrainer:
             slot.ws_grid = torch.empty(gb.backward_workspace_bytes(cap, self.L, self.rows), dtype=torch.uint8, device=dev)
         # record layout of the binned table backward at this capacity: does it want the encoder's forward to count records?
         self.binned_counts = gb.backward_needs_counts(cap, self.L, model.grid_encoder.offsets)
-        # The step split by levels (inside step groups): the table backward reduces (and Adam-steps) the chunks of levels
-        # 0 .. A - 1 first; while it works on the others, the NEXT step's encoder already runs on the levels that are final
-        # (a third stream) -- only levels A .. L - 1 are left on the critical path.  One rank with the fused Adam, tile-local
-        # records.  NGP_LEVEL_SPLIT = A (0: off) [",spread": the late levels dealt over all XCDs in equal slots].
-        text = os.environ.get("NGP_LEVEL_SPLIT", "8").split(",")
-        a = int(text[0])
-        self._level_split = None
-        if dev.type == "cuda" and self.fuse_adam and not self.binned_counts and not self.pose and 0 < a < self.L:
-            offs = model.grid_encoder.offsets.cpu().numpy().astype(np.int64)          # (one read, at construction)
-            per_chunk = gb.binned_geometry()[0]
-            chunks = [int(-(-(offs[l + 1] - offs[l]) // per_chunk)) for l in range(self.L)]
-            self._level_split = (a, sum(chunks[:a]), sum(chunks[a:]), "spread" in text[1:])
-        self._partials = None
         self._image_ready = False                      # the step path expects the f16 weight image of the current weights
         self.global_step = 0
         self._groups_precaptured = False
@@ -479,22 +465,11 @@ class FusedTrainer:
                 if self.pose:       # the window's adjoint: d enc' -> d enc
                     eb.slab_window(self.denc, cap, self.L, self.level_w, back_n, cap, backward=True, scale_only=not self.baa)
 
-        def encode(levels=None, level_cost=None):      # levels = (first, n): only those (the step split by levels)
-            eb.grid_encode_forward_slab(
+        ops = [
+            ("ngp_x_grid_encode_forward_slab", lambda: eb.grid_encode_forward_slab(
                 ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt, cap, cap, self.L, self.L, self.S, self.H,
                 binned_workspace=slot.ws_grid if self.binned_counts else None,
-                dydx=self.dydx if self.pose or self.orient else None,
-                level_cost=self.level_cost_step if levels is None else level_cost, levels=levels)
-
-        def table_backward(part=None):                  # part = (fill, chunk_first, chunk_count)
-            gb.grid_backward_binned_apply(
-                self.denc, self.x01, offsets, self._wire if overwrite and self.wire16 else self.table_grad, back_n, cap, cap,
-                self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite, mlp_tail=mlp_tail,
-                sample_index=back_idx, part=part)
-
-        self._partials = {"encode": encode, "table_backward": table_backward}
-        ops = [
-            ("ngp_x_grid_encode_forward_slab", encode),
+                dydx=self.dydx if self.pose or self.orient else None, level_cost=self.level_cost_step)),
             ("ngp_x_grid_backward_binned_prepare", lambda: gb.grid_backward_binned_prepare(
                 None, 0.0, offsets, self.rows, cnt, cap, self.L, self.L, self.S, self.H, slot.ws_grid,
                 single_segment=fused_adam or overwrite, stage=2)),
@@ -506,7 +481,10 @@ class FusedTrainer:
                 self.image)),
             ("ngp_x_composite_mse_backward", loss_and_composite_backward),
             ("ngp_x_mlp_backward", mlp_backward),
-            ("ngp_x_grid_backward_binned_apply" + ("_mlp" if mlp_tail is not None else ""), table_backward),
+            ("ngp_x_grid_backward_binned_apply" + ("_mlp" if mlp_tail is not None else ""), lambda: gb.grid_backward_binned_apply(
+                self.denc, self.x01, offsets, self._wire if overwrite and self.wire16 else self.table_grad, back_n, cap, cap,
+                self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite, mlp_tail=mlp_tail,
+                sample_index=back_idx)),
         ]
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
@@ -1031,21 +1009,13 @@ class FusedTrainer:
             self.graph_pool = torch.cuda.graph_pool_handle()
         opt = self.opt
         g = torch.cuda.CUDAGraph()
-        plans = []
-        for k in range(G):
-            self._partials = None
-            ops = self._step_ops(self.slots[(parity + k) % 2])
-            plans.append((ops, self._partials))
-        split = self._level_split if all(p is not None for _, p in plans) else None
         with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
             main = torch.cuda.current_stream(self.device)
             for k in range(G):
                 cur = self.slots[(parity + k) % 2]
                 whole = k + 1 < G or last_ahead         # (else a refresh follows: only the bitfield-independent part)
                 nxt = self.slots[(parity + k + 1) % 2] if (whole or self._split_march) else None
-                ops = plans[k][0]
-                if split is not None:
-                    ops = self._split_by_levels(ops, plans[k][1], plans[k + 1][1] if k + 1 < G else None, k > 0, split, main)
+                ops = self._step_ops(cur)
                 at = min(max(int(os.environ.get("NGP_SIDE_FORK_AT", "0")), 0), len(ops) - 1) if nxt is not None else 0
                 self._run_ops(ops[:at], fork=False)
                 if nxt is not None:         # fork: the next step's rays, on the side stream
@@ -1059,33 +1029,6 @@ class FusedTrainer:
                     main.wait_stream(self.side)     # join
         self._graphs_alive.append(g)
         self.graphs[("multi", parity, G, last_ahead, head)] = [g.replay]
-
-    def _split_by_levels(self, ops, mine, nxt, early_done, split, main):
-        """The ops of one step of a group with the encoder / table backward split at level A (`_level_split`).
-        early_done: this step's levels 0 .. A - 1 were encoded beside the previous step's reduce; nxt: the partial
-        launchers of the step behind this one (None: last of the group -- its table backward stays whole)."""
-        A, chunks_a, chunks_b, spread = split
-        late = (A, self.L - A)
-        late_cost = [1.0] * (self.L - A) if spread else None
-        out = []
-        for name, op, lane in ops:
-            if name == "ngp_x_grid_encode_forward_slab" and early_done:
-                def encode_late(mine=mine):
-                    main.wait_stream(self.early)                # levels 0 .. A - 1 are in the slab
-                    mine["encode"](levels=late, level_cost=late_cost)
-                out.append((name, encode_late, lane))
-            elif name.startswith("ngp_x_grid_backward_binned_apply") and nxt is not None:
-                def backward_split(mine=mine, nxt=nxt):
-                    mine["table_backward"](part=(True, 0, chunks_a))        # fill; levels 0 .. A - 1 reduced, Adam done
-                    main.wait_stream(self.side)                 # (the next batch's samples: marched on the side stream)
-                    self.early.wait_stream(main)
-                    with torch.cuda.stream(self.early):
-                        nxt["encode"](levels=(0, A))
-                    mine["table_backward"](part=(False, chunks_a, chunks_b))
-                out.append((name, backward_split, lane))
-            else:
-                out.append((name, op, lane))
-        return out
 
     def precapture_groups(self):
         """Capture the step groups of every length (2 .. update_extra_interval - 1, both slot parities, with and without

@@ -1229,86 +1229,6 @@ def test_table_backward_over_a_sample_list(lib, orc):
     np.testing.assert_allclose(listed, full, rtol=1e-5, atol=1e-6 * scale_)
 
 
-@pytest.mark.parametrize("A", [8, 10, 5])
-def test_encoder_and_table_backward_in_two_level_ranges_change_no_bit(lib, orc, A):
-    """ngp_x_grid_encode_forward_slab_levels + ngp_x_grid_backward_binned_apply_part: levels 0 .. A - 1 and A .. 15 in two
-    calls each (the late levels of the forward also dealt over the XCDs in equal slots) against the whole calls -- the slab,
-    x01, and after the fused Adam the table and both moments, bit for bit."""
-    gb, mb, e = lib.gridencoder_backend, lib.mlp_backend, lib.engine_backend
-    rng = np.random.default_rng(29)
-    L, H, B, cap = 16, 16, 20000, 21000
-    offsets, scale = orc.grid_offsets(desired_resolution=2048)
-    S, rows = float(np.log2(scale)), int(offsets[-1])
-    if gb.backward_needs_counts(cap, L, dev(offsets)):
-        pytest.skip("global-bins layout: no chunk ranges")
-    xyz = dev(rng.uniform(-1, 1, (cap, 3)).astype(np.float32))
-    table0 = dev(rng.uniform(-1, 1, (rows, 2)).astype(np.float32))
-    cnt = torch.tensor([B, B, 0, 0], dtype=torch.int32, device="cuda")
-    enc, x01 = torch.full((L, cap, 2), 7.0, device="cuda"), torch.full((cap, 3), 7.0, device="cuda")
-    e.grid_encode_forward_slab(xyz, 1.0, table0, dev(offsets), enc, x01, cnt, cap, cap, L, L, S, H)
-    for late_cost in (None, [1.0] * (L - A)):
-        enc2, x012 = torch.full((L, cap, 2), 7.0, device="cuda"), torch.full((cap, 3), 7.0, device="cuda")
-        e.grid_encode_forward_slab(xyz, 1.0, table0, dev(offsets), enc2, x012, cnt, cap, cap, L, L, S, H, levels=(A, L - A),
-                                   level_cost=late_cost)
-        assert torch.all(enc2[:A] == 7.0) and torch.all(x012 == 7.0)           # (x01 belongs to the call with level 0)
-        e.grid_encode_forward_slab(xyz, 1.0, table0, dev(offsets), enc2, x012, cnt, cap, cap, L, L, S, H, levels=(0, A))
-        assert torch.equal(enc2, enc) and torch.equal(x012, x01)
-    # table backward with the fused Adam: whole, and chunk range by chunk range
-    per_chunk = gb.binned_geometry()[0]
-    chunks = [int(-(-(int(offsets[l + 1]) - int(offsets[l])) // per_chunk)) for l in range(L)]
-    denc = dev(rng.normal(size=(L, cap, 2)).astype(np.float32))
-    hyper = torch.tensor([1e-2, 0.1, 31.6, 0.0], device="cuda")
-    W = [torch.zeros(o_, i_, device="cuda") for o_, i_ in [(64, 32), (64, 64), (16, 64), (64, 31), (64, 64), (3, 64)]]
-    mws = torch.zeros(mb.backward_workspace_bytes(cap), dtype=torch.uint8, device="cuda")
-
-    def run(parts):
-        t, m_, v_ = table0.clone(), torch.zeros(rows, 2, device="cuda"), torch.full((rows, 2), 1e-4, device="cuda")
-        ws = torch.zeros(gb.backward_workspace_bytes(cap, L, rows), dtype=torch.uint8, device="cuda")
-        gb.grid_backward_binned_prepare(None, 0.0, dev(offsets), rows, cnt, cap, L, L, S, H, ws, stage=1)
-        dws = [torch.full_like(w, 7.0) for w in W]
-        for part in parts:
-            gb.grid_backward_binned_apply(denc, x01, dev(offsets), None, cnt, cap, cap, L, L, S, H, ws,
-                                          adam=(t, m_, v_, hyper, 0.9, 0.999, 1e-15), mlp_tail=(cap, 1.0, dws, mws, None, None),
-                                          part=part)
-        return t, m_, v_, dws
-    whole = run([None])
-    na, nb = sum(chunks[:A]), sum(chunks[A:])
-    split = run([(True, 0, na), (False, na, nb)])
-    for a, b in zip(whole[:3], split[:3]):
-        assert torch.equal(a, b)
-    for a, b in zip(whole[3], split[3]):          # the passenger ran once, with the fill
-        assert torch.equal(a, b)
-    assert not torch.equal(whole[0], table0)
-    only_a = run([(True, 0, na)])                 # the late levels' rows are untouched until their part runs
-    lo = int(offsets[A])
-    assert torch.equal(only_a[0][lo:], table0[lo:]) and torch.equal(only_a[0][:lo], whole[0][:lo])
-
-
-def test_step_groups_split_by_levels_train_the_same_bits(lib, monkeypatch):
-    """The step groups with the encoder / table backward split at a level (NGP_LEVEL_SPLIT, the default) against the same run
-    without the split: the same table and MLP weights, bit for bit, after two density-grid refresh periods."""
-    from raw_ngp_amd.nerf.engine import FusedTrainer
-    from raw_ngp_amd.nerf.network import NeRFNetwork
-    from raw_ngp_amd.nerf.options import Options
-    from raw_ngp_amd.nerf.scene import SyntheticDataset
-    res = {}
-    for split in ("8", "0", "10,spread"):
-        monkeypatch.setenv("NGP_LEVEL_SPLIT", split)
-        torch.manual_seed(0)
-        opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True)
-        data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
-        eng = FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=1024 * 256)
-        assert (eng._level_split is not None) == (split != "0")
-        eng.train(40)
-        torch.cuda.synchronize()
-        assert any(isinstance(k, tuple) and k[0] == "multi" for k in eng.graphs)          # groups were replayed
-        res[split] = (eng.table.clone(), eng.w_flat.clone(), float(eng.loss))
-    for split in ("8", "10,spread"):
-        assert torch.equal(res[split][0], res["0"][0]) and torch.equal(res[split][1], res["0"][1])
-        np.testing.assert_allclose(res[split][2], res["0"][2], rtol=1e-5)
-    assert np.isfinite(res["8"][2])
-
-
 def test_step_over_the_live_sample_list_equals_the_step_over_all_samples(lib, monkeypatch):
     """The fused step's backward over the list of samples in front of the compositor's early stop (default) against the
     same step with the list switched off: identical samples and loss, the same gradient of the table and the MLP weights
