@@ -537,6 +537,15 @@ def main():
         SE3 = CAM.lie.se3_to_SE3(torch.from_numpy(wu))
         comp = CAM.pose.compose([SE3, a34])
     np.savez(os.path.join(args.out, "pose_lie.npz"), wu=wu, SE3=SE3.numpy(), other=a34.numpy(), composed=comp.numpy())
+    # ---------------------------------------------------------------- HDR loss weights (raw/raw_utils.py:30-53)
+    # what train_step multiplies the squared residuals with (train_utils.py:520-527): called as it calls them
+    import raw.raw_utils as RU
+    wrng = np.random.default_rng(17)
+    gt = wrng.uniform(0.0, 1.6, (257, 3)).astype(np.float32)
+    gt[:5] = [[0.0, 0.5, 1.0], [1.45, 1.4499, 1.4501], [-0.45, -0.4501, -0.4499], [0.05, 0.95, 0.5], [1.0, 1.0, 1.0]]
+    tg = torch.from_numpy(gt)
+    np.savez(os.path.join(args.out, "loss_weights.npz"), gt_rgb=gt, gaussian=RU.gaussian_weighting(tg).numpy(),
+             planck=RU.planck_taper_weighting(tg).numpy(), hanning=RU.hanning_weighting(tg).numpy())
     print("fixtures written to", args.out)
     for f in sorted(os.listdir(args.out)):
         print("  ", f, os.path.getsize(os.path.join(args.out, f)))

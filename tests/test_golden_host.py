@@ -41,6 +41,17 @@ def test_near_far_torch(golden_dir):
     assert (g["nears"] == 1e9).sum() > 0        # the fixture contains misses
 
 
+@pytest.mark.parametrize("kind", ["gaussian", "planck", "hanning"])
+def test_hdr_loss_weights_match_the_reference(golden_dir, kind):
+    """nerf.utils.hdr_loss_weight (what the per-op Trainer and the fused step multiply the HDR residuals with) against the
+    reference's raw_utils functions run on the same targets (raw/raw_utils.py:30-53, called as train_utils.py:520-527 does)."""
+    g = load(golden_dir, "loss_weights.npz")
+    w = U.hdr_loss_weight(kind, torch.from_numpy(g["gt_rgb"]))
+    assert w.shape == g[kind].shape and not w.requires_grad
+    np.testing.assert_allclose(w.numpy(), g[kind], rtol=2e-6, atol=1e-7)
+    assert U.hdr_loss_weight("none", torch.from_numpy(g["gt_rgb"])) is None
+
+
 def test_contract_roundtrip(golden_dir):
     g = load(golden_dir, "contract.npz")
     z = R.contract(torch.from_numpy(g["x"]))
