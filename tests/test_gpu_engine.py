@@ -137,7 +137,7 @@ def test_mse_backward_matches_autograd(lib, orc):
     lo = torch.zeros(1, device="cuda")
     e.composite_mse_backward(dev(gt), dev(bg), 0.0, tsig.detach(), trgb.detach(), dev(ts), dev(rays), ws.detach(),
                              dep.detach(), img.detach(), M, N, 1e-4, gs, gc, lo)
-    np.testing.assert_allclose(float(lo), float(loss), rtol=1e-5)
+    np.testing.assert_allclose(float(lo), float(loss.detach()), rtol=1e-5)
     covered = np.zeros(M, bool)
     for n in range(N):
         covered[rays[n, 0]:rays[n, 0] + rays[n, 1]] = True
@@ -171,7 +171,7 @@ def test_entropy_term_of_the_fused_compositor_step_matches_autograd(lib, lam):
     e.composite_train_live(dev(gt), None, 0.0, None, None, 1.0 / (3 * N), None, tsig.detach(), trgb.detach(), dev(ts), dev(rays),
                            M, N, 1e-4, ws2, dep2, img2, gs, gc, lo, lambda_entropy=lam)
     np.testing.assert_allclose(float(lo), float(loss.detach()), rtol=2e-5)
-    assert float(ent) > 0.05
+    assert float(ent.detach()) > 0.05
     covered = np.zeros(M, bool)
     for n in range(N):
         covered[rays[n, 0]:rays[n, 0] + rays[n, 1]] = True
