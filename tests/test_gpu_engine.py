@@ -235,7 +235,7 @@ def test_fused_step_matches_autograd_path(lib):
     tgt = gt[:, :3] * gt[:, 3:]
     loss = ((out["image"] - tgt) ** 2).mean(-1).mean()
     loss.backward()
-    np.testing.assert_allclose(float(eng.loss), float(loss), rtol=2e-4)
+    np.testing.assert_allclose(float(eng.loss), float(loss.detach()), rtol=2e-4)
     ref_t = model.grid_encoder.embeddings.grad
     ref_w = torch.cat([l.weight.grad.reshape(-1) for l in list(model.grid_mlp.net) + list(model.view_mlp.net)])
 

@@ -191,7 +191,7 @@ def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield, orien
         assert float(term.detach()) > 0, mse
     params = [l.weight for l in model.grid_mlp.net] + [l.weight for l in model.view_mlp.net]
     grads = torch.autograd.grad(loss, [xi] + params)
-    np.testing.assert_allclose(loss_fused, float(loss), rtol=2e-2)
+    np.testing.assert_allclose(loss_fused, float(loss.detach()), rtol=2e-2)
     # level window of that step: what the fused step used
     np.testing.assert_allclose(lw.cpu().numpy(),
                                Pm_window(model, opt), rtol=0, atol=2e-6)
