@@ -2,7 +2,9 @@
 """Benchmark of the hot path: training rays/s on a synthetic 800x800 Lego-style scene.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.  Started WITHOUT that environment and
+--gpus N > 1, the script launches the N ranks itself (child processes, before this process touches the GPU) or exits
+non-zero: it never reports a one-GPU number for an N-GPU request.
 
   step      = one optimiser step of the density-grid path: 4096 random rays -> near/far -> occupancy march
               -> hash-grid + SH encode -> tiny MLPs -> composite -> MSE -> backward (composite, MLPs, SH,
@@ -12,8 +14,11 @@ torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
   burn-in   = untimed training steps before the W warm-up steps, so that the 16 full density-grid sweeps
               are over and the occupancy grid has converged (metric definition):
               setup, not part of W or K.
-  roofline  = the dominant kernel of the step, timed live with HIP events around each of its launches
-              inside the timed region; algorithmic bytes per sample from SURVEY.md section 8d.  On one GPU that
+  roofline  = the dominant kernel of the step, timed live with HIP events around its launches in a PROBE TAIL: the
+              timed region itself carries no probes (a probed step splits its graph around the probed launches); right
+              after it -- same graphs' kernels, same scene state, the schedule simply continues -- `--probe-launches`
+              steps are probed, one in `--probe-every`, half way between two density-grid refreshes.  Algorithmic bytes
+              per sample from SURVEY.md section 8d.  On one GPU that
               launch also applies Adam to the table (fused into its reduce kernel): the optimiser's 24 B per
               table entry are then part of its algorithmic bytes (`optimizer_bytes_per_launch`; the figure without
               them is `frac_grid_only`).
@@ -164,7 +169,8 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
                   aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
                   dp_rehearsal=args.dp_rehearsal, dp_exchange=args.dp_exchange, group_steps=args.group_steps,
-                  dp_mode=args.dp_mode, **({"loss_scale": args.loss_scale} if args.loss_scale else {}))
+                  dp_mode=args.dp_mode, dynamic_loss_scale=not args.static_loss_scale,
+                  **({"loss_scale": args.loss_scale} if args.loss_scale else {}))
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
     fused = not (args.autograd or args.torch_mlp)
@@ -188,20 +194,15 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     probed = symbols + ((fwd_symbol,) if fused and fwd_symbol not in symbols else ())
     # (every probe_every-th step, in the middle of the period: with the default 16 these are the steps half way between two
     # density-grid refreshes -- a timed step splits its graphs around the probed launches, ~ 50 us the other steps do not pay)
-    _lib.set_probe(None if (args.no_probe or not probe_on) else probed, arg_idx, every=args.probe_every,
-                   phase=args.probe_every // 2)
-    if fused and trainer.xchg is not None and trainer.xchg.carrier != "none" and not args.no_probe and probe_on:
-        # HIP events around the collectives of the steps whose kernels are probed (the other steps replay them from inside
-        # their graphs, where nothing can be timed); switched on BEFORE the burn-in, so that the step variant with its
-        # collectives outside the graph is captured there and not inside the timed region
-        trainer.collective_events, trainer.collective_steps = [], 0
+    probing = probe_on and not args.no_probe
+    _lib.set_probe(None)                    # (the timed region carries no probes: they follow it, see `probe tail` below)
     # The fused engine replays runs of consecutive steps from hipGraphs whose shape depends on where a run starts inside the
     # 16-step density-grid cycle, on its length and on which steps are probed; a variant that is first needed inside the
     # timed region would be CAPTURED there (milliseconds of host time: the driver's 20-step region is 7 ms long).  So the
     # burn-in contains a dress rehearsal: the same number of steps, launched by the same call, a whole number of
     # refresh / probe periods before the timed region -- every graph the timed region replays has then been captured and
     # launched once, inside ordinary (untimed) burn-in training.  The schedule of steps is unchanged.
-    period = int(np.lcm(opt.update_extra_interval, max(args.probe_every, 1)))
+    period = int(opt.update_extra_interval)
     back = -(-(args.steps + args.warmup) // period) * period
     start = args.burnin + args.warmup                    # first step of the timed region
     if fused and start - back >= 2 * period:
@@ -220,9 +221,6 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     # ---- timed region -------------------------------------------------------------------------
     parallel.barrier()
     torch.cuda.synchronize()
-    _lib.probe_reset()
-    if fused and trainer.collective_events is not None:
-        trainer.collective_events, trainer.collective_steps = [], 0      # (forget the burn-in's measurements)
     seen0 = int(trainer.samples_seen) if fused else 0
     t0 = time.perf_counter()
     samples = 0
@@ -240,19 +238,10 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
-    collective_ms = None
-    if fused and getattr(trainer, "collective_events", None):
-        collective_ms = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / max(trainer.collective_steps, 1)
-        trainer.collective_events = None
-    probe = _lib.probe_results(symbols)
-    probe_fwd = _lib.probe_results((fwd_symbol,)) if fwd_symbol in probed else (0, 0, 0.0)
-    _lib.set_probe(None)
     overflow = False
     if fused:
         samples = int(trainer.samples_seen) - seen0
         overflow = int(trainer.arena.counter[1]) > trainer.cap
-        # live samples per launch (the launch argument is the arena capacity), scaled to the launches measured
-        probe = (probe[0], samples / max(args.steps, 1) * probe[0], probe[2])
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -271,13 +260,51 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
     psnr = None
     if args.psnr_iters > trainer.global_step:
         trainer.train(args.psnr_iters - trainer.global_step)
+    psnr_step = trainer.global_step
     if args.psnr_iters > 0:
         val = SyntheticDataset(opt, dev, "val", n_views=4, H=args.res, W=args.res)
         psnr = trainer.evaluate(val)
+    scaler_state = trainer.scaler.state() if fused and getattr(trainer, "scaler", None) is not None else None
+
+    # ---- probe tail: the roofline kernels under HIP events, untimed --------------------------------------------
+    # The schedule simply continues (same weights, same occupancy grid, the graphs' own kernels); one step in
+    # --probe-every is probed, half way between two density-grid refreshes, until --probe-launches launches are in.  A probed
+    # step splits its graph around the probed launches (~ 50 us it would cost the timed region).  Under data parallelism the
+    # collectives of the probed steps are timed the same way (they stay outside those steps' graphs).
+    probe, probe_fwd, collective_ms = (0, 0, 0.0), (0, 0, 0.0), None
+    if probing:
+        _lib.set_probe(probed, arg_idx, every=args.probe_every, phase=args.probe_every // 2)
+        tail = args.probe_every * (args.probe_launches + 2)
+        if fused and trainer.xchg is not None and trainer.xchg.carrier != "none":
+            trainer.collective_events, trainer.collective_steps = [], 0
+        trainer.train(2 * args.probe_every)               # (the probed variants of the step are captured here)
+        torch.cuda.synchronize()
+        _lib.probe_reset()
+        if fused and trainer.collective_events is not None:
+            trainer.collective_events, trainer.collective_steps = [], 0
+        seen1 = int(trainer.samples_seen) if fused else 0
+        if fused:
+            trainer.train(tail - 2 * args.probe_every)
+        else:
+            for _ in range(tail - 2 * args.probe_every):
+                trainer.train_step()
+        torch.cuda.synchronize()
+        if fused and getattr(trainer, "collective_events", None):
+            collective_ms = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / max(trainer.collective_steps, 1)
+        if fused:
+            trainer.collective_events = None
+        probe = _lib.probe_results(symbols)
+        probe_fwd = _lib.probe_results((fwd_symbol,)) if fwd_symbol in probed else (0, 0, 0.0)
+        _lib.set_probe(None)
+        if fused:
+            # live samples per launch (the launch argument is the arena capacity): the tail's own average
+            per_step = (int(trainer.samples_seen) - seen1) / max(tail - 2 * args.probe_every, 1)
+            probe = (probe[0], per_step * probe[0], probe[2])
+            probe_fwd = (probe_fwd[0], per_step * probe_fwd[0], probe_fwd[2])
 
     return dict(dt=dt, host=host, samples=samples, probe=probe, probe_fwd=probe_fwd, probed=probed, fwd_symbol=fwd_symbol,
                 bytes_per_sample=bytes_per_sample, in_sync=in_sync, psnr=psnr, trainer=trainer, fused=fused,
-                collective_ms=collective_ms,
+                collective_ms=collective_ms, psnr_step=psnr_step, scaler_state=scaler_state,
                 untrained_cells=untrained_cells, overflow=bool(fused and overflow), model=model)
 
 
@@ -324,6 +351,27 @@ def run_config4(args, dev):
     return out
 
 
+def launch_ranks(n):
+    """`--gpus n` without torchrun's environment: start the n ranks as CHILD processes of this one (torch.distributed.run,
+    one per GPU, rendezvous on 127.0.0.1) and return their exit code.  Called before anything in this process has
+    initialised the GPU -- counting devices does not -- and never as an exec; the children print the JSON line."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and "NGP_LOCAL_DEVICE" not in os.environ:
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); refusing to report a smaller job under that name "
+              "(rehearsal on one device: NGP_DIST_BACKEND=gloo NGP_LOCAL_DEVICE=0)", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sock:           # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -356,7 +404,10 @@ def main():
                     help="fused step: consecutive steps per captured graph (1 = one graph launch per step)")
     ap.add_argument("--precapture", action="store_true", help="capture step groups of every length up front instead of 2/4/8 on demand")
     ap.add_argument("--probe-every", type=int, default=16,
-                    help="time every N-th launch of the roofline entry point with HIP events (each timed launch drains the queue)")
+                    help="probe tail: time every N-th launch of the roofline entry points with HIP events (16 = the step half way "
+                         "between two density-grid refreshes)")
+    ap.add_argument("--probe-launches", type=int, default=12,
+                    help="probe tail: how many launches of each roofline entry point to time after the timed region")
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event roofline probe (roofline: null)")
     ap.add_argument("--no-graph", action="store_true", help="fused step: launch kernels one by one (no hipGraph replay)")
     ap.add_argument("--torch-sampler", action="store_true", help="fused step: draw rays with torch ops (implies no graph)")
@@ -365,7 +416,9 @@ def main():
                     help="separate Adam pass over the table (what data-parallel ranks run), on one GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--loss-scale", type=float, default=0.0,
-                    help="static loss scale of the fused MLP backward's f16 deltas (0 = the Options default)")
+                    help="(initial) loss scale of the fused MLP backward's f16 deltas (0 = the Options default, 2^16)")
+    ap.add_argument("--static-loss-scale", action="store_true",
+                    help="keep the loss scale fixed (deltas saturate) instead of GradScaler's rule on the device")
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"],
                     help="data parallel: wire format of the table-gradient all-reduce")
     ap.add_argument("--dp-mode", default="shard", choices=["shard", "allreduce"],
@@ -386,8 +439,13 @@ def main():
 
     if args.dp_rehearsal:
         os.environ["NGP_DP_REHEARSAL"] = "1"
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        # not under a launcher: become one (children do the work), or fail -- never a 1-GPU line for an N-GPU request
+        sys.exit(launch_ranks(args.gpus))
     rank, world, local = parallel.init_from_env("cuda")
-    assert world == max(args.gpus, 1) or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != max(args.gpus, 1):
+        print(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr, flush=True)
+        sys.exit(2)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     _lib.load()
@@ -404,14 +462,16 @@ def main():
     probed, fwd_symbol, bytes_per_sample, in_sync, psnr = (res["probed"], res["fwd_symbol"], res["bytes_per_sample"],
                                                            res["in_sync"], res["psnr"])
     trainer, fused, untrained_cells, overflow = res["trainer"], res["fused"], res["untrained_cells"], res["overflow"]
-    collective_ms = res["collective_ms"]
+    collective_ms, psnr_step, scaler_state = res["collective_ms"], res["psnr_step"], res["scaler_state"]
     # what the JSON line needs from the primary run's trainer (it is freed before the secondary runs)
     tinfo = {"fuse_adam": bool(fused and getattr(trainer, "fuse_adam", False)),
              "table_numel": int(trainer.table.numel()) if fused else 0,
              "graph": bool(fused and trainer.use_graph), "prefetch": bool(fused and trainer.prefetch),
              "device_sampler": bool(fused and trainer.device_sampler), "cap": trainer.cap if fused else 0,
-             "step": trainer.global_step,
+             "step": psnr_step,
              "dp_exchange": trainer.xchg.carrier if fused and getattr(trainer, "xchg", None) is not None else None}
+    if fused:
+        trainer.close()
     del res, trainer
     # the reference's own defaults as secondary rows (main.py:31,46: --bound 2, black background): same schedule and
     # timing protocol, no probes.  The headline stays the benchmark framing (bound 1, random background).
@@ -428,6 +488,8 @@ def main():
                                "host_enqueue_ms_per_step": round(r2["host"] / max(args.steps, 1) * 1e3, 4),
                                "psnr": None if r2["psnr"] is None else round(float(r2["psnr"]), 3),
                                "arena_overflow": r2["overflow"], "untrained_cells": r2["untrained_cells"]}
+            if r2["fused"]:
+                r2["trainer"].close()
             del r2
         if world == 1 and not (args.autograd or args.torch_mlp):
             torch.cuda.empty_cache()
@@ -453,13 +515,14 @@ def main():
                     "traffic_source": ("FETCH_SIZE + WRITE_SIZE measured on this script's steady state (profiles/r03_pmc_bench_"
                                        "traffic.csv), per-sample part scaled to this run's samples"
                                        + (", plus the optimiser's 24 B per table entry" if fused_adam else "")),
-                    "launches": launches, "timed_every": args.probe_every, "avg_us": round(ksec / launches * 1e6, 2),
+                    "launches": launches, "timed": f"probe tail after the timed region and the PSNR evaluation, one step in "
+                                                   f"{args.probe_every}", "avg_us": round(ksec / launches * 1e6, 2),
                     "bytes_per_sample": bytes_per_sample, "samples_per_launch": round(units / launches),
                     "optimizer_bytes_per_launch": opt_bytes, "achieved_grid_only": round(grid_only, 1),
                     "frac_grid_only": round(grid_only / HBM_PEAK_GBPS, 4)}
         roof_fwd = None
         if fused and probe_fwd[0]:
-            per_launch = samples / max(args.steps, 1)
+            per_launch = probe_fwd[1] / probe_fwd[0]
             ach = per_launch * FWD_BYTES_PER_SAMPLE * probe_fwd[0] / probe_fwd[2] / 1e9
             roof_fwd = {"bound": "hbm", "kernel": fwd_symbol, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
@@ -492,7 +555,9 @@ def main():
                        "graph": tinfo["graph"], "group_steps": args.group_steps, "prefetch": tinfo["prefetch"],
                        "device_sampler": tinfo["device_sampler"],
                        "host_enqueue_ms_per_step": round(host / max(args.steps, 1) * 1e3, 4),
-                       "untrained_cells": untrained_cells, "arena_capacity": tinfo["cap"], "arena_overflow": bool(fused and overflow)},
+                       "untrained_cells": untrained_cells, "arena_capacity": tinfo["cap"], "arena_overflow": bool(fused and overflow),
+                       # torch.cuda.amp.GradScaler's rule on the device (train_utils.py:404,897-904): state at the PSNR iteration
+                       "loss_scaler": scaler_state},
             "roofline": roof, "roofline_forward": roof_fwd, "cpu_baseline": cpu,
             "secondary": secondary or None,
         }

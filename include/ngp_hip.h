@@ -251,7 +251,7 @@ int ngp_x_grid_backward_binned_apply(const float *grad, const float *inputs, con
                                      int align_corners, uint32_t interp, uint32_t n_rows_total, uint32_t max_level_rows,
                                      void *workspace, size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
                                      float *adam_exp_avg_sq, const float *adam_hyper, float beta1, float beta2,
-                                     float eps, int overwrite, ngp_stream_t stream);
+                                     float eps, int overwrite, float *loss_scaler, ngp_stream_t stream);
 /* ngp_x_grid_backward_binned_apply over a LIST of samples (see ngp_x_grid_backward_binned_apply_mlp_list) */
 int ngp_x_grid_backward_binned_apply_list(const float *grad, const float *inputs, const int32_t *sample_index,
                                           const int32_t *offsets, float *grad_embeddings, const int32_t *B_dev, uint32_t B,
@@ -260,7 +260,7 @@ int ngp_x_grid_backward_binned_apply_list(const float *grad, const float *inputs
                                           uint32_t max_level_rows, void *workspace, size_t workspace_bytes,
                                           float *adam_param, float *adam_exp_avg, float *adam_exp_avg_sq,
                                           const float *adam_hyper, float beta1, float beta2, float eps, int overwrite,
-                                          ngp_stream_t stream);
+                                          float *loss_scaler, ngp_stream_t stream);
 /* ngp_x_grid_backward_binned_apply with ngp_x_mlp_reduce_dw riding along (its arguments, mlp_ prefix, same meaning and
  * checks): the weight-gradient reduction of the fused MLP runs as extra workgroups of the fill kernel instead of as a
  * kernel of its own -- one launch and one dependent-launch gap fewer on the fused step's critical path.  Nothing in the
@@ -273,7 +273,7 @@ int ngp_x_grid_backward_binned_apply_mlp(
     uint32_t mlp_M, float mlp_loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6,
     const void *mlp_workspace, size_t mlp_workspace_bytes, float *mlp_adam_param, const float *mlp_adam_grad,
     float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq, uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1,
-    float mlp_beta2, float mlp_eps, void *mlp_adam_image, ngp_stream_t stream);
+    float mlp_beta2, float mlp_eps, void *mlp_adam_image, float *loss_scaler, ngp_stream_t stream);
 /* ngp_x_grid_backward_binned_apply_mlp over a LIST of samples (tile-local layout only): entry b of the call is sample
  * sample_index[b] -- `inputs` is addressed by sample, the gradient slab `grad` is in list order (as ngp_x_mlp_backward_list
  * writes it), *B_dev entries are used.  NULL: samples 0 .. B - 1. */
@@ -286,11 +286,16 @@ int ngp_x_grid_backward_binned_apply_mlp_list(
     float *dw3, float *dw4, float *dw5, float *dw6, const void *mlp_workspace, size_t mlp_workspace_bytes,
     float *mlp_adam_param, const float *mlp_adam_grad, float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq,
     uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1, float mlp_beta2, float mlp_eps, void *mlp_adam_image,
-    ngp_stream_t stream);
+    float *loss_scaler, ngp_stream_t stream);
 /* overwrite != 0 (workspace prepared with single_segment, max_level == L): grad_embeddings = sums for EVERY row of every
  * level (zeros where nothing landed) instead of +=, so the caller neither zeroes the gradient nor pays its read.
  * overwrite == 2: the same, stored as bfloat16 (round to nearest even) -- grad_embeddings then points to
  * n_rows_total * C 16-bit values, the wire format of the data-parallel gradient exchange. */
+/* loss_scaler (NULL: none): the dynamic loss scale of the fused MLP backward (see "Dynamic loss scale" below).  The reduce
+ * launch settles the step: a non-finite feature gradient anywhere in the batch raises the scaler's overflow word; with the
+ * fused Adam the table is left alone when that word is set (by this launch or by the weight-gradient reduction); in the
+ * _mlp variants with mlp_adam_param the MLP weights' Adam step (and their operand-image entries) moves from the fill
+ * launch's passengers to passengers of the reduce launch, so that it falls under the same verdict. */
 /* adam_param != NULL (single GPU, no weight decay / TV on the table): the gradient of a chunk never leaves LDS -- the
  * reduce kernel applies torch.optim.Adam to the chunk's rows of `adam_param` directly (hyper as in
  * ngp_x_adam_step_dev) and grad_embeddings is neither read nor written.  Requires a workspace prepared with
@@ -331,7 +336,17 @@ int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float *dirs, cons
  * layout of `enc` (rows >= M untouched) and the six weight gradients (fp32, torch layout, OVERWRITTEN).
  * Activations are recomputed from enc / dirs; nothing from the forward call is needed.  `loss_scale`
  * multiplies the incoming deltas before they become f16 operands and is divided out of every output
- * (the role GradScaler plays in the reference's --fp16 path, train_utils.py:404,897); 1024 is a good value.
+ * (the role GradScaler plays in the reference's --fp16 path, train_utils.py:404,897); deltas saturate at +-65504.
+ *
+ * Dynamic loss scale (`loss_scaler`, the _list / reduce / apply entry points; NULL: the static `loss_scale` above): eight
+ * 32-bit device words owned by the caller -- [0] f32 scale, [1] f32 1 / scale, [2] u32 overflow seen in the current step,
+ * [3] u32 clean steps since the scale last changed, [4] u32 optimiser steps taken, [5] u32 steps skipped, [6] u32 a step
+ * has run, [7] reserved; initialise to {S, 1 / S, 0, 0, 0, 0, 0, 0}.  The backward kernels read [0] / [1] and let an
+ * overflowing delta become inf (no saturation): it makes the weight gradient of its layer non-finite, the reduction of the
+ * weight gradients raises [2], every optimiser kernel that is handed the words (or &[2] as `skip`) leaves its parameters
+ * alone, and ngp_x_step_begin of the NEXT step halves the scale (or doubles it after growth_interval clean steps) and
+ * advances Adam's t only for steps that were taken: torch.cuda.amp.GradScaler's scale / step / update
+ * (train_utils.py:404,897-904) without a host read.
  * workspace: ngp_x_mlp_backward_workspace_bytes(M) bytes, 16-byte aligned. */
 size_t ngp_x_mlp_backward_workspace_bytes(uint32_t M);
 int ngp_x_mlp_backward(const float *enc, uint32_t stride, const float *dirs, const float *dsigma,
@@ -355,7 +370,7 @@ int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const float *dirs
                             const float *drgb, const int32_t *M_dev, uint32_t M, const int32_t *sample_index,
                             const void *image, float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2,
                             float *dw3, float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
-                            ngp_stream_t stream);
+                            float *loss_scaler, ngp_stream_t stream);
 /* d h0 / d enc for samples 0 .. M - 1 (level-major slab like `enc`), h0 = the density network's first output, sigma =
  * trunc_exp(h0) (nerf/network.py:111-118): the MLP's part of torch.autograd.grad(sigma, pos) in the orientation term
  * (nerf/renderer.py:558-566).  The f16 chain of the backward's density kernel with delta = e_0; no weight gradients. */
@@ -370,11 +385,13 @@ int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, fl
                         float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
                         const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,
                         const float *adam_hyper, float beta1, float beta2, float eps, void *adam_image,
-                        ngp_stream_t stream);
+                        float *loss_scaler, ngp_stream_t stream);
 /* adam_param != NULL: dw1..dw6 are views of the flat buffer adam_grad (adam_n floats) and every element is also pushed
  * through ngp_x_adam_step_dev's update of adam_param / exp_avg / exp_avg_sq as it comes out of the reduction.
  * adam_image != NULL (an image ngp_x_mlp_prepare has filled once): each updated weight is also written, as f16, to its
- * two places in the operand image, so the next forward needs no prepare pass. */
+ * two places in the operand image, so the next forward needs no prepare pass.
+ * loss_scaler != NULL: 1 / scale comes from it, non-finite sums raise its overflow word, and Adam (if asked for) runs as a
+ * second launch that is skipped when the word is set. */
 
 /* ------------------------------------------------------------------------------------
  * The same fused field for the light-conditioned configuration (`--rfield`, nerf/network.py:55-56,111-143:
@@ -405,7 +422,7 @@ int ngp_x_mlp_rf_backward_list(const float *enc, uint32_t stride, const float *d
                                const float *dsigma, const float *drgb, const int32_t *M_dev, uint32_t M,
                                const int32_t *sample_index, const void *image, float loss_scale, float *denc, float *ddirs,
                                float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6, void *workspace,
-                               size_t workspace_bytes, ngp_stream_t stream);
+                               size_t workspace_bytes, float *loss_scaler, ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Kernels of the fused training step (csrc/engine_kernels.hip; host side raw_ngp_amd/nerf/engine.py).
@@ -496,14 +513,16 @@ int ngp_x_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq
  * ngp_x_schedule_step earlier on the stream): no host scalar changes between steps, so the launch can be replayed
  * from a captured graph. */
 int ngp_x_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, const float *hyper,
-                        float beta1, float beta2, float eps, int zero_grad, ngp_stream_t stream);
+                        float beta1, float beta2, float eps, int zero_grad, const uint32_t *skip, ngp_stream_t stream);
+/* skip (NULL: never): a device word; non-zero = leave everything alone (the step saw a non-finite gradient: word [2] of the
+ * dynamic loss scale -- GradScaler.step, train_utils.py:897) */
 /* Two parameter tensors in one launch (the hash table and the flat MLP weights).  grad_a_bf16 != 0: grad_a points
  * to n_a bfloat16 values (the data-parallel wire format written by ngp_x_grid_backward_binned_apply with
  * overwrite = 2 and averaged over the ranks in place); it is then never zeroed. */
 int ngp_x_adam_step_dev2(float *param_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a, uint64_t n_a,
                          int zero_grad_a, float *param_b, float *grad_b, float *exp_avg_b, float *exp_avg_sq_b,
                          uint64_t n_b, int zero_grad_b, const float *hyper, float beta1, float beta2, float eps,
-                         int grad_a_bf16, ngp_stream_t stream);
+                         int grad_a_bf16, const uint32_t *skip, ngp_stream_t stream);
 
 /* Device-side scheduler: t = step_counter[0] steps are done; writes hyper = {lr0 * 0.1^min(t/decay_steps, 1)
  * (the LambdaLR of main.py:261), 1 - beta1^(t+1), 1/sqrt(1 - beta2^(t+1))} and increments the counter. */
@@ -513,7 +532,12 @@ int ngp_x_schedule_step(uint32_t *step_counter, float *hyper, double lr0, double
  * backward accumulates into it) and samples_seen[0] += sample_counter[0]; each pair may be NULL. */
 int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1, double beta2,
                      float *loss_out, int64_t *samples_seen, const int32_t *sample_counter, void *binned_workspace,
-                     uint32_t L, uint32_t n_rows_total, int single_segment, ngp_stream_t stream);
+                     uint32_t L, uint32_t n_rows_total, int single_segment, float *loss_scaler, double growth, double backoff,
+                     uint32_t growth_interval, ngp_stream_t stream);
+/* loss_scaler != NULL (the eight words of the dynamic loss scale): the PREVIOUS step is settled first -- overflow: scale *=
+ * backoff, tracker = 0, skipped + 1; else taken + 1 and, after growth_interval clean steps, scale *= growth (GradScaler's
+ * defaults: 2, 0.5, 2000) -- and the bias corrections follow the optimiser steps taken instead of the step counter (the
+ * learning rate follows the step counter either way: lr_scheduler.step() is unconditional, train_utils.py:906-907). */
 /* binned_workspace != NULL: the same launch also does ngp_x_grid_backward_binned_prepare(stage 2) on that workspace
  * (L levels, n_rows_total table rows) -- call it after the encoder's counting forward pass. */
 
@@ -523,7 +547,8 @@ int ngp_x_mlp_forward_step_begin(const float *enc, uint32_t stride, const float 
                                  const void *image, float *sigma, float *rgb, uint32_t *step_counter, float *hyper,
                                  double lr0, double decay_steps, double beta1, double beta2, float *loss_out,
                                  int64_t *samples_seen, const int32_t *sample_counter, void *binned_workspace, uint32_t L,
-                                 uint32_t n_rows_total, int single_segment, ngp_stream_t stream);
+                                 uint32_t n_rows_total, int single_segment, float *loss_scaler, double growth,
+                                 double backoff, uint32_t growth_interval, ngp_stream_t stream);
 
 /* counter[0] += delta, stream-ordered. */
 int ngp_x_counter_add(uint32_t *counter, uint32_t delta, ngp_stream_t stream);
@@ -609,7 +634,9 @@ int ngp_x_orientation_term(const float *dh_denc, const float *dydx, uint32_t str
  *                     compose(exp(xi), base) (barf/camera.py:47-63,91-102).  grad_pose != NULL: first one
  *                     torch.optim.Adam step on xi (lr = lr0 * gamma^step, bias corrections from step + 1, step = flags[1])
  *                     when flags[0] != 0, with d loss / d xi by forward-mode differentiation of the exponential map;
- *                     grad_xi (optional) receives that gradient */
+ *                     grad_xi (optional) receives that gradient; loss_scaler (optional, the eight words of the dynamic
+ *                     loss scale): no step when its overflow word is set, Adam's t counts the steps taken
+ *                     (train_utils.py:898-899: the pose optimiser goes through the same GradScaler) */
 int ngp_x_step_window(const uint32_t *step_counter, uint32_t step_offset, double iters, float start_annealing,
                       float end_annealing, uint32_t L, float *level_w, int32_t *flags, ngp_stream_t stream);
 /* ... the BAA-NGP window (network.py:77-97): level 0 always counts, level j >= 1 ramps in like the (j - 1)-th of L - 1 levels;
@@ -640,7 +667,7 @@ int ngp_x_pose_gradient(const int32_t *index, const float *grad_rays_o, const fl
                         uint32_t W, float fx, float fy, float cx, float cy, float *grad_pose, ngp_stream_t stream);
 int ngp_x_pose_update(float *xi, const float *base, const float *grad_pose, uint32_t V, const int32_t *flags,
                       float *exp_avg, float *exp_avg_sq, float lr0, float gamma, float beta1, float beta2, float eps,
-                      float *refined, float *grad_xi, ngp_stream_t stream);
+                      float *refined, float *grad_xi, const float *loss_scaler, ngp_stream_t stream);
 
 /* The slab test NeRFRenderer.run_cuda actually uses (the torch function, nerf/renderer.py:139-158, not the
  * CUDA kernel): divides by (d + 1e-15), marks a miss with near = far = 1e9. */

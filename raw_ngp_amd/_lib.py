@@ -46,31 +46,32 @@ _SIGNATURES = {
     "ngp_x_grid_backward_binned_prepare": [_p, _f, _p, _p, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _i, _u, _i, _p,
                                            ctypes.c_size_t],
     "ngp_x_grid_backward_binned_apply": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
-                                         ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i],
+                                         ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i, _p],
     "ngp_x_grid_backward_binned_apply_list": [_p, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
-                                              ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i],
+                                              ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i, _p],
     "ngp_x_grid_backward_binned_apply_mlp": [_p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
                                              ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i,
                                              _u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f,
-                                             _f, _f, _p],
+                                             _f, _f, _p, _p],
     "ngp_x_grid_backward_binned_apply_mlp_list": [_p, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _u, _u, _p,
                                                   ctypes.c_size_t, _p, _p, _p, _p, _f, _f, _f, _i,
                                                   _u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p,
-                                                  _f, _f, _f, _p],
+                                                  _f, _f, _f, _p, _p],
     "ngp_x_grid_input_backward": [_p, _p, _p, _u, _u, _u, _u, _i],
     "ngp_x_grid_encode_forward_jac": [_p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _p, _u, _i, _u, _i],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_mlp_backward_dirs": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
-    "ngp_x_mlp_backward_list": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
-    "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f, _f, _f, _p],
+    "ngp_x_mlp_backward_list": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t,
+                                _p],
+    "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f, _f, _f, _p, _p],
     "ngp_x_mlp_rf_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_rf_forward": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_rf_backward": [_p, _u, _p, _p, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                               ctypes.c_size_t],
     "ngp_x_mlp_rf_backward_list": [_p, _u, _p, _p, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                   ctypes.c_size_t],
+                                   ctypes.c_size_t, _p],
     "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
     "ngp_x_grid_encode_forward_slab_jac": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p],
     "ngp_x_grid_encode_forward_slab_placed": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p, _p],
@@ -94,7 +95,7 @@ _SIGNATURES = {
     "ngp_x_ray_gradients": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_ray_gradients_list": [_p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_pose_gradient": [_p, _p, _p, _u, _u, _u, _f, _f, _f, _f, _p],
-    "ngp_x_pose_update": [_p, _p, _p, _u, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p],
+    "ngp_x_pose_update": [_p, _p, _p, _u, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p, _p],
     "ngp_x_composite_rays_train_forward": [_p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p],
     "ngp_x_composite_rays_train_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p],
     "ngp_x_composite_mse_backward": [_p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p],
@@ -102,11 +103,12 @@ _SIGNATURES = {
     "ngp_x_composite_mse_train_idx": [_p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "ngp_x_adam_step": [_p, _p, _p, _p, ctypes.c_uint64, _f, _d, _d, _f, _u, _i],
     "ngp_x_near_far_from_aabb_v2": [_p, _p, _p, _u, _f, _p, _p],
-    "ngp_x_adam_step_dev": [_p, _p, _p, _p, ctypes.c_uint64, _p, _f, _f, _f, _i],
+    "ngp_x_adam_step_dev": [_p, _p, _p, _p, ctypes.c_uint64, _p, _f, _f, _f, _i, _p],
     "ngp_x_schedule_step": [_p, _p, _d, _d, _d, _d],
-    "ngp_x_step_begin": [_p, _p, _d, _d, _d, _d, _p, _p, _p, _p, _u, _u, _i],
-    "ngp_x_mlp_forward_step_begin": [_p, _u, _p, _p, _u, _p, _p, _p, _p, _p, _d, _d, _d, _d, _p, _p, _p, _p, _u, _u, _i],
-    "ngp_x_adam_step_dev2": [_p, _p, _p, _p, ctypes.c_uint64, _i, _p, _p, _p, _p, ctypes.c_uint64, _i, _p, _f, _f, _f, _i],
+    "ngp_x_step_begin": [_p, _p, _d, _d, _d, _d, _p, _p, _p, _p, _u, _u, _i, _p, _d, _d, _u],
+    "ngp_x_mlp_forward_step_begin": [_p, _u, _p, _p, _u, _p, _p, _p, _p, _p, _d, _d, _d, _d, _p, _p, _p, _p, _u, _u, _i,
+                                     _p, _d, _d, _u],
+    "ngp_x_adam_step_dev2": [_p, _p, _p, _p, ctypes.c_uint64, _i, _p, _p, _p, _p, ctypes.c_uint64, _i, _p, _f, _f, _f, _i, _p],
     "ngp_x_counter_add": [_p, _u],
     "ngp_x_sample_rays": [_p, _u, _u, _u, _u, _p, _f, _f, _f, _f, _u, ctypes.c_uint64, _p, _u, _p, _p, _p, _p, _p, _p],
     "ngp_x_march_rays_train_backward": [_p, _p, _p, _p, _u, _u, _p, _p],
@@ -185,6 +187,40 @@ def _ptr(t, kind, name, optional=False):
     if t.dtype != _DT[kind]:
         raise RuntimeError(f"{name} must be a {_DT[kind]} tensor, got {t.dtype}")
     return t.data_ptr()
+
+
+class LossScaler:
+    """torch.cuda.amp.GradScaler's state as eight device words the kernels read and settle themselves (include/ngp_hip.h,
+    "Dynamic loss scale"; the reference: train_utils.py:404,897-904).  Defaults are GradScaler's: 2^16, x2 after 2000
+    clean steps, x0.5 on overflow.  Nothing here reads the device; `state()` does, for logging and tests."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.words = torch.zeros(8, dtype=torch.float32, device=device)
+        self.words[0], self.words[1] = float(init_scale), 1.0 / float(init_scale)
+        self.counters = self.words.view(torch.int32)
+        self.found = self.counters[2:3]             # the `skip` word of the optimiser kernels
+        self.growth, self.backoff, self.interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+
+    def state(self):
+        w, c = self.words.tolist(), self.counters.tolist()      # host read
+        return dict(scale=w[0], found_inf=c[2], growth_tracker=c[3], steps_taken=c[4], steps_skipped=c[5])
+
+
+def _scaler_ptr(scaler):
+    """Device pointer of a LossScaler's words (or of a bare 8-element float32 tensor); None passes through."""
+    if scaler is None:
+        return None
+    words = scaler.words if isinstance(scaler, LossScaler) else scaler
+    if words.dtype != torch.float32 or words.numel() < 8:
+        raise RuntimeError("loss scaler: eight float32 device words expected")
+    return _ptr(words, "f", "loss_scaler")
+
+
+def _scaler_args(scaler):
+    """(words, growth, backoff, growth_interval) as the step_begin entry points take them."""
+    if scaler is None:
+        return None, 2.0, 0.5, 2000
+    return _scaler_ptr(scaler), scaler.growth, scaler.backoff, scaler.interval
 
 
 # Optional per-entry-point probe (bench.py): HIP events recorded on the launch stream around every call of ONE
@@ -372,14 +408,17 @@ class _GridBackend:
     @staticmethod
     def grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
                                    workspace, gridtype=0, align_corners=False, interp=0, adam=None, overwrite=False,
-                                   mlp_tail=None, sample_index=None):
+                                   mlp_tail=None, sample_index=None, scaler=None):
         """Fill + reduce on a workspace prepared for the same positions.  adam = (param, exp_avg, exp_avg_sq, hyper,
         beta1, beta2, eps): apply the optimiser inside the reduce kernel instead of writing grad_embeddings.
         overwrite: grad_embeddings = sums for every row (no +=); a bfloat16 grad_embeddings selects the 16-bit store.
         mlp_tail = (M, loss_scale, dws, workspace, adam, image), the arguments of mlp_backend.reduce_dw: that reduction
         rides along as extra workgroups of the fill kernel (ngp_x_grid_backward_binned_apply_mlp).
         sample_index (int32): the call runs over a LIST of samples -- `inputs` by sample, `grad` in list order,
-        B_dev[0] entries (ngp_x_grid_backward_binned_apply_mlp_list / ..._apply_list)."""
+        B_dev[0] entries (ngp_x_grid_backward_binned_apply_mlp_list / ..._apply_list).
+        scaler: the eight device words of the dynamic loss scale (LossScaler.words); the reduce launch then settles the
+        step -- overflow word, table untouched on overflow, the MLP weights' Adam step as ITS passengers."""
+        sc = _scaler_ptr(scaler)
         n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
         wire16 = grad_embeddings is not None and grad_embeddings.dtype == torch.bfloat16
         if wire16 and not overwrite:
@@ -397,9 +436,9 @@ class _GridBackend:
         if mlp_tail is None:
             if sample_index is not None:
                 _call("ngp_x_grid_backward_binned_apply_list", grad, *args[:2], _ptr(sample_index, "i", "sample_index"), *args[2:],
-                      probe_as="ngp_x_grid_backward_binned_apply", probe_shift=1)
+                      sc, probe_as="ngp_x_grid_backward_binned_apply", probe_shift=1)
             else:
-                _call("ngp_x_grid_backward_binned_apply", grad, *args)
+                _call("ngp_x_grid_backward_binned_apply", grad, *args, sc)
             return
         M, loss_scale, dws, mlp_ws, mlp_adam, image = mlp_tail
         mextra = [None, None, None, None, 0, None, 0.0, 0.0, 0.0]
@@ -409,7 +448,7 @@ class _GridBackend:
                       _ptr(v_, "f", "mlp_adam_exp_avg_sq"), g_.numel(), _ptr(hyper, "f", "mlp_adam_hyper"), float(b1),
                       float(b2), float(eps)]
         tail = [M, float(loss_scale), *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], mlp_ws.data_ptr(), mlp_ws.numel(),
-                *mextra, image.data_ptr() if image is not None else None]
+                *mextra, image.data_ptr() if image is not None else None, sc]
         if sample_index is not None:
             # (the probe and the engine know the operation by ONE name: the list variant reports as the plain one)
             _call("ngp_x_grid_backward_binned_apply_mlp_list", grad, *args[:2], _ptr(sample_index, "i", "sample_index"), *args[2:],
@@ -616,13 +655,14 @@ class _MlpBackend:
         if step_begin is None:
             _call("ngp_x_mlp_forward", enc, *args)
             return
-        ctr, hyper, lr0, decay, b1, b2, loss_out, seen, counter, ws, L, n_rows, single = step_begin
+        ctr, hyper, lr0, decay, b1, b2, loss_out, seen, counter, ws, L, n_rows, single, *scaling = step_begin
         if seen is not None and (seen.dtype != torch.int64 or not seen.is_cuda):
             raise RuntimeError("samples_seen must be an int64 CUDA tensor")
         _call("ngp_x_mlp_forward_step_begin", enc, *args, _ptr(ctr, "u", "step_counter"), _ptr(hyper, "f", "hyper"),
               float(lr0), float(decay), float(b1), float(b2), _ptr(loss_out, "f", "loss_out", True),
               seen.data_ptr() if seen is not None else None, _ptr(counter, "i", "sample_counter", True),
-              ws.data_ptr() if ws is not None else None, int(L), int(n_rows), int(bool(single)))
+              ws.data_ptr() if ws is not None else None, int(L), int(n_rows), int(bool(single)),
+              *_scaler_args(scaling[0] if scaling else None))
 
 
     @staticmethod
@@ -631,11 +671,12 @@ class _MlpBackend:
 
     @staticmethod
     def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws, workspace=None, ddirs=None,
-                 sample_index=None):
+                 sample_index=None, scaler=None):
         """dws: six pre-allocated fp32 tensors shaped like the weights (overwritten), or None to leave the partial
         sums in `workspace` for reduce_dw().  workspace: uint8 tensor of backward_workspace_bytes(M) (allocated per
         call when omitted).  ddirs [M,3] (optional): d loss / d (un-normalised view direction).  sample_index (int32,
-        optional): run over a LIST of M_dev[0] samples; enc / dirs / dsigma / drgb by sample, denc in list order."""
+        optional): run over a LIST of M_dev[0] samples; enc / dirs / dsigma / drgb by sample, denc in list order.
+        scaler: the device words of the dynamic loss scale (LossScaler.words) instead of the static `loss_scale`."""
         nbytes = load().ngp_x_mlp_backward_workspace_bytes(M)
         ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
         if ws.numel() < nbytes or not ws.is_cuda:
@@ -643,9 +684,9 @@ class _MlpBackend:
         grads = [_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)] if dws is not None else [None] * 6
         head = (_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"), _ptr(dsigma, "f", "dsigma"), _ptr(drgb, "f", "drgb"),
                 _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"))
-        if sample_index is not None:
-            _call("ngp_x_mlp_backward_list", enc, *head[:7], _ptr(sample_index, "i", "sample_index"), *head[7:],
-                  _ptr(ddirs, "f", "ddirs", True), *grads, ws.data_ptr(), nbytes)
+        if sample_index is not None or scaler is not None:
+            _call("ngp_x_mlp_backward_list", enc, *head[:7], _ptr(sample_index, "i", "sample_index", True), *head[7:],
+                  _ptr(ddirs, "f", "ddirs", True), *grads, ws.data_ptr(), nbytes, _scaler_ptr(scaler))
         elif ddirs is not None:
             _call("ngp_x_mlp_backward_dirs", enc, *head, _ptr(ddirs, "f", "ddirs"), *grads, ws.data_ptr(), nbytes)
         else:
@@ -659,7 +700,7 @@ class _MlpBackend:
               image.data_ptr(), _ptr(denc, "f", "denc"))
 
     @staticmethod
-    def reduce_dw(M, loss_scale, dws, workspace, adam=None, image=None):
+    def reduce_dw(M, loss_scale, dws, workspace, adam=None, image=None, scaler=None):
         """Second half of backward(..., dws=None): weight gradients from the partial sums left in `workspace`.
         adam = (param, grad, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps) with dws views of the flat `grad`: also
         apply Adam to the flat weights, element by element; image (a prepared operand image): keep it in step with the
@@ -672,7 +713,7 @@ class _MlpBackend:
                      float(eps)]
         _call("ngp_x_mlp_reduce_dw", workspace, M, float(loss_scale),
               *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], workspace.data_ptr(), workspace.numel(), *extra,
-              image.data_ptr() if image is not None else None)
+              image.data_ptr() if image is not None else None, _scaler_ptr(scaler))
 
 
 class _MlpRfBackend:
@@ -706,7 +747,7 @@ class _MlpRfBackend:
 
     @staticmethod
     def backward(enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, image, loss_scale, denc, ddirs, dws,
-                 workspace=None, sample_index=None):
+                 workspace=None, sample_index=None, scaler=None):
         """sample_index (int32, optional): run over a LIST of M_dev[0] samples -- inputs and ddirs by sample, denc in list order."""
         nbytes = load().ngp_x_mlp_rf_backward_workspace_bytes(M)
         ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
@@ -717,9 +758,9 @@ class _MlpRfBackend:
                 _ptr(drgb, "f", "drgb"), _ptr(M_dev, "i", "M_dev", True), M]
         tail = [image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"), _ptr(ddirs, "f", "ddirs", True),
                 *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], ws.data_ptr(), nbytes]
-        if sample_index is not None:
-            _call("ngp_x_mlp_rf_backward_list", enc, *head, _ptr(sample_index, "i", "sample_index"), *tail,
-                  probe_as="ngp_x_mlp_rf_backward")
+        if sample_index is not None or scaler is not None:
+            _call("ngp_x_mlp_rf_backward_list", enc, *head, _ptr(sample_index, "i", "sample_index", True), *tail,
+                  _scaler_ptr(scaler), probe_as="ngp_x_mlp_rf_backward")
         else:
             _call("ngp_x_mlp_rf_backward", enc, *head, *tail)
 
@@ -893,12 +934,13 @@ class _EngineBackend:
               _ptr(grad_rays_d, "f", "grad_rays_d"), N, V, W, fx, fy, cx, cy, _ptr(grad_pose, "f", "grad_pose"))
 
     @staticmethod
-    def pose_update(xi, base, grad_pose, flags, exp_avg, exp_avg_sq, lr0, gamma, beta1, beta2, eps, refined, grad_xi=None):
+    def pose_update(xi, base, grad_pose, flags, exp_avg, exp_avg_sq, lr0, gamma, beta1, beta2, eps, refined, grad_xi=None,
+                    scaler=None):
         """grad_pose None: only refined = compose(exp(xi), base); else one Adam step on xi first (when flags[0] != 0)."""
         _call("ngp_x_pose_update", xi, _ptr(xi, "f", "xi"), _ptr(base, "f", "base"), _ptr(grad_pose, "f", "grad_pose", True),
               xi.shape[0], _ptr(flags, "i", "flags", True), _ptr(exp_avg, "f", "exp_avg", True),
               _ptr(exp_avg_sq, "f", "exp_avg_sq", True), float(lr0), float(gamma), float(beta1), float(beta2), float(eps),
-              _ptr(refined, "f", "refined"), _ptr(grad_xi, "f", "grad_xi", True))
+              _ptr(refined, "f", "refined"), _ptr(grad_xi, "f", "grad_xi", True), _scaler_ptr(scaler))
 
     @staticmethod
     def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, zero_grad=False):
@@ -907,10 +949,12 @@ class _EngineBackend:
               float(beta1), float(beta2), float(eps), int(step), int(bool(zero_grad)))
 
     @staticmethod
-    def adam_step_dev(param, grad, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps, zero_grad=False):
+    def adam_step_dev(param, grad, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps, zero_grad=False, skip=None):
+        """skip: a one-element int32 device tensor (LossScaler.found); non-zero at run time = the launch does nothing."""
         _call("ngp_x_adam_step_dev", param, _ptr(param, "f", "param"), _ptr(grad, "f", "grad"),
               _ptr(exp_avg, "f", "exp_avg"), _ptr(exp_avg_sq, "f", "exp_avg_sq"), param.numel(),
-              _ptr(hyper, "f", "hyper"), float(beta1), float(beta2), float(eps), int(bool(zero_grad)))
+              _ptr(hyper, "f", "hyper"), float(beta1), float(beta2), float(eps), int(bool(zero_grad)),
+              _ptr(skip, "i", "skip", True))
 
     @staticmethod
     def schedule_step(step_counter, hyper, lr0, decay_steps, beta1, beta2):
@@ -919,7 +963,8 @@ class _EngineBackend:
 
     @staticmethod
     def step_begin(step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out=None, samples_seen=None,
-                   sample_counter=None, binned_workspace=None, L=0, n_rows_total=0, single_segment=False):
+                   sample_counter=None, binned_workspace=None, L=0, n_rows_total=0, single_segment=False, scaling=None):
+        """scaling: a LossScaler -- the previous step is settled (GradScaler.update) and Adam's t follows the steps taken."""
         if samples_seen is not None and (samples_seen.dtype != torch.int64 or not samples_seen.is_cuda):
             raise RuntimeError("samples_seen must be an int64 CUDA tensor")
         _call("ngp_x_step_begin", hyper, _ptr(step_counter, "u", "step_counter"), _ptr(hyper, "f", "hyper"), float(lr0),
@@ -927,10 +972,10 @@ class _EngineBackend:
               samples_seen.data_ptr() if samples_seen is not None else None,
               _ptr(sample_counter, "i", "sample_counter", True),
               binned_workspace.data_ptr() if binned_workspace is not None else None, int(L), int(n_rows_total),
-              int(bool(single_segment)))
+              int(bool(single_segment)), *_scaler_args(scaling))
 
     @staticmethod
-    def adam_step_dev2(a, b, hyper, beta1, beta2, eps):
+    def adam_step_dev2(a, b, hyper, beta1, beta2, eps, skip=None):
         """a, b = (param, grad, exp_avg, exp_avg_sq, zero_grad) of two tensors updated by one launch; a's gradient may
         be bfloat16 (the data-parallel wire format)."""
         args = []
@@ -941,7 +986,7 @@ class _EngineBackend:
             args += [_ptr(p_, "f", f"param_{name}"), _ptr(g_, "h" if a16 and name == "a" else "f", f"grad_{name}"),
                      _ptr(m_, "f", f"exp_avg_{name}"), _ptr(v_, "f", f"exp_avg_sq_{name}"), p_.numel(), int(bool(z_))]
         _call("ngp_x_adam_step_dev2", hyper, *args, _ptr(hyper, "f", "hyper"), float(beta1), float(beta2), float(eps),
-              int(a16))
+              int(a16), _ptr(skip, "i", "skip", True))
 
     @staticmethod
     def counter_add(counter, delta=1):

@@ -198,6 +198,10 @@ struct StepBegin {
     bool scan, single_segment;
     uint32_t L;
     WsLayout w;
+    // dynamic loss scale (mlp_common.hpp: LossScalerWord; NULL: none): the previous step is settled here -- GradScaler.update()
+    float *scaler;
+    float growth, backoff;
+    uint32_t growth_interval;
 };
 __device__ __forceinline__ void step_begin_block(const StepBegin &a)
 {
@@ -205,22 +209,54 @@ __device__ __forceinline__ void step_begin_block(const StepBegin &a)
     // while the others already wait on the scan's first loads
     const uint32_t done = a.step_counter[0];
     const uint32_t nw = blockDim.x >> 6, wid = threadIdx.x >> 6;
+    // Dynamic loss scale: what torch.cuda.amp.GradScaler.update() does after a step (train_utils.py:897-904), done at the
+    // start of the next one, where a single workgroup runs anyway.  A step that saw a non-finite gradient was skipped by
+    // every optimiser kernel: the scale backs off, Adam's t does not advance (its bias corrections below follow the
+    // optimiser steps TAKEN, as torch's do); the learning-rate schedule follows the step counter either way
+    // (lr_scheduler.step() is unconditional, train_utils.py:906-907).
+    uint32_t *sw = reinterpret_cast<uint32_t *>(a.scaler);
+    uint32_t found = 0, pending = 0, taken = done;
+    if (sw) {
+        found = sw[2], pending = sw[6];
+        taken = sw[4] + ((pending && !found) ? 1u : 0u);
+    }
     if ((threadIdx.x & 63u) == 0) {
-        const double t = (double)done + 1.0;
+        const double t = (double)taken + 1.0;
         if (wid == nw - 1) a.hyper[0] = (float)(a.lr0 * pow(0.1, fmin((double)done / a.decay_steps, 1.0)));
         if (wid == (nw >= 2 ? nw - 2 : 0)) a.hyper[1] = (float)(1.0 - pow(a.b1, t));
         if (wid == (nw >= 3 ? nw - 3 : 0)) a.hyper[2] = (float)(1.0 / sqrt(1.0 - pow(a.b2, t)));
     }
     if (a.scan) bin_scan_block(a.L, a.w, a.single_segment);
-    __syncthreads();   // every wave has read the step counter
+    __syncthreads();   // every wave has read the step counter (and the scaler's words)
     if (threadIdx.x != 0) return;
     a.step_counter[0] = done + 1u;
+    if (sw) {
+        float scale = a.scaler[0];
+        uint32_t tracker = sw[3];
+        if (pending) {
+            if (found) {
+                scale *= a.backoff;
+                tracker = 0;
+                sw[5] += 1u;
+            } else if (++tracker >= a.growth_interval) {
+                scale = fminf(scale * a.growth, 0x1p+60f);
+                tracker = 0;
+            }
+        }
+        a.scaler[0] = scale;
+        a.scaler[1] = 1.0f / scale;
+        sw[2] = 0u;
+        sw[3] = tracker;
+        sw[4] = taken;
+        sw[6] = 1u;
+    }
     if (a.loss_out) a.loss_out[0] = 0.0f;
     if (a.samples_seen && a.sample_counter) a.samples_seen[0] += (long long)a.sample_counter[0];
 }
 // host side: checks and packing shared by the two entry points
 int step_begin_args(StepBegin &a, const char *who, uint32_t *step_counter, float *hyper, double lr0, double decay_steps,
                     double beta1, double beta2, float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
-                    void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment);
+                    void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment, float *scaler = nullptr,
+                    double growth = 2.0, double backoff = 0.5, uint32_t growth_interval = 2000);
 
 }  // namespace ngp

@@ -563,8 +563,11 @@ __device__ __forceinline__ void adam_span(float *__restrict__ p, const float *g,
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *g, float *__restrict__ m,
                                                    float *__restrict__ v, size_t n4, size_t n, float lr, float b1,
                                                    float b2, float eps, float bc1, float rsqrt_bc2, bool zero_grad,
-                                                   float *g_mut, const float *__restrict__ hyper)
+                                                   float *g_mut, const float *__restrict__ hyper,
+                                                   const uint32_t *__restrict__ skip)
 {
+    // dynamic loss scale: a step that saw a non-finite gradient takes no optimiser step (GradScaler.step, train_utils.py:897)
+    if (skip && skip[0] != 0u) return;
     if (hyper) {   // {lr, 1 - beta1^t, 1/sqrt(1 - beta2^t)} written by schedule_kernel earlier on this stream
         lr = hyper[0];
         bc1 = hyper[1];
@@ -583,8 +586,10 @@ struct AdamTensor {
 // blocks [0, blocks_a) update tensor a, the rest tensor b
 template <bool A16>
 __global__ __launch_bounds__(256) void adam2_kernel(AdamTensor a, AdamTensor b, uint32_t blocks_a, float b1, float b2,
-                                                    float eps, const float *__restrict__ hyper)
+                                                    float eps, const float *__restrict__ hyper,
+                                                    const uint32_t *__restrict__ skip)
 {
+    if (skip && skip[0] != 0u) return;   // (as adam_kernel)
     const bool first = blockIdx.x < blocks_a;
     const AdamTensor t = first ? a : b;
     const uint32_t blk = first ? blockIdx.x : blockIdx.x - blocks_a, nblk = first ? blocks_a : gridDim.x - blocks_a;
@@ -1014,14 +1019,14 @@ extern "C" int ngp_x_adam_step(float *param, float *grad, float *exp_avg, float 
     const uint32_t blocks = (uint32_t)min((size_t)256 * 8, (n4 + 255) / 256 + 1);
     adam_kernel<<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n4, n, lr, (float)beta1,
                                                                   (float)beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), zero_grad != 0,
-                                                                  grad, nullptr);
+                                                                  grad, nullptr, nullptr);
     NGP_CHECK_LAUNCH("adam_step");
     return NGP_OK;
 }
 
 extern "C" int ngp_x_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n,
                                    const float *hyper, float beta1, float beta2, float eps, int zero_grad,
-                                   ngp_stream_t stream)
+                                   const uint32_t *skip, ngp_stream_t stream)
 {
     if (n == 0) return NGP_OK;
     NGP_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper, "adam_step_dev: null tensor");
@@ -1030,7 +1035,7 @@ extern "C" int ngp_x_adam_step_dev(float *param, float *grad, float *exp_avg, fl
     const size_t n4 = n / 4;
     const uint32_t blocks = (uint32_t)min((size_t)256 * 8, (n4 + 255) / 256 + 1);
     adam_kernel<<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n4, n, 0.0f, beta1,
-                                                                  beta2, eps, 1.0f, 1.0f, zero_grad != 0, grad, hyper);
+                                                                  beta2, eps, 1.0f, 1.0f, zero_grad != 0, grad, hyper, skip);
     NGP_CHECK_LAUNCH("adam_step_dev");
     return NGP_OK;
 }
@@ -1047,9 +1052,12 @@ extern "C" int ngp_x_schedule_step(uint32_t *step_counter, float *hyper, double 
 
 int ngp::step_begin_args(StepBegin &a, const char *who, uint32_t *step_counter, float *hyper, double lr0, double decay_steps,
                          double beta1, double beta2, float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
-                         void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment)
+                         void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment, float *scaler,
+                         double growth, double backoff, uint32_t growth_interval)
 {
     NGP_REQUIRE(step_counter && hyper, "%s: null tensor", who);
+    NGP_REQUIRE(!scaler || (growth >= 1.0 && backoff > 0.0 && backoff <= 1.0 && growth_interval >= 1),
+                "%s: loss scaler: growth >= 1, 0 < backoff <= 1, growth_interval >= 1", who);
     NGP_REQUIRE(decay_steps > 0.0, "%s: decay_steps must be positive", who);
     NGP_REQUIRE((samples_seen == nullptr) == (sample_counter == nullptr), "%s: samples_seen and sample_counter go together", who);
     WsLayout w{};
@@ -1061,18 +1069,20 @@ int ngp::step_begin_args(StepBegin &a, const char *who, uint32_t *step_counter, 
         w = ws_layout(binned_workspace, n_chunks_max);
     }
     a = StepBegin{step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out, reinterpret_cast<long long *>(samples_seen),
-                  sample_counter, binned_workspace != nullptr, single_segment != 0, L, w};
+                  sample_counter, binned_workspace != nullptr, single_segment != 0, L, w, scaler, (float)growth, (float)backoff,
+                  growth_interval};
     return NGP_OK;
 }
 
 extern "C" int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0, double decay_steps, double beta1,
                                 double beta2, float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
                                 void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment,
-                                ngp_stream_t stream)
+                                float *scaler, double growth, double backoff, uint32_t growth_interval, ngp_stream_t stream)
 {
     StepBegin a;
     const int rc = step_begin_args(a, "step_begin", step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out, samples_seen,
-                                   sample_counter, binned_workspace, L, n_rows_total, single_segment);
+                                   sample_counter, binned_workspace, L, n_rows_total, single_segment, scaler, growth, backoff,
+                                   growth_interval);
     if (rc != NGP_OK) return rc;
     step_begin_kernel<<<dim3(1), dim3(binned_workspace ? 1024 : 64), 0, as_stream(stream)>>>(a);
     NGP_CHECK_LAUNCH("step_begin");
@@ -1082,7 +1092,7 @@ extern "C" int ngp_x_step_begin(uint32_t *step_counter, float *hyper, double lr0
 extern "C" int ngp_x_adam_step_dev2(float *param_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a, uint64_t n_a,
                                     int zero_grad_a, float *param_b, float *grad_b, float *exp_avg_b,
                                     float *exp_avg_sq_b, uint64_t n_b, int zero_grad_b, const float *hyper, float beta1,
-                                    float beta2, float eps, int grad_a_bf16, ngp_stream_t stream)
+                                    float beta2, float eps, int grad_a_bf16, const uint32_t *skip, ngp_stream_t stream)
 {
     NGP_REQUIRE(n_a > 0 && n_b > 0, "adam_step_dev2: empty tensor (use adam_step_dev)");
     NGP_REQUIRE(!(grad_a_bf16 && zero_grad_a), "adam_step_dev2: a bfloat16 gradient is not zeroed");
@@ -1096,9 +1106,9 @@ extern "C" int ngp_x_adam_step_dev2(float *param_a, float *grad_a, float *exp_av
     const AdamTensor a{param_a, grad_a, exp_avg_a, exp_avg_sq_a, (size_t)n_a, zero_grad_a != 0};
     const AdamTensor b{param_b, grad_b, exp_avg_b, exp_avg_sq_b, (size_t)n_b, zero_grad_b != 0};
     if (grad_a_bf16)
-        adam2_kernel<true><<<dim3(ba + bb), dim3(256), 0, as_stream(stream)>>>(a, b, ba, beta1, beta2, eps, hyper);
+        adam2_kernel<true><<<dim3(ba + bb), dim3(256), 0, as_stream(stream)>>>(a, b, ba, beta1, beta2, eps, hyper, skip);
     else
-        adam2_kernel<false><<<dim3(ba + bb), dim3(256), 0, as_stream(stream)>>>(a, b, ba, beta1, beta2, eps, hyper);
+        adam2_kernel<false><<<dim3(ba + bb), dim3(256), 0, as_stream(stream)>>>(a, b, ba, beta1, beta2, eps, hyper, skip);
     NGP_CHECK_LAUNCH("adam_step_dev2");
     return NGP_OK;
 }

@@ -236,6 +236,7 @@ extern "C" int ngp_x_mlp_forward_step_begin(const float *enc, uint32_t stride, c
                                             float *hyper, double lr0, double decay_steps, double beta1, double beta2,
                                             float *loss_out, int64_t *samples_seen, const int32_t *sample_counter,
                                             void *binned_workspace, uint32_t L, uint32_t n_rows_total, int single_segment,
+                                            float *scaler, double growth, double backoff, uint32_t growth_interval,
                                             ngp_stream_t stream)
 {
     NGP_REQUIRE(M != 0, "mlp_forward_step_begin: M must be positive");
@@ -244,7 +245,8 @@ extern "C" int ngp_x_mlp_forward_step_begin(const float *enc, uint32_t stride, c
     NGP_REQUIRE(stride >= M, "mlp_forward_step_begin: encoder slab stride smaller than M");
     StepBegin a;
     const int rc = step_begin_args(a, "mlp_forward_step_begin", step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out,
-                                   samples_seen, sample_counter, binned_workspace, L, n_rows_total, single_segment);
+                                   samples_seen, sample_counter, binned_workspace, L, n_rows_total, single_segment, scaler,
+                                   growth, backoff, growth_interval);
     if (rc != NGP_OK) return rc;
     const uint32_t tiles = ceil_div(M, 32u);
     const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * kFwdWgPerCu);

@@ -151,12 +151,12 @@ __device__ __forceinline__ TileInB<WANT_SH> convert_raw(const RawTile &r, uint32
 
 // registers 8S..8S+7 of `a`, zeroed where the matching post-ReLU activation (same tile, same k-step) is 0
 template <int S>
-__device__ __forceinline__ half8 pack_masked(const f32x16 &a, const half8 &act)
+__device__ __forceinline__ half8 pack_masked(const f32x16 &a, const half8 &act, _Float16 lim)
 {
     // mask = all ones where act > 0, built with packed 16-bit integer ops on the f16 bit patterns (a positive f16 is
     // a positive int16; -0 is negative): clamp to {0, 1}, multiply by 0xffff
     typedef short short8 __attribute__((ext_vector_type(8)));
-    const half8 o = pack_sat<S>(a);   // deltas saturate instead of overflowing to inf (mlp_common.hpp)
+    const half8 o = pack_sat<S>(a, lim);   // static loss scale: deltas saturate instead of overflowing (mlp_common.hpp)
     short8 m = __builtin_bit_cast(short8, act);
     m = __builtin_elementwise_min(__builtin_elementwise_max(m, (short8)0), (short8)1) * (short8)-1;
     return __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, o) & m));
@@ -220,10 +220,14 @@ template <bool DDIRS>
 __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
     const float *__restrict__ enc, uint32_t stride, const float *__restrict__ dirs, const float *__restrict__ dsigma,
     const float *__restrict__ drgb, const int32_t *__restrict__ M_dev, uint32_t M_host,
-    const half8 *__restrict__ image, float loss_scale, half8 *__restrict__ d3buf, float *__restrict__ partial,
-    float *__restrict__ ddirs, const int32_t *__restrict__ live_idx)
+    const half8 *__restrict__ image, float loss_scale_host, half8 *__restrict__ d3buf, float *__restrict__ partial,
+    float *__restrict__ ddirs, const int32_t *__restrict__ live_idx, const float *__restrict__ scaler)
 {
     extern __shared__ half8 lds_w[];   // fragments 0..45 (46 KiB); reused as the f32 reduction image at the end
+    // scaler: the loss scale lives on the device and adapts (mlp_common.hpp: LossScalerWord); deltas then overflow to inf
+    // instead of saturating -- the overflow is the signal
+    const float loss_scale = scaler ? scaler[LS_SCALE] : loss_scale_host;
+    const _Float16 lim = delta_limit(scaler);
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
     const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_host) : M_host;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             d6[1] = e1 <= 5.0f ? gr1 * e1 * loss_scale : 0.0f;
             d6[2] = e2 <= 5.0f ? gr2 * e2 * loss_scale : 0.0f;
         }
-        const half8 p6 = pack_sat<0>(d6);
+        const half8 p6 = pack_sat<0>(d6, lim);
 
         // ---------------- layer 6: dW6 = delta6 x H4^T ; delta5 = W6^T delta6 (masked)
         half8 aT[2], bT[2];
@@ -370,8 +374,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
             const f32x16 dh = mfma(NGP_FRAG(T_W6 + rb), p6, zero16());
-            p5[rb][0] = pack_masked<0>(dh, h4[rb][0]);
-            p5[rb][1] = pack_masked<1>(dh, h4[rb][1]);
+            p5[rb][0] = pack_masked<0>(dh, h4[rb][0], lim);
+            p5[rb][1] = pack_masked<1>(dh, h4[rb][1], lim);
         }
         NGP_STAMP_AT(3);      // deltas 6, dW6, delta 5
         // ---------------- layer 5: dW5 = delta5 x H3^T ; delta4 = W5^T delta5 (masked)
@@ -403,8 +407,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int s = 0; s < 2; s++) dh = mfma(NGP_FRAG(T_W5 + rb * 4 + kb * 2 + s), p5[kb][s], dh);
-            p4[rb][0] = pack_masked<0>(dh, h3[rb][0]);
-            p4[rb][1] = pack_masked<1>(dh, h3[rb][1]);
+            p4[rb][0] = pack_masked<0>(dh, h3[rb][0], lim);
+            p4[rb][1] = pack_masked<1>(dh, h3[rb][1], lim);
         }
         NGP_STAMP_AT(4);      // dW5, delta 4
         // ---------------- layer 4: dW4 = delta4 x X3^T ; dX3 = W4^T delta4
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             for (int s = 0; s < 2; s++) dx3 = mfma(NGP_FRAG(T_W4 + kb * 2 + s), p4[kb][s], dx3);
         // delta3: rows 1..15 = d features, row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp)
         if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
-        if (valid) d3buf[(size_t)c_idx * 2 + h] = pack_sat<0>(dx3);
+        if (valid) d3buf[(size_t)c_idx * 2 + h] = pack_sat<0>(dx3, lim);
         if constexpr (DDIRS) {
             float dx = 0.f, dy = 0.f, dz = 1.f;
             if (valid) {
@@ -481,11 +485,13 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 template <bool WINDOW, bool UNIT = false>
 __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
     const float *__restrict__ enc, uint32_t stride, const int32_t *__restrict__ M_dev, uint32_t M_host,
-    const half8 *__restrict__ image, float inv_loss_scale, const half8 *__restrict__ d3buf,
+    const half8 *__restrict__ image, float inv_loss_scale_host, const half8 *__restrict__ d3buf,
     float *__restrict__ denc, float *__restrict__ partial, const float *__restrict__ level_w, uint32_t t3_base,
-    const int32_t *__restrict__ live_idx)
+    const int32_t *__restrict__ live_idx, const float *__restrict__ scaler)
 {
     extern __shared__ half8 lds_w[];   // local 0..11 = F_W1, F_W2 ; 12..25 = T_W3, T_W2, T_W1
+    const float inv_loss_scale = scaler ? scaler[LS_INV] : inv_loss_scale_host;   // (see the view kernel)
+    const _Float16 lim = delta_limit(scaler);
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
     const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_host) : M_host;
@@ -599,8 +605,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
             const f32x16 dh = mfma(NGP_FRAG(LT_W3 + rb), p3, zero16());
-            p2[rb][0] = pack_masked<0>(dh, h2[rb][0]);
-            p2[rb][1] = pack_masked<1>(dh, h2[rb][1]);
+            p2[rb][0] = pack_masked<0>(dh, h2[rb][0], lim);
+            p2[rb][1] = pack_masked<1>(dh, h2[rb][1], lim);
         }
         // ---------------- layer 2: dW2 = delta2 x H1^T ; delta1 = W2^T delta2 (masked)
         if constexpr (!UNIT) {
@@ -631,8 +637,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int s = 0; s < 2; s++) dh = mfma(NGP_FRAG(LT_W2 + rb * 4 + kb * 2 + s), p2[kb][s], dh);
-            p1[rb][0] = pack_masked<0>(dh, h1[rb][0]);
-            p1[rb][1] = pack_masked<1>(dh, h1[rb][1]);
+            p1[rb][0] = pack_masked<0>(dh, h1[rb][0], lim);
+            p1[rb][1] = pack_masked<1>(dh, h1[rb][1], lim);
         }
         // ---------------- layer 1: dW1 = delta1 x X0^T ; d enc = W1^T delta1
         if constexpr (!UNIT) {
@@ -684,6 +690,12 @@ __global__ __launch_bounds__(256) void mlp_reduce_dw_kernel(MlpDwReduce r)
     __shared__ float part[4][64];
     mlp_reduce_dw_group(r, blockIdx.x, threadIdx.x, part);
 }
+// dynamic loss scale: Adam on the MLP weights as a launch of its own, after the reduction has seen every weight gradient
+__global__ __launch_bounds__(256) void mlp_adam_kernel(MlpDwReduce r)
+{
+    if (reinterpret_cast<const uint32_t *>(r.scaler)[LS_FOUND] != 0u) return;   // the step is skipped
+    mlp_adam_group(r, blockIdx.x * 256u + threadIdx.x);
+}
 
 // the backward kernels stage their partial sums in 64 KiB of dynamic LDS (the default limit)
 static bool mlp_backward_lds_ok()
@@ -708,17 +720,18 @@ static bool mlp_backward_lds_ok()
 
 int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
                              const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
-                             float *partial, uint32_t blocks, hipStream_t st, const int32_t *sample_index)
+                             float *partial, uint32_t blocks, hipStream_t st, const int32_t *sample_index,
+                             const float *scaler)
 {
     NGP_REQUIRE(mlp_backward_lds_ok(), "mlp_backward_grid: cannot raise the dynamic LDS limit");
     if (level_w)
         mlp_backward_grid_kernel<true><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
                                                                                   d3buf, denc, partial, level_w, t3_base,
-                                                                                  sample_index);
+                                                                                  sample_index, scaler);
     else
         mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
                                                                                    d3buf, denc, partial, nullptr, t3_base,
-                                                                                   sample_index);
+                                                                                   sample_index, scaler);
     NGP_CHECK_LAUNCH("mlp_backward_grid");
     return NGP_OK;
 }
@@ -748,7 +761,8 @@ static uint32_t mlp_bwd_blocks(uint32_t M)
 int ngp::mlp_dw_reduce_args(MlpDwReduce &r, const char *who, uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3,
                             float *dw4, float *dw5, float *dw6, const void *workspace, size_t workspace_bytes,
                             float *adam_param, const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq,
-                            uint32_t adam_n, const float *adam_hyper, float beta1, float beta2, float eps, void *adam_image)
+                            uint32_t adam_n, const float *adam_hyper, float beta1, float beta2, float eps, void *adam_image,
+                            float *scaler)
 {
     NGP_REQUIRE(dw1 && dw2 && dw3 && dw4 && dw5 && dw6 && workspace, "%s: null tensor", who);
     NGP_REQUIRE(!adam_image || adam_param, "%s: the operand image is only patched together with Adam", who);
@@ -766,6 +780,7 @@ int ngp::mlp_dw_reduce_args(MlpDwReduce &r, const char *who, uint32_t M, float l
     r.dw1 = dw1, r.dw2 = dw2, r.dw3 = dw3, r.dw4 = dw4, r.dw5 = dw5, r.dw6 = dw6;
     r.adam = MlpAdam{adam_param, adam_grad, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps,
                      reinterpret_cast<_Float16 *>(adam_image)};
+    r.scaler = scaler;
     return NGP_OK;
 }
 
@@ -790,14 +805,14 @@ extern "C" int ngp_x_mlp_backward_dirs(const float *enc, uint32_t stride, const 
                                        ngp_stream_t stream)
 {
     return ngp_x_mlp_backward_list(enc, stride, dirs, dsigma, drgb, M_dev, M, nullptr, image, loss_scale, denc, ddirs, dw1, dw2,
-                                   dw3, dw4, dw5, dw6, workspace, workspace_bytes, stream);
+                                   dw3, dw4, dw5, dw6, workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const float *dirs, const float *dsigma,
                                        const float *drgb, const int32_t *M_dev, uint32_t M, const int32_t *sample_index,
                                        const void *image, float loss_scale, float *denc, float *ddirs, float *dw1,
                                        float *dw2, float *dw3, float *dw4, float *dw5, float *dw6, void *workspace,
-                                       size_t workspace_bytes, ngp_stream_t stream)
+                                       size_t workspace_bytes, float *loss_scaler, ngp_stream_t stream)
 {
     const bool reduce_now = dw1 != nullptr;   // all NULL: leave the per-workgroup partials for ngp_x_mlp_reduce_dw
     NGP_REQUIRE(image && workspace, "mlp_backward: null tensor");
@@ -818,17 +833,17 @@ extern "C" int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const 
     if (ddirs)
         mlp_backward_view_kernel<true><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
                                                                                   loss_scale, d3buf, part_view, ddirs,
-                                                                                  sample_index);
+                                                                                  sample_index, loss_scaler);
     else
         mlp_backward_view_kernel<false><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M,
                                                                                    img, loss_scale, d3buf, part_view, nullptr,
-                                                                                   sample_index);
+                                                                                   sample_index, loss_scaler);
     mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
                                                                                d3buf, denc, part_grid, nullptr, T_W3,
-                                                                               sample_index);
+                                                                               sample_index, loss_scaler);
     if (reduce_now)
         mlp_reduce_dw_kernel<<<dim3(kDwGroups), dim3(256), 0, st>>>(
-            MlpDwReduce{part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, MlpAdam{}});
+            MlpDwReduce{part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, MlpAdam{}, loss_scaler});
     NGP_CHECK_LAUNCH("mlp_backward");
     return NGP_OK;
 }
@@ -847,11 +862,11 @@ int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stri
     if (level_w)    // the window scales the features in front of the network and, as its adjoint, d enc behind it
         mlp_backward_grid_kernel<true, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, st>>>(
             enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, level_w, t3_base,
-            nullptr);
+            nullptr, nullptr);
     else
         mlp_backward_grid_kernel<false, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, st>>>(
             enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, nullptr, t3_base,
-            nullptr);
+            nullptr, nullptr);
     NGP_CHECK_LAUNCH(who);
     return NGP_OK;
 }
@@ -870,14 +885,16 @@ extern "C" int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, flo
                                    float *dw5, float *dw6, const void *workspace, size_t workspace_bytes,
                                    float *adam_param, const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq,
                                    uint32_t adam_n, const float *adam_hyper, float beta1, float beta2, float eps,
-                                   void *adam_image, ngp_stream_t stream)
+                                   void *adam_image, float *loss_scaler, ngp_stream_t stream)
 {
     MlpDwReduce r;
     const int rc = mlp_dw_reduce_args(r, "mlp_reduce_dw", M, loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, workspace, workspace_bytes,
                                       adam_param, adam_grad, adam_exp_avg, adam_exp_avg_sq, adam_n, adam_hyper, beta1, beta2,
-                                      eps, adam_image);
+                                      eps, adam_image, loss_scaler);
     if (rc != NGP_OK) return rc;
     mlp_reduce_dw_kernel<<<dim3(kDwGroups), dim3(256), 0, as_stream(stream)>>>(r);
+    if (loss_scaler && adam_param)   // the optimiser step waits for the verdict over ALL weight gradients
+        mlp_adam_kernel<<<dim3(2 * kAccFloats / 256), dim3(256), 0, as_stream(stream)>>>(r);
     NGP_CHECK_LAUNCH("mlp_reduce_dw");
     return NGP_OK;
 }

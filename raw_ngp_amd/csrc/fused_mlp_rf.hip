@@ -79,10 +79,10 @@ __global__ __launch_bounds__(256) void mlp_rf_prepare_kernel(MlpWeights W, _Floa
 #define RF_FRAG(id) lds_w[(id) * 64 + lane]
 
 template <int S>
-__device__ __forceinline__ half8 pack_masked_sat(const f32x16 &a, const half8 &act)
+__device__ __forceinline__ half8 pack_masked_sat(const f32x16 &a, const half8 &act, _Float16 lim)
 {
     typedef short short8 __attribute__((ext_vector_type(8)));
-    const half8 o = pack_sat<S>(a);
+    const half8 o = pack_sat<S>(a, lim);
     short8 m = __builtin_bit_cast(short8, act);
     m = __builtin_elementwise_min(__builtin_elementwise_max(m, (short8)0), (short8)1) * (short8)-1;
     return __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, o) & m));
@@ -275,11 +275,14 @@ constexpr uint32_t kRfTilesV = 9, kRfTilesG = 8;
 __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
     const float *__restrict__ enc, uint32_t stride, const float *__restrict__ dirs, const float *__restrict__ ldirs,
     const float *__restrict__ level_w, const float *__restrict__ dsigma, const float *__restrict__ drgb,
-    const int32_t *__restrict__ M_dev, uint32_t M_host, const half8 *__restrict__ image, float loss_scale,
+    const int32_t *__restrict__ M_dev, uint32_t M_host, const half8 *__restrict__ image, float loss_scale_host,
     half8 *__restrict__ d3buf, half8 *__restrict__ scratch, float *__restrict__ ddirs, float *__restrict__ partial,
-    const int32_t *__restrict__ live_idx)
+    const int32_t *__restrict__ live_idx, const float *__restrict__ scaler)
 {
     extern __shared__ half8 lds_w[];   // fragments 0..67 (68 KiB); reused as the f32 reduction image at the end
+    // (scaler: the dynamic loss scale, as in fused_mlp_backward.hip's view kernel)
+    const float loss_scale = scaler ? scaler[LS_SCALE] : loss_scale_host;
+    const _Float16 lim = delta_limit(scaler);
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
     const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_host) : M_host;
@@ -339,15 +342,15 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
             d6[1] = e1 <= 5.0f ? gr1 * e1 * loss_scale : 0.0f;
             d6[2] = e2 <= 5.0f ? gr2 * e2 * loss_scale : 0.0f;
         }
-        const half8 p6 = pack_sat<0>(d6);
+        const half8 p6 = pack_sat<0>(d6, lim);
 
         // ---------------- delta5 = W6^T delta6 (masked)
         half8 p5[5];
 #pragma unroll
         for (int rb = 0; rb < 3; rb++) {
             const f32x16 dh = mfma(RF_FRAG(RF_T6 + rb), p6, zero16());
-            p5[2 * rb] = pack_masked_sat<0>(dh, h4[2 * rb]);
-            if (rb < 2) p5[2 * rb + 1] = pack_masked_sat<1>(dh, h4[2 * rb + 1]);
+            p5[2 * rb] = pack_masked_sat<0>(dh, h4[2 * rb], lim);
+            if (rb < 2) p5[2 * rb + 1] = pack_masked_sat<1>(dh, h4[2 * rb + 1], lim);
         }
         // ---------------- dW5 += delta5 x H3^T
         {
@@ -376,8 +379,8 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
             f32x16 dh = zero16();
 #pragma unroll
             for (int kk = 0; kk < 5; kk++) dh = mfma(RF_FRAG(RF_T5 + rb * 5 + kk), p5[kk], dh);
-            p4[2 * rb] = pack_masked_sat<0>(dh, h3[2 * rb]);
-            if (rb < 2) p4[2 * rb + 1] = pack_masked_sat<1>(dh, h3[2 * rb + 1]);
+            p4[2 * rb] = pack_masked_sat<0>(dh, h3[2 * rb], lim);
+            if (rb < 2) p4[2 * rb + 1] = pack_masked_sat<1>(dh, h3[2 * rb + 1], lim);
         }
         // ---------------- d (view-MLP inputs 0..31) = W4^T delta4: row 0 unused, 1..15 features, 16..31 SH(view dir)
         f32x16 dx3 = zero16();
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
         for (int kk = 0; kk < 5; kk++) dx3 = mfma(RF_FRAG(RF_T4 + kk), p4[kk], dx3);
         // delta3 row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp backward)
         if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
-        if (valid) d3buf[(size_t)c_idx * 2 + h] = pack_sat<0>(dx3);
+        if (valid) d3buf[(size_t)c_idx * 2 + h] = pack_sat<0>(dx3, lim);
 
         if (ddirs) {   // d loss / d (un-normalised view direction)
             float dx = 0.f, dy = 0.f, dz = 1.f;
@@ -526,7 +529,7 @@ struct RfGrads {
 __global__ __launch_bounds__(256) void mlp_rf_reduce_dw_kernel(const float *__restrict__ part_v1,
                                                               const float *__restrict__ part_v2,
                                                               const float *__restrict__ part_g, uint32_t n_wg,
-                                                              float inv_loss_scale, RfGrads G)
+                                                              float inv_loss_scale, RfGrads G, float *__restrict__ scaler)
 {
     __shared__ float part[4][64];
     const uint32_t e = blockIdx.x * 64 + (threadIdx.x & 63u), q = threadIdx.x >> 6;
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(256) void mlp_rf_reduce_dw_kernel(const float *__re
     __syncthreads();
     if (q != 0) return;
     s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-    s *= inv_loss_scale;
+    s *= scaler ? scaler[LS_INV] : inv_loss_scale;
     const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
     const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;
     float *dst = nullptr;
@@ -575,6 +578,8 @@ __global__ __launch_bounds__(256) void mlp_rf_reduce_dw_kernel(const float *__re
         }
     }
     if (dst) *dst = s;
+    // dynamic loss scale: an overflowed delta shows here (mlp_common.hpp: mlp_reduce_dw_group); the optimiser kernels skip
+    if (dst && scaler && !(fabsf(s) < __uint_as_float(0x7f800000u))) reinterpret_cast<uint32_t *>(scaler)[LS_FOUND] = 1u;
 }
 
 }  // namespace ngp
@@ -633,7 +638,7 @@ extern "C" int ngp_x_mlp_rf_backward(const float *enc, uint32_t stride, const fl
                                      void *workspace, size_t workspace_bytes, ngp_stream_t stream)
 {
     return ngp_x_mlp_rf_backward_list(enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, nullptr, image, loss_scale, denc,
-                                      ddirs, dw1, dw2, dw3, dw4, dw5, dw6, workspace, workspace_bytes, stream);
+                                      ddirs, dw1, dw2, dw3, dw4, dw5, dw6, workspace, workspace_bytes, nullptr, stream);
 }
 
 // ... over a LIST of samples (as ngp_x_mlp_backward_list): inputs and ddirs by sample, denc in list order
@@ -642,7 +647,7 @@ extern "C" int ngp_x_mlp_rf_backward_list(const float *enc, uint32_t stride, con
                                           const int32_t *M_dev, uint32_t M, const int32_t *sample_index, const void *image,
                                           float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2, float *dw3,
                                           float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
-                                          ngp_stream_t stream)
+                                          float *loss_scaler, ngp_stream_t stream)
 {
     NGP_REQUIRE(image && workspace && dw1 && dw2 && dw3 && dw4 && dw5 && dw6, "mlp_rf_backward: null tensor");
     NGP_REQUIRE(M == 0 || (enc && dirs && ldirs && dsigma && drgb && denc), "mlp_rf_backward: null sample tensor");
@@ -669,14 +674,15 @@ extern "C" int ngp_x_mlp_rf_backward_list(const float *enc, uint32_t stride, con
     float *part_g = part_v2 + (size_t)256 * kRfTilesV * 1024;
     const half8 *img = reinterpret_cast<const half8 *>(image);
     mlp_rf_backward_v1_kernel<<<dim3(blocks), dim3(256), kV1Lds, st>>>(
-        enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, loss_scale, d3buf, scratch, ddirs, part_v1, sample_index);
+        enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, loss_scale, d3buf, scratch, ddirs, part_v1, sample_index,
+        loss_scaler);
     mlp_rf_backward_v2_kernel<<<dim3(blocks), dim3(256), kV2Lds, st>>>(
         enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, scratch, part_v2, sample_index);
     const int rc = launch_mlp_backward_grid(enc, stride, level_w, M_dev, M, img, RF_T3, 1.0f / loss_scale, d3buf, denc,
-                                            part_g, blocks, st, sample_index);
+                                            part_g, blocks, st, sample_index, loss_scaler);
     if (rc != NGP_OK) return rc;
     mlp_rf_reduce_dw_kernel<<<dim3((2 * kRfTilesV + kRfTilesG) * 1024u / 64u), dim3(256), 0, st>>>(
-        part_v1, part_v2, part_g, blocks, 1.0f / loss_scale, RfGrads{dw1, dw2, dw3, dw4, dw5, dw6});
+        part_v1, part_v2, part_g, blocks, 1.0f / loss_scale, RfGrads{dw1, dw2, dw3, dw4, dw5, dw6}, loss_scaler);
     NGP_CHECK_LAUNCH("mlp_rf_backward");
     return NGP_OK;
 }

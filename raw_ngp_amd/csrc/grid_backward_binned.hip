@@ -578,13 +578,39 @@ struct LocalRecords {
     const int32_t *B_dev = nullptr;
     uint32_t B_cap = 0, ntiles = 0;
 };
+// Dynamic loss scale (mlp_common.hpp: LossScalerWord).  The reduce launch is the first one that knows whether the step saw a
+// non-finite gradient anywhere: the weight-gradient reduction (passengers of the fill launch in front of it) has raised
+// LS_FOUND for the MLPs, the fill has left the batch's largest feature gradient in the workspace header.  The fused-Adam
+// reduce skips the table on either; the first n_pass workgroups are passengers that do the MLP weights' Adam step (and their
+// operand-image entries) under the same verdict, and one of them records the table's half of it for step_begin.
+struct ScalerTail {
+    float *scaler = nullptr;
+    uint32_t n_pass = 0;
+    MlpDwReduce mlp{};
+};
+constexpr uint32_t kAdamPassengers = 2 * kAccFloats / kReduceBlock;
 
 template <int MODE, bool LOCAL = false>
 __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(kReduceWaves, kReduceWaves))) void bin_reduce_kernel(const int32_t *__restrict__ offsets,
                                                                  float *__restrict__ grad_table, uint32_t L, WsLayout w,
-                                                                 AdamArgs opt, LocalRecords loc = LocalRecords{})
+                                                                 AdamArgs opt, LocalRecords loc = LocalRecords{},
+                                                                 ScalerTail st = ScalerTail{})
 {
     constexpr bool ADAM = MODE == 1, ALL = MODE != 0 || LOCAL;
+    uint32_t *sw = reinterpret_cast<uint32_t *>(st.scaler);
+    if (sw && (blockIdx.x < st.n_pass || (st.n_pass == 0 && blockIdx.x == 0 && threadIdx.x == 0))) {
+        // (with passengers: workgroup 0 is one; without -- the exchange step, whose optimiser kernels read the word --
+        // thread 0 of the first chunk's workgroup writes it and carries on)
+        const bool overflow = !(__uint_as_float(w.chunk_base[kMaxLevels + 1]) < __uint_as_float(0x7f800000u));
+        if (blockIdx.x == 0 && threadIdx.x == 0 && overflow) sw[LS_FOUND] = 1u;
+        if (st.n_pass != 0) {
+            if (!overflow && sw[LS_FOUND] == 0u && st.mlp.adam.param)
+                mlp_adam_group(st.mlp, blockIdx.x * kReduceBlock + threadIdx.x);
+            return;
+        }
+    }
+    // (the chunk workgroups test the verdict further down, next to the batch maximum they read anyway: its round trip then
+    // hides behind the directory and optimiser-state requests instead of standing in front of them)
     __shared__ unsigned long long acc[kChunkRows * 2];   // 16 bytes a row: int64 fixed-point sums, [row][channel]
     __shared__ uint32_t s_chunk, s_level;
     __shared__ uint32_t s_base[kMaxLevels + 1];
@@ -607,7 +633,7 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(kR
     for (uint32_t i = threadIdx.x; i < kChunkRows * 2; i += kReduceBlock) acc[i] = 0ull;
     __syncthreads();
     const uint32_t n_chunks = s_base[L];
-    const uint32_t item = blockIdx.x;
+    const uint32_t item = blockIdx.x - st.n_pass;
     if (ALL) {   // one segment per chunk: the work item IS the chunk
         if (item >= n_chunks) return;
     } else {
@@ -704,7 +730,9 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(kR
     // a non-finite gradient anywhere in the batch (the fill turns NaN into inf): no fixed-point scale exists and an Adam
     // step on it would poison the table for good -- skip the table's update, as the reference's GradScaler skips the step
     // (the MLP weights are protected element by element: mlp_reduce_dw_group)
-    if (ADAM && !(gmax < __uint_as_float(0x7f800000u))) return;
+    // (dynamic loss scale: the overflow word the weight-gradient reduction may have raised counts the same; workgroup 0 only
+    // ever writes it when the maximum is non-finite, which every workgroup sees for itself)
+    if (ADAM && (!(gmax < __uint_as_float(0x7f800000u)) || (sw && sw[LS_FOUND] != 0u))) return;
     frexpf(gmax, &e);
     const int k = 62 - kHeadroomBits - e;
 
@@ -1018,7 +1046,8 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
                                                 uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
                                                 size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
                                                 float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
-                                                float beta2, float eps, int overwrite, ngp_stream_t stream)
+                                                float beta2, float eps, int overwrite, ngp_stream_t stream,
+                                                float *scaler = nullptr)
 {
     (void)who;
     if (B == 0 || max_level == 0) return NGP_OK;
@@ -1043,6 +1072,16 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
     const uint32_t ft = ceil_div(B, kFillTile);
     const uint32_t n_tail = tail ? kDwGroups / 2u : 0u;   // two groups of 64 outputs per 512-lane workgroup
     const AdamArgs opt{adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps};
+    // dynamic loss scale: the reduce launch decides the step (ScalerTail); the MLP weights' Adam step rides on it when the
+    // caller asked for one (the fill launch's passengers then only reduce the weight gradients and raise the overflow word)
+    ScalerTail stl;
+    stl.scaler = scaler;
+    if (scaler && tail && tail->adam.param) {
+        NGP_REQUIRE(fused, "grid_backward_binned_apply_mlp: a loss scaler with the MLP's Adam step needs the table's fused Adam");
+        stl.n_pass = kAdamPassengers;
+        stl.mlp = *tail;
+    }
+    const uint32_t np = stl.n_pass;
     if (binned_local(B, c.nbins_cap)) {   // (else: the global-bins layout below)
         const size_t rec_cap = ws_rec_cap_local(B, L);
         const WsLayout wl = ws_layout(workspace, c.n_chunks_max, rec_cap);
@@ -1063,13 +1102,13 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
         // every level was filled, otherwise max_level of them)
         const uint32_t Lr = max_level;
         if (fused)
-            bin_reduce_kernel<1, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+            bin_reduce_kernel<1, true><<<c.n_chunks_max + np, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc, stl);
         else if (overwrite == 2)
-            bin_reduce_kernel<3, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+            bin_reduce_kernel<3, true><<<c.n_chunks_max + np, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc, stl);
         else if (overwrite)
-            bin_reduce_kernel<2, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+            bin_reduce_kernel<2, true><<<c.n_chunks_max + np, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc, stl);
         else
-            bin_reduce_kernel<0, true><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc);
+            bin_reduce_kernel<0, true><<<c.n_chunks_max + np, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc, stl);
         NGP_CHECK_LAUNCH("grid_backward_binned_apply");
         return NGP_OK;
     }
@@ -1079,13 +1118,13 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
                                                                             interp, c.w, n_tail, tail ? *tail : MlpDwReduce{});
     const uint32_t n_items_max = c.n_chunks_max + (uint32_t)(((uint64_t)B * max_level * 8) / kSeg) + 1;
     if (fused)   // prepared with single_segment: one workgroup owns each chunk's rows
-        bin_reduce_kernel<1><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
+        bin_reduce_kernel<1><<<c.n_chunks_max + np, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt, LocalRecords{}, stl);
     else if (overwrite == 2)
-        bin_reduce_kernel<3><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
+        bin_reduce_kernel<3><<<c.n_chunks_max + np, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt, LocalRecords{}, stl);
     else if (overwrite)
-        bin_reduce_kernel<2><<<c.n_chunks_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
+        bin_reduce_kernel<2><<<c.n_chunks_max + np, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt, LocalRecords{}, stl);
     else
-        bin_reduce_kernel<0><<<n_items_max, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt);
+        bin_reduce_kernel<0><<<n_items_max + np, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, c.w, opt, LocalRecords{}, stl);
     NGP_CHECK_LAUNCH("grid_backward_binned_apply");
     return NGP_OK;
 }
@@ -1097,12 +1136,12 @@ extern "C" int ngp_x_grid_backward_binned_apply(const float *grad, const float *
                                                 uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
                                                 size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
                                                 float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
-                                                float beta2, float eps, int overwrite, ngp_stream_t stream)
+                                                float beta2, float eps, int overwrite, float *loss_scaler, ngp_stream_t stream)
 {
     return binned_apply("grid_backward_binned_apply", nullptr, nullptr, grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L,
                         max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
                         workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
-                        stream);
+                        stream, loss_scaler);
 }
 
 // ngp_x_grid_backward_binned_apply over a LIST of samples (see ngp_x_grid_backward_binned_apply_mlp_list)
@@ -1113,12 +1152,13 @@ extern "C" int ngp_x_grid_backward_binned_apply_list(const float *grad, const fl
                                                      uint32_t n_rows_total, uint32_t max_level_rows, void *workspace,
                                                      size_t workspace_bytes, float *adam_param, float *adam_exp_avg,
                                                      float *adam_exp_avg_sq, const float *adam_hyper, float beta1,
-                                                     float beta2, float eps, int overwrite, ngp_stream_t stream)
+                                                     float beta2, float eps, int overwrite, float *loss_scaler,
+                                                     ngp_stream_t stream)
 {
     return binned_apply("grid_backward_binned_apply", nullptr, sample_index, grad, inputs, offsets, grad_embeddings, B_dev, B,
                         grad_stride, L, max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
                         workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
-                        stream);
+                        stream, loss_scaler);
 }
 
 // the same launch sequence with ngp_x_mlp_reduce_dw (same arguments, mlp_ prefix) riding along as extra workgroups of the
@@ -1131,14 +1171,14 @@ extern "C" int ngp_x_grid_backward_binned_apply_mlp(
     uint32_t mlp_M, float mlp_loss_scale, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6,
     const void *mlp_workspace, size_t mlp_workspace_bytes, float *mlp_adam_param, const float *mlp_adam_grad,
     float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq, uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1,
-    float mlp_beta2, float mlp_eps, void *mlp_adam_image, ngp_stream_t stream)
+    float mlp_beta2, float mlp_eps, void *mlp_adam_image, float *loss_scaler, ngp_stream_t stream)
 {
     return ngp_x_grid_backward_binned_apply_mlp_list(
         grad, inputs, nullptr, offsets, grad_embeddings, B_dev, B, grad_stride, L, max_level, S, H, gridtype, align_corners, interp,
         n_rows_total, max_level_rows, workspace, workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1,
         beta2, eps, overwrite, mlp_M, mlp_loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, mlp_workspace, mlp_workspace_bytes,
         mlp_adam_param, mlp_adam_grad, mlp_adam_exp_avg, mlp_adam_exp_avg_sq, mlp_adam_n, mlp_adam_hyper, mlp_beta1, mlp_beta2,
-        mlp_eps, mlp_adam_image, stream);
+        mlp_eps, mlp_adam_image, loss_scaler, stream);
 }
 
 // ... over a LIST of samples: entry b of the call is sample sample_index[b] (its position is inputs[sample_index[b]]), the
@@ -1152,19 +1192,19 @@ extern "C" int ngp_x_grid_backward_binned_apply_mlp_list(
     float *dw3, float *dw4, float *dw5, float *dw6, const void *mlp_workspace, size_t mlp_workspace_bytes,
     float *mlp_adam_param, const float *mlp_adam_grad, float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq,
     uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1, float mlp_beta2, float mlp_eps, void *mlp_adam_image,
-    ngp_stream_t stream)
+    float *loss_scaler, ngp_stream_t stream)
 {
     NGP_REQUIRE(B != 0 && max_level != 0, "grid_backward_binned_apply_mlp: nothing to launch the reduction with");
     MlpDwReduce r;
     const int rc = mlp_dw_reduce_args(r, "grid_backward_binned_apply_mlp", mlp_M, mlp_loss_scale, dw1, dw2, dw3, dw4, dw5, dw6,
                                       mlp_workspace, mlp_workspace_bytes, mlp_adam_param, mlp_adam_grad, mlp_adam_exp_avg,
                                       mlp_adam_exp_avg_sq, mlp_adam_n, mlp_adam_hyper, mlp_beta1, mlp_beta2, mlp_eps,
-                                      mlp_adam_image);
+                                      mlp_adam_image, loss_scaler);
     if (rc != NGP_OK) return rc;
     return binned_apply("grid_backward_binned_apply_mlp", &r, sample_index, grad, inputs, offsets, grad_embeddings, B_dev, B,
                         grad_stride, L, max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
                         workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
-                        stream);
+                        stream, loss_scaler);
 }
 
 extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,
@@ -1182,5 +1222,5 @@ extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float 
     if (rc != NGP_OK) return rc;
     return ngp_x_grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B, grad_stride, L, max_level, S, H,
                                             gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
-                                            workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, 0.0f, 0, stream);
+                                            workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, 0.0f, 0, nullptr, stream);
 }

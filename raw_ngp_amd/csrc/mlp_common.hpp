@@ -74,14 +74,28 @@ __device__ __forceinline__ half8 pack(const f32x16 &a)
     return o;
 }
 
-// conversion of a delta tile to f16 with saturation: a plain cast turns |x| > 65504 into inf, and one inf in a delta
-// becomes NaN weights for good (the reference's GradScaler would skip that step; here the sample's gradient is clipped)
+// conversion of a delta tile to f16 with saturation at +-lim: a plain cast turns |x| > 65504 into inf, and one inf in a
+// delta becomes NaN weights for good.  Static loss scale: lim = 65504, the sample's gradient is clipped.  Dynamic loss
+// scale (LossScaler below): lim = inf, the overflow is let through ON PURPOSE -- it poisons the weight gradient of its
+// own layer, the reduction of the weight gradients sees it, the step is skipped and the scale halved, which is what the
+// reference's GradScaler does (train_utils.py:404,897-904).  Same instruction count either way.
 template <int S>
-__device__ __forceinline__ half8 pack_sat(const f32x16 &a)
+__device__ __forceinline__ half8 pack_sat(const f32x16 &a, _Float16 lim)
 {
     half8 o = pack<S, false>(a);
-    o = __builtin_elementwise_min(__builtin_elementwise_max(o, (half8)(_Float16)-65504.0f), (half8)(_Float16)65504.0f);
+    o = __builtin_elementwise_min(__builtin_elementwise_max(o, (half8)(-lim)), (half8)lim);
     return o;
+}
+// ---- dynamic loss scale (torch.cuda.amp.GradScaler on the device) ----------------------------------------------------
+// eight 32-bit words in HBM, owned by the caller: [0] f32 scale, [1] f32 1 / scale, [2] u32 "a non-finite gradient was seen
+// in the current step", [3] u32 clean steps since the scale last changed, [4] u32 optimiser steps taken (Adam's t),
+// [5] u32 steps skipped, [6] u32 a step has run since the words were last settled, [7] reserved.
+// Readers: the MLP backward kernels ([0], [1]); writers of [2]: the weight-gradient reduction and the table reduce;
+// the optimiser kernels skip on [2]; step_begin settles the previous step (binned_common.hpp: step_begin_block).
+enum LossScalerWord : uint32_t { LS_SCALE = 0, LS_INV = 1, LS_FOUND = 2, LS_TRACKER = 3, LS_ADAM_T = 4, LS_SKIPPED = 5, LS_PENDING = 6 };
+__device__ __forceinline__ _Float16 delta_limit(const float *scaler)
+{
+    return scaler ? (_Float16)__uint_as_float(0x7f800000u) : (_Float16)65504.0f;
 }
 struct MlpWeights {
     const float *w1, *w2, *w3, *w4, *w5, *w6;
@@ -214,7 +228,8 @@ constexpr size_t flush_lds_bytes(int NT) { return (size_t)4 * ((NT + 1) / 2) * 4
 // NULL (no window); t3_base = first of the 14 transposed fragments (T_W3, T_W2, T_W1) in `image`
 int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
                              const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
-                             float *partial, uint32_t blocks, hipStream_t st, const int32_t *sample_index = nullptr);
+                             float *partial, uint32_t blocks, hipStream_t st, const int32_t *sample_index = nullptr,
+                             const float *scaler = nullptr);
 // ... with a unit delta on the first output and no weight gradients: denc <- d h0 / d enc (ngp_x_mlp_density_gradient)
 int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev,
                                 uint32_t M, const void *image, uint32_t t3_base, float *denc, hipStream_t st);
@@ -241,11 +256,77 @@ struct MlpDwReduce {
     float inv_loss_scale;
     float *dw1, *dw2, *dw3, *dw4, *dw5, *dw6;
     MlpAdam adam;
+    float *scaler = nullptr;   // dynamic loss scale (LossScalerWord): 1 / scale is read from it, non-finite sums raise LS_FOUND
 };
 int mlp_dw_reduce_args(MlpDwReduce &r, const char *who, uint32_t M, float loss_scale, float *dw1, float *dw2, float *dw3,
                        float *dw4, float *dw5, float *dw6, const void *workspace, size_t workspace_bytes, float *adam_param,
                        const float *adam_grad, float *adam_exp_avg, float *adam_exp_avg_sq, uint32_t adam_n,
-                       const float *adam_hyper, float beta1, float beta2, float eps, void *adam_image);
+                       const float *adam_hyper, float beta1, float beta2, float eps, void *adam_image, float *scaler = nullptr);
+
+// element e (0 .. 2 kAccFloats) of the two partial slabs -> its weight (NULL: a padding element of the tiles) and the
+// weight's two places in the f16 operand image (as-is and transposed block)
+struct DwPlace {
+    float *dst;
+    uint32_t pos_f, pos_t;
+};
+__device__ __forceinline__ DwPlace mlp_dw_place(const MlpDwReduce &a, uint32_t e)
+{
+    const bool view = e >= kAccFloats;
+    const uint32_t i = view ? e - kAccFloats : e;
+    const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
+    const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;
+    DwPlace p{nullptr, 0, 0};
+    if (b < 2) {   // first-layer tiles: rb = b
+        if (view) {
+            if (j >= 1) {
+                p.dst = &a.dw4[(32 * b + o) * 31 + j - 1];
+                p.pos_f = frag_pos(F_W4 + b * 2, o, j);
+                p.pos_t = frag_pos(T_W4 + b * 2, j, o);
+            }
+        } else {
+            p.dst = &a.dw1[(32 * b + o) * 32 + j];
+            p.pos_f = frag_pos(F_W1 + b * 2, o, j);
+            p.pos_t = frag_pos(T_W1 + b * 2, j, o);
+        }
+    } else if (b < 6) {   // 64 x 64 tiles: rb = (b-2) >> 1, cb = (b-2) & 1
+        const uint32_t rb = (b - 2) >> 1, cb = (b - 2) & 1;
+        p.dst = &(view ? a.dw5 : a.dw2)[(32 * rb + o) * 64 + 32 * cb + j];
+        p.pos_f = frag_pos((view ? F_W5 : F_W2) + rb * 4 + cb * 2, o, j);
+        p.pos_t = frag_pos((view ? T_W5 : T_W2) + cb * 4 + rb * 2, j, o);
+    } else {   // last-layer tiles: cb = b - 6
+        const uint32_t cb = b - 6;
+        if (view) {
+            if (o < 3) {
+                p.dst = &a.dw6[o * 64 + 32 * cb + j];
+                p.pos_f = frag_pos(F_W6 + cb * 2, o, j);
+                p.pos_t = frag_pos(T_W6 + cb, j, o);
+            }
+        } else {
+            if (o < 16) {
+                p.dst = &a.dw3[o * 64 + 32 * cb + j];
+                p.pos_f = frag_pos(F_W3 + cb * 2, o, j);
+                p.pos_t = frag_pos(T_W3 + cb, j, o);
+            }
+        }
+    }
+    return p;
+}
+// torch.optim.Adam on one MLP weight whose gradient is s (+ the weight's two entries in the f16 operand image)
+__device__ __forceinline__ void mlp_adam_element(const MlpAdam &adam, const DwPlace &pl, float s)
+{
+    const size_t k = (size_t)(pl.dst - adam.grad);
+    const float step_size = adam.hyper[0] / adam.hyper[1], rsqrt_bc2 = adam.hyper[2];
+    const float mi = adam.b1 * adam.exp_avg[k] + (1.0f - adam.b1) * s;
+    const float vi = adam.b2 * adam.exp_avg_sq[k] + (1.0f - adam.b2) * s * s;
+    adam.exp_avg[k] = mi;
+    adam.exp_avg_sq[k] = vi;
+    const float p = adam.param[k] - step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + adam.eps));
+    adam.param[k] = p;
+    if (adam.image) {   // next step's operand image without a prepare pass (its padding entries never change)
+        adam.image[pl.pos_f] = (_Float16)p;
+        adam.image[pl.pos_t] = (_Float16)p;
+    }
+}
 
 // One group = 64 outputs, reduced by 256 lanes (tid 0..255; every lane of the group must call: there is a barrier inside).
 // Wave q sums the slabs q, q + 4, q + 8, ... (eight loads in flight: the sum is latency-bound otherwise) and the four partial
@@ -272,66 +353,33 @@ __device__ __forceinline__ void mlp_reduce_dw_group(const MlpDwReduce &a, uint32
     __syncthreads();
     if (q != 0) return;
     s = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-    s *= a.inv_loss_scale;
-    const uint32_t b = i >> 10, v = (i >> 6) & 15u, lane = i & 63u;
-    const uint32_t o = (v & 3u) + 8u * (v >> 2) + 4u * (lane >> 5), j = lane & 31u;
-    float *dst = nullptr;   // padding elements of the tiles have no weight behind them
-    uint32_t pos_f = 0, pos_t = 0;   // the weight's two places in the f16 operand image (as-is and transposed block)
-    if (b < 2) {   // first-layer tiles: rb = b
-        if (view) {
-            if (j >= 1) {
-                dst = &a.dw4[(32 * b + o) * 31 + j - 1];
-                pos_f = frag_pos(F_W4 + b * 2, o, j);
-                pos_t = frag_pos(T_W4 + b * 2, j, o);
-            }
-        } else {
-            dst = &a.dw1[(32 * b + o) * 32 + j];
-            pos_f = frag_pos(F_W1 + b * 2, o, j);
-            pos_t = frag_pos(T_W1 + b * 2, j, o);
-        }
-    } else if (b < 6) {   // 64 x 64 tiles: rb = (b-2) >> 1, cb = (b-2) & 1
-        const uint32_t rb = (b - 2) >> 1, cb = (b - 2) & 1;
-        dst = &(view ? a.dw5 : a.dw2)[(32 * rb + o) * 64 + 32 * cb + j];
-        pos_f = frag_pos((view ? F_W5 : F_W2) + rb * 4 + cb * 2, o, j);
-        pos_t = frag_pos((view ? T_W5 : T_W2) + cb * 4 + rb * 2, j, o);
-    } else {   // last-layer tiles: cb = b - 6
-        const uint32_t cb = b - 6;
-        if (view) {
-            if (o < 3) {
-                dst = &a.dw6[o * 64 + 32 * cb + j];
-                pos_f = frag_pos(F_W6 + cb * 2, o, j);
-                pos_t = frag_pos(T_W6 + cb, j, o);
-            }
-        } else {
-            if (o < 16) {
-                dst = &a.dw3[o * 64 + 32 * cb + j];
-                pos_f = frag_pos(F_W3 + cb * 2, o, j);
-                pos_t = frag_pos(T_W3 + cb, j, o);
-            }
-        }
+    s *= a.scaler ? a.scaler[LS_INV] : a.inv_loss_scale;
+    const DwPlace pl = mlp_dw_place(a, e);
+    if (!pl.dst) return;   // padding elements of the tiles have no weight behind them
+    *pl.dst = s;
+    const bool finite = fabsf(s) < __uint_as_float(0x7f800000u);
+    if (a.scaler) {
+        // dynamic loss scale: an f16 delta that overflowed has made the weight gradients of its layer non-finite (inf x
+        // activation, or NaN out of the on-matrix-core transposes) -- this is where the step's overflow is detected.  Whether
+        // the optimiser steps is decided for the WHOLE step once every gradient is known: Adam on the MLP weights follows in
+        // a later launch (mlp_adam_group: passengers of the table's reduce kernel, or ngp_x_adam_step_dev with the flag).
+        if (!finite) reinterpret_cast<uint32_t *>(a.scaler)[LS_FOUND] = 1u;
+        return;
     }
-    if (!dst) return;
-    *dst = s;
-    const MlpAdam &adam = a.adam;
-    // (a non-finite weight gradient -- one NaN dsigma / drgb in the batch -- leaves this weight, its moments and its
-    // image entries alone: the update would poison it for good.  The table's half of that rule is in bin_reduce_kernel,
-    // which skips the whole table when the batch's largest feature gradient is not finite.  Unlike a GradScaler the skip
-    // is per MLP weight, not per step: this reduction runs beside the fill, before the batch's maximum is known; the
-    // step counter and the bias corrections advance either way.)
-    if (adam.param && fabsf(s) < __uint_as_float(0x7f800000u)) {   // Adam on the element just reduced
-        const size_t k = (size_t)(dst - adam.grad);
-        const float step_size = adam.hyper[0] / adam.hyper[1], rsqrt_bc2 = adam.hyper[2];
-        const float mi = adam.b1 * adam.exp_avg[k] + (1.0f - adam.b1) * s;
-        const float vi = adam.b2 * adam.exp_avg_sq[k] + (1.0f - adam.b2) * s * s;
-        adam.exp_avg[k] = mi;
-        adam.exp_avg_sq[k] = vi;
-        const float p = adam.param[k] - step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + adam.eps));
-        adam.param[k] = p;
-        if (adam.image) {   // next step's operand image without a prepare pass (its padding entries never change)
-            adam.image[pos_f] = (_Float16)p;
-            adam.image[pos_t] = (_Float16)p;
-        }
-    }
+    // static loss scale: (a non-finite weight gradient -- one NaN dsigma / drgb in the batch -- leaves this weight, its
+    // moments and its image entries alone: the update would poison it for good.  The table's half of that rule is in
+    // bin_reduce_kernel, which skips the whole table when the batch's largest feature gradient is not finite.  The skip is
+    // per MLP weight, not per step: this reduction runs beside the fill, before the batch's maximum is known; the step
+    // counter and the bias corrections advance either way.)
+    if (a.adam.param && finite) mlp_adam_element(a.adam, pl, s);
+}
+
+// Dynamic loss scale: Adam on the MLP weights (+ operand image) from the gradients a previous launch's mlp_reduce_dw_group
+// left in a.dw*, element e of 2 kAccFloats; the caller has already decided that the step is not skipped.
+__device__ __forceinline__ void mlp_adam_group(const MlpDwReduce &a, uint32_t e)
+{
+    const DwPlace pl = mlp_dw_place(a, e);
+    if (pl.dst) mlp_adam_element(a.adam, pl, *pl.dst);
 }
 
 }  // namespace ngp

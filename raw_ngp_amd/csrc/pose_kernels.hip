@@ -372,7 +372,7 @@ struct PoseAdam {
 // and the refined pose for the next step.
 __global__ void pose_update_kernel(float *__restrict__ xi, const float *__restrict__ base, const float *__restrict__ grad_pose,
                                    uint32_t V, const int32_t *__restrict__ flags, PoseAdam opt, float *__restrict__ refined,
-                                   float *__restrict__ grad_xi)
+                                   float *__restrict__ grad_xi, const uint32_t *__restrict__ scaler)
 {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
@@ -400,8 +400,12 @@ __global__ void pose_update_kernel(float *__restrict__ xi, const float *__restri
 #pragma unroll
             for (int i = 0; i < 6; i++) grad_xi[(size_t)v * 6 + i] = g[i];
         }
-        if (flags[0] != 0) {
-            const double step = (double)flags[1], t = step + 1.0;
+        // dynamic loss scale (ngp_hip.h; words [2] overflow in this step, [5] steps skipped before it): the reference hands the
+        // pose optimiser to the same GradScaler (train_utils.py:898-899) -- no step on overflow, Adam's t counts the steps
+        // taken, the ExponentialLR follows the step counter
+        const bool skip = scaler && scaler[2] != 0u;
+        if (flags[0] != 0 && !skip) {
+            const double step = (double)flags[1], t = step + 1.0 - (scaler ? (double)min(scaler[5], (uint32_t)flags[1]) : 0.0);
             const float lr = (float)((double)opt.lr0 * pow((double)opt.gamma, step));
             const float bc1 = (float)(1.0 - pow((double)opt.b1, t)), bc2s = (float)sqrt(1.0 - pow((double)opt.b2, t));
 #pragma unroll
@@ -554,14 +558,14 @@ extern "C" int ngp_x_pose_gradient(const int32_t *index, const float *grad_rays_
 
 extern "C" int ngp_x_pose_update(float *xi, const float *base, const float *grad_pose, uint32_t V, const int32_t *flags,
                                  float *exp_avg, float *exp_avg_sq, float lr0, float gamma, float beta1, float beta2,
-                                 float eps, float *refined, float *grad_xi, ngp_stream_t stream)
+                                 float eps, float *refined, float *grad_xi, const float *loss_scaler, ngp_stream_t stream)
 {
     if (V == 0) return NGP_OK;
     NGP_REQUIRE(xi && base && refined, "pose_update: null tensor");
     NGP_REQUIRE(!grad_pose || (flags && exp_avg && exp_avg_sq), "pose_update: an update needs flags and the Adam state");
     const PoseAdam opt{exp_avg, exp_avg_sq, lr0, gamma, beta1, beta2, eps};
-    pose_update_kernel<<<dim3(ceil_div(V, 64u)), dim3(64), 0, as_stream(stream)>>>(xi, base, grad_pose, V, flags, opt, refined,
-                                                                                  grad_xi);
+    pose_update_kernel<<<dim3(ceil_div(V, 64u)), dim3(64), 0, as_stream(stream)>>>(
+        xi, base, grad_pose, V, flags, opt, refined, grad_xi, reinterpret_cast<const uint32_t *>(loss_scaler));
     NGP_CHECK_LAUNCH("pose_update");
     return NGP_OK;
 }

@@ -88,7 +88,7 @@ class FusedTrainer:
         self.orient = float(getattr(opt, "lambda_orientation", 0.0)) > 0
         # (with pose refinement the term also reaches the cameras through the view directions -- ray_gradients takes that
         # part -- and the level window's adjoint enters d sigma / d xyz)
-        assert not getattr(opt, "fp16", False) or opt.loss_scale > 0, "fused step: --fp16 maps to the static loss scale"
+        assert opt.loss_scale > 0, "fused step: the f16 deltas of the MLP backward need a positive loss scale"
         self.opt, self.model, self.data, self.device = opt, model.to(device), dataset, torch.device(device)
         opt.fused_mlp = True
         assert model._fused(), "fused step needs the default field configuration"
@@ -230,6 +230,12 @@ class FusedTrainer:
         self.seed64 = (seed * 1000 + self.rank) & (2 ** 64 - 1)
         i32 = dict(dtype=torch.int32, device=dev)
         self.draw_ctr, self.step_ctr = torch.zeros(1, **i32), torch.zeros(1, **i32)
+        # torch.cuda.amp.GradScaler (train_utils.py:404,897-904) as eight device words: the MLP backward reads the scale,
+        # an overflowing f16 delta makes the step's weight gradients non-finite, every optimiser kernel then leaves its
+        # parameters alone and the next step's step_begin halves the scale -- inside the step graphs, no host read
+        from .._lib import LossScaler
+        self.scaler = LossScaler(dev, init_scale=opt.loss_scale, growth_interval=getattr(opt, "scale_growth_interval", 2000)) \
+            if getattr(opt, "dynamic_loss_scale", True) and dev.type == "cuda" else None
         self.hyper = torch.zeros(4, **f32)                  # {lr, 1 - b1^t, 1/sqrt(1 - b2^t)} of the current step
         # the main stream's part of a step replayed from captured hipGraphs (one per ray slot)
         self.use_graph = bool(getattr(opt, "capture_graph", True)) and opt.lambda_tv == 0 and dev.type == "cuda"
@@ -331,6 +337,11 @@ class FusedTrainer:
         self.last_loss = None
         if self.world_size > 1:
             parallel.broadcast_module(self.model)
+
+    def close(self):
+        """Give back what outlives the object otherwise: the RCCL communicator of the exchange step."""
+        if self.xchg is not None:
+            self.xchg.close()
 
     # ------------------------------------------------------------------ pieces
     def lr(self):
@@ -455,13 +466,13 @@ class FusedTrainer:
             if self.rfield:         # one call: both view kernels, the density kernel, the weight-gradient reduction
                 self.mb.backward(self.enc, cap, ar.dirs, ar.ldirs, None if self.baa else self.level_w, self.dsigma, self.drgb,
                                  back_n, cap, self.mlp_image, opt.loss_scale, self.denc, self.ddirs if self.pose else None,
-                                 self.dws, self.ws_mlp, sample_index=back_idx)
+                                 self.dws, self.ws_mlp, sample_index=back_idx, scaler=self.scaler)
                 if self.baa:        # the blend's adjoint: d enc' -> d enc (what the table backward and the ray gradients read)
                     eb.slab_window(self.denc, cap, self.L, self.level_w, back_n, cap, backward=True)
             else:
                 self.mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, back_n, cap, self.mlp_image, opt.loss_scale,
                                  self.denc, None if split_weights else self.dws, self.ws_mlp,
-                                 ddirs=self.ddirs if self.pose else None, sample_index=back_idx)
+                                 ddirs=self.ddirs if self.pose else None, sample_index=back_idx, scaler=self.scaler)
                 if self.pose:       # the window's adjoint: d enc' -> d enc
                     eb.slab_window(self.denc, cap, self.L, self.level_w, back_n, cap, backward=True, scale_only=not self.baa)
 
@@ -484,7 +495,7 @@ class FusedTrainer:
             ("ngp_x_grid_backward_binned_apply" + ("_mlp" if mlp_tail is not None else ""), lambda: gb.grid_backward_binned_apply(
                 self.denc, self.x01, offsets, self._wire if overwrite and self.wire16 else self.table_grad, back_n, cap, cap,
                 self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite, mlp_tail=mlp_tail,
-                sample_index=back_idx)),
+                sample_index=back_idx, scaler=self.scaler)),
         ]
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
@@ -592,8 +603,8 @@ class FusedTrainer:
 
     def _timed(self, fn):
         """Run fn() between two HIP events on the current stream when bench.py asked for collective timings."""
-        if self.collective_events is None:
-            return fn()
+        if self.collective_events is None or torch.cuda.is_current_stream_capturing():
+            return fn()         # (events recorded during a capture are never executed: nothing to time there)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         fn()
@@ -608,6 +619,10 @@ class FusedTrainer:
             self.collective_steps += 1
 
         def run():
+            if self.scaler is not None:
+                # GradScaler under DDP sees the all-reduced gradients, inf on one rank is inf on all: here every rank owns a
+                # shard of them, so the overflow word itself travels (4 bytes, MAX) and all ranks skip or step together
+                x.all_reduce_max(self.scaler.found)
             if self.dp_mode == "shard":
                 x.reduce_scatter_avg(self.gflat)
                 if self.wire16:
@@ -619,6 +634,10 @@ class FusedTrainer:
         if x.carrier != "none":
             self._timed(run)
 
+    def _skip(self):
+        """The overflow word of the dynamic loss scale (None without one): optimiser kernels do nothing while it is set."""
+        return self.scaler.found if self.scaler is not None else None
+
     def _xchg_adam(self):
         """ONE launch: Adam on this rank's part of the flat parameter (f32 wire: the MLP weights are part of it)."""
         x = self.xchg
@@ -629,9 +648,10 @@ class FusedTrainer:
             own_p, own_g = self.flat, self.gflat
         if self.wire16:
             eb.adam_step_dev2((own_p, own_g, self.t_m, self.t_v, False),
-                              (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps)
+                              (self.w_flat, self.w_grad, self.w_m, self.w_v, False), self.hyper, *self.betas, self.eps,
+                              skip=self._skip())
         else:
-            eb.adam_step_dev(own_p, own_g, self.t_m, self.t_v, self.hyper, *self.betas, self.eps)
+            eb.adam_step_dev(own_p, own_g, self.t_m, self.t_v, self.hyper, *self.betas, self.eps, skip=self._skip())
 
     def _xchg_post(self):
         """Publish the updated shards (shard mode)."""
@@ -716,7 +736,7 @@ class FusedTrainer:
         begin = ("ngp_x_step_begin", lambda: eb.step_begin(
             self.step_ctr, self.hyper, self.lr0, float(opt.iters), *self.betas, self.loss, self.samples_seen,
             slot.arena.counter, binned_workspace=slot.ws_grid if self.binned_counts else None, L=self.L,
-            n_rows_total=self.rows, single_segment=True))
+            n_rows_total=self.rows, single_segment=True, scaling=self.scaler))
         ops = []
         # separate Adam (data parallel, or fuse_adam off): the reduction writes every row of the gradient, so nothing
         # has to zero it and the accumulate's read disappears (TV / weight decay are added afterwards, in optimizer_step)
@@ -736,7 +756,7 @@ class FusedTrainer:
             # compositor): one kernel and one dependent-launch gap fewer on the critical path
             ar, cap = slot.arena, self.cap
             sb = (self.step_ctr, self.hyper, self.lr0, float(opt.iters), *self.betas, self.loss, self.samples_seen,
-                  ar.counter, slot.ws_grid if self.binned_counts else None, self.L, self.rows, True)
+                  ar.counter, slot.ws_grid if self.binned_counts else None, self.L, self.rows, True, self.scaler)
             field = [("ngp_x_mlp_forward_step_begin", lambda: self._mlp_forward(cap, ar.dirs, ar.ldirs, ar.counter, cap, self.sigma,
                                                                                self.rgb, step_begin=sb))
                      if o[0] == "ngp_x_mlp_forward" else o for o in field]
@@ -764,14 +784,14 @@ class FusedTrainer:
                                                                  d.W, d.intrinsics, self.grad_pose)),
                 ("ngp_x_pose_update", lambda: eb.pose_update(self.xi, self.pose_base, self.grad_pose, self.flags, self.pose_m,
                                                              self.pose_v, self.pose_lr0, self.pose_gamma, 0.9, 0.999, 1e-8,
-                                                             self.poses_refined)),
+                                                             self.poses_refined, scaler=self.scaler)),
             ]
         if split:
             if self.rfield:
                 # (the light-conditioned kernels reduce their weight gradients themselves: Adam and next step's operand
                 # image are two more small launches)
                 tail = [("ngp_x_adam_step_dev", lambda: eb.adam_step_dev(self.w_flat, self.w_grad, self.w_m, self.w_v,
-                                                                         self.hyper, *self.betas, self.eps)),
+                                                                         self.hyper, *self.betas, self.eps, skip=self._skip())),
                         ("ngp_x_mlp_prepare", self._mlp_prepare)]
             else:
                 # weight gradients out of the partial sums and, element by element, Adam on the flat MLP weights and the
@@ -779,17 +799,22 @@ class FusedTrainer:
                 tail = [("ngp_x_mlp_reduce_dw", lambda: self.mb.reduce_dw(
                             self.cap, opt.loss_scale, self.dws, self.ws_mlp,
                             adam=(self.w_flat, self.w_grad, self.w_m, self.w_v, self.hyper, *self.betas, self.eps),
-                            image=self.mlp_image))]
+                            image=self.mlp_image, scaler=self.scaler))]
+            # (dynamic loss scale: the weights' optimiser step waits for the table backward's verdict on the batch)
+            late = self.scaler is not None
             for name, op in field:
-                if name == "ngp_x_grid_backward_binned_apply":      # right after the MLP backward, beside the apply
+                if name == "ngp_x_grid_backward_binned_apply" and not late:   # right after the MLP backward, beside the apply
                     ops += [(n, o, "aux") for n, o in tail]
                 ops.append((name, op, "main"))
+                if name == "ngp_x_grid_backward_binned_apply" and late:
+                    ops += [(n, o, "main") for n, o in tail]
             ops += [(n, o, "main") for n, o in pose_tail]
             return ops
         # ---- the exchange step: gradients -> collectives -> ONE Adam launch -> collectives -> next step's operand image
         ops += [(n, o, "main") for n, o in field]
         if not ride and not self.rfield:            # (the light-conditioned backward reduces its weight gradients itself)
-            ops.append(("ngp_x_mlp_reduce_dw", lambda: self.mb.reduce_dw(self.cap, opt.loss_scale, self.dws, self.ws_mlp), "main"))
+            ops.append(("ngp_x_mlp_reduce_dw", lambda: self.mb.reduce_dw(self.cap, opt.loss_scale, self.dws, self.ws_mlp,
+                                                                         scaler=self.scaler), "main"))
         if self.pose:
             # the cameras are replicated: every rank folds its rays into its own pose gradient, the ranks average them and
             # all take the same se(3) step

@@ -39,7 +39,7 @@ class _FusedField(Function):
         return (denc, None, None) + tuple(dws)
 
 
-def fused_field(enc, dirs, weights, loss_scale=1024.0):
+def fused_field(enc, dirs, weights, loss_scale=65536.0):
     return _FusedField.apply(enc, dirs, loss_scale, *weights)
 
 

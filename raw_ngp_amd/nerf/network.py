@@ -158,7 +158,7 @@ class NeRFNetwork(NeRFRenderer):
             from .fused_field import fused_field
             enc = self.grid_encoder(x.reshape(-1, 3), bound=self.bound, slab=True)
             sigma, color = fused_field(enc, d.reshape(-1, 3), self._mlp_weights(),
-                                       getattr(self.opt, "loss_scale", 1024.0))
+                                       getattr(self.opt, "loss_scale", 65536.0))
             return {"sigma": sigma.view(x.shape[:-1]), "color": color.view(*x.shape[:-1], 3)}
         sigma, feat = self.common_forward(x)
         parts = [feat, self.view_encoder(d)]

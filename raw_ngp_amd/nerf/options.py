@@ -61,7 +61,11 @@ class Options:
     device: str = "cuda"
     # --- extensions of this implementation (no reference counterpart) -----------------------------
     fused_mlp: bool = False       # hand-written MFMA tiny-MLP instead of nn.Linear stacks
-    loss_scale: float = 1024.0    # static loss scale of the fused MLP backward (f16 deltas)
+    loss_scale: float = 65536.0   # loss scale of the fused MLP backward's f16 deltas: GradScaler's initial value
+                                  # (train_utils.py:404); the per-op path keeps it static (deltas saturate), the fused engine
+                                  # adapts it on the device:
+    dynamic_loss_scale: bool = True   # GradScaler's rule inside the step graphs: x0.5 and the step skipped on overflow, x2 after
+    scale_growth_interval: int = 2000  # this many clean steps (torch.cuda.amp.GradScaler defaults, train_utils.py:897-904)
     arena_capacity: int = 0       # > 0: sample arena (no host sync per step); 0 = reference 2-pass protocol
     native_grid_refresh: bool = True  # fused engine: density-grid refresh as device kernels (no host syncs)
     dp_exchange: str = None       # data parallel, carrier of the collectives: "rccl" = bare RCCL calls on the step's stream,

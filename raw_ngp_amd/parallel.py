@@ -138,7 +138,7 @@ class Exchange:
     buffer of its own for gloo; all_gather(buf) publishes every rank's shard of buf in place; all_reduce_avg(*bufs)
     averages whole buffers.  Buffers are flat, padded_numel() long."""
 
-    def __init__(self, device, carrier=None):
+    def __init__(self, device, carrier=None, uid=None):
         self.R, self.r = world_size(), rank()
         self.device = torch.device(device)
         backend = dist.get_backend() if is_dist() else None
@@ -152,7 +152,14 @@ class Exchange:
         self._recv, self._send = {}, {}
         if carrier == "rccl":
             from . import rccl
-            self.comm = rccl.Communicator(self.device)
+            self.comm = rccl.Communicator(self.device, uid=uid)
+
+    def close(self, abort=False):
+        """Give the RCCL communicator back (abort: without waiting for outstanding work)."""
+        if self.comm is not None:
+            (self.comm.abort if abort else self.comm.destroy)()
+            self.comm = None
+            self.carrier, self.capturable = "none", True
 
     def shard_bounds(self, buf):
         n = buf.numel()
@@ -212,6 +219,14 @@ class Exchange:
                     dist.all_reduce(b)
                     b.div_(self.R)
 
+    def all_reduce_max(self, buf):
+        """Element-wise maximum over the ranks, in place (the overflow word of the dynamic loss scale: one int32)."""
+        if self.carrier == "rccl":
+            from . import rccl
+            self.comm.all_reduce_(buf, op=rccl.ncclMax)
+        elif self.carrier in ("torch", "gloo"):
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+
     def self_test(self, graph=True, agree=True):
         """Known-answer check of the three collectives on this carrier (rank r contributes r + 1), eagerly and -- for a
         capturable carrier on a GPU -- replayed from a captured graph.  Returns True when every rank agrees that every
@@ -233,7 +248,10 @@ class Exchange:
                 self.all_reduce_avg(b)
             a, b = fill(), fill()
             run(a, b)
-            ok = bool(torch.all(a == want)) and bool(torch.all(b == want))
+            # (RCCL forms the average as a pre-multiplied sum: for rank counts that are not powers of two the result may sit
+            # one ulp beside (R + 1) / 2)
+            right = lambda t: bool(torch.allclose(t, torch.full_like(t, want), rtol=1e-6, atol=0.0))
+            ok = right(a) and right(b)
             if ok and graph and self.capturable and self.device.type == "cuda" and self.carrier == "rccl":
                 a.fill_(float(self.r + 1))
                 b.fill_(float(self.r + 1))
@@ -245,7 +263,7 @@ class Exchange:
                     b.fill_(float(self.r + 1))
                     g.replay()
                     torch.cuda.synchronize(self.device)
-                    ok = ok and bool(torch.all(a == want)) and bool(torch.all(b == want))
+                    ok = ok and right(a) and right(b)
         except Exception as e:      # noqa: BLE001 -- any failure means "do not use this carrier"
             print(f"[rank {self.r}] Exchange.self_test({self.carrier}) failed: {e}", flush=True)
             ok = False
@@ -265,29 +283,58 @@ def all_ranks_agree(ok, device):
 def guarded_rccl_exchange(device, timeout_s=None):
     """An Exchange over bare RCCL calls that has passed its self-test on every rank -- or None, on every rank.
 
-    Communicator set-up and the self-test (eager and replayed from a captured graph) run in a worker thread with a
-    deadline: a carrier that has never seen more than one rank must not be able to hang the job it is supposed to speed
-    up.  A rank whose worker is still busy at the deadline votes "no" from its main thread; the vote travels over
-    torch.distributed's own communicator, so it completes whatever state the abandoned worker is in."""
+    A carrier that has never seen more than one rank must not be able to hang the job it is supposed to speed up, nor to
+    take torch.distributed's own communicator down with it:
+      * the unique id travels through the process group's key-value STORE, on the main thread -- no collective of ours ever
+        touches the default group;
+      * communicator set-up and the self-test (eager and replayed from a captured graph) run in a worker thread, the
+        self-test on a stream of its own, under a deadline (`NGP_RCCL_TIMEOUT`, 240 s);
+      * a rank whose worker has not answered in time ABORTS its communicator if it has one (ncclCommAbort: the kernels of a
+        collective that will never complete leave the GPU) and votes "no"; the vote is an all-reduce over the default
+        group, which nothing of the worker's has used;
+      * unless every rank votes "yes" every rank closes its communicator and the caller falls back to torch.distributed's
+        collectives between graph segments -- and says why."""
     import threading
+    from . import rccl
     timeout_s = float(os.environ.get("NGP_RCCL_TIMEOUT", "240")) if timeout_s is None else float(timeout_s)
-    box = {}
+    dev = torch.device(device)
+    box, why = {}, None
+    try:
+        uid = rccl.exchange_unique_id()         # main thread, over the store
+    except Exception as e:      # noqa: BLE001 -- no id, no carrier
+        uid, why = None, f"unique id: {e}"
 
     def work():
         try:
-            if torch.device(device).type == "cuda":
-                torch.cuda.set_device(device)
-            x = Exchange(device, carrier="rccl")
-            box["ok"] = x.carrier == "rccl" and x.self_test(agree=False)
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)
+            x = Exchange(dev, carrier="rccl", uid=uid)
             box["x"] = x
+            side = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side):
+                box["ok"] = x.carrier == "rccl" and x.self_test(agree=False)
+            side.synchronize()
         except Exception as e:      # noqa: BLE001 -- any failure means "do not use this carrier"
             box["ok"] = False
-            print(f"[rank {rank()}] direct RCCL exchange: {e}", flush=True)
+            box["why"] = str(e)
 
-    t = threading.Thread(target=work, daemon=True)
-    t.start()
-    t.join(timeout_s)
-    mine = (not t.is_alive()) and bool(box.get("ok"))
-    if t.is_alive():
-        print(f"[rank {rank()}] direct RCCL exchange: no answer within {timeout_s:.0f} s", flush=True)
-    return box.get("x") if all_ranks_agree(mine, device) else None
+    if uid is not None:
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        t.join(timeout_s)
+        if t.is_alive():
+            why = f"no answer within {timeout_s:.0f} s"
+            x = box.get("x")
+            if x is not None:               # set up, but stuck in (or before) a collective: get its kernels off the GPU
+                x.close(abort=True)
+        elif not box.get("ok"):
+            why = box.get("why", "self-test: wrong result")
+    mine = why is None and bool(box.get("ok"))
+    if why is not None:
+        print(f"[rank {rank()}] direct RCCL exchange not used: {why}", flush=True)
+    if all_ranks_agree(mine, dev):
+        return box["x"]
+    x = box.get("x")
+    if x is not None and mine:              # some other rank failed: give this rank's healthy communicator back
+        x.close(abort=True)
+    return None

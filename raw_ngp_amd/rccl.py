@@ -4,7 +4,7 @@ Why not torch.distributed for these: a ProcessGroupNCCL collective brings its ow
 inside a hipGraph capture that bookkeeping is the fragile part.  A bare ncclReduceScatter / ncclAllGather on the capture
 stream is one kernel node of the step graph like any other, so a group of training steps -- collectives included --
 replays from ONE graph launch (raw_ngp_amd.nerf.engine, `dp_exchange = "rccl"`).  torch.distributed stays what it is good
-at: rendezvous (the unique id travels over the default process group), barriers, the CPU/gloo rehearsal.
+at: rendezvous (the unique id travels through the process group's key-value store), barriers, the CPU/gloo rehearsal.
 
 The library is the librccl.so PyTorch already links (same symbols, one copy in the process).  Everything here is in place:
   reduce_scatter(buf): every rank passes its full-length buffer, rank r ends with the reduction of shard r AT shard r
@@ -39,12 +39,13 @@ def lib():
         L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
         L.ncclCommInitRank.argtypes = [ctypes.POINTER(vp), i, _UniqueId, i]
         L.ncclCommDestroy.argtypes = [vp]
+        L.ncclCommAbort.argtypes = [vp]
         L.ncclReduceScatter.argtypes = [vp, vp, sz, i, i, vp, vp]         # send, recv, recvcount, dtype, op, comm, stream
         L.ncclAllGather.argtypes = [vp, vp, sz, i, vp, vp]                # send, recv, sendcount, dtype, comm, stream
         L.ncclAllReduce.argtypes = [vp, vp, sz, i, i, vp, vp]             # send, recv, count, dtype, op, comm, stream
         L.ncclGroupStart.argtypes = []
         L.ncclGroupEnd.argtypes = []
-        for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclReduceScatter", "ncclAllGather",
+        for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclReduceScatter", "ncclAllGather",
                      "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd"):
             getattr(L, name).restype = i
         _lib = L
@@ -56,25 +57,41 @@ def _check(rc, what):
         raise RuntimeError(f"RCCL: {what} failed: {lib().ncclGetErrorString(rc).decode()}")
 
 
+_uid_round = [0]
+
+
+def exchange_unique_id():
+    """The communicator's unique id, created on rank 0 and handed to the others through torch.distributed's key-value STORE
+    (TCP; the rendezvous the process group itself was built over) -- not through a collective: whatever happens to a
+    communicator that is being set up, the default process group has seen no traffic of ours and stays usable (for the
+    vote in parallel.guarded_rccl_exchange, for the fallback carrier).  Call on every rank, from the main thread."""
+    import torch.distributed as dist
+    assert dist.is_initialized(), "rccl: initialise torch.distributed first (its store carries the unique id)"
+    store = dist.distributed_c10d._get_default_store()
+    key = f"raw_ngp_amd/rccl_uid/{_uid_round[0]}"
+    _uid_round[0] += 1
+    if dist.get_rank() == 0:
+        uid = _UniqueId()
+        _check(lib().ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        store.set(key, bytes(uid))
+        return bytes(uid)
+    return bytes(store.get(key))            # blocks until rank 0 has set it (the store's own timeout applies)
+
+
 class Communicator:
     """One RCCL communicator over the ranks of torch.distributed's default group (one process per GPU)."""
 
-    def __init__(self, device):
+    def __init__(self, device, uid=None):
         import torch.distributed as dist
-        assert dist.is_initialized(), "rccl.Communicator: initialise torch.distributed first (it carries the unique id)"
         self.device = torch.device(device)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        L = lib()
-        uid = _UniqueId()
-        if self.rank == 0:
-            _check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        on = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=on)
-        dist.broadcast(t, src=0)
-        ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().tolist()), NCCL_UNIQUE_ID_BYTES)
+        raw = exchange_unique_id() if uid is None else uid
+        assert len(raw) == NCCL_UNIQUE_ID_BYTES
+        u = _UniqueId()
+        ctypes.memmove(ctypes.byref(u), raw, NCCL_UNIQUE_ID_BYTES)
         self.comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _check(L.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+            _check(lib().ncclCommInitRank(ctypes.byref(self.comm), self.world, u, self.rank), "ncclCommInitRank")
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -125,4 +142,11 @@ class Communicator:
     def destroy(self):
         if self.comm:
             lib().ncclCommDestroy(self.comm)
+            self.comm = ctypes.c_void_p()
+
+    def abort(self):
+        """Tear the communicator down without waiting for its outstanding work (ncclCommAbort: kernels of a collective that
+        will never complete leave the GPU) -- what a rank does with a carrier that missed its deadline."""
+        if self.comm:
+            lib().ncclCommAbort(self.comm)
             self.comm = ctypes.c_void_p()

@@ -55,3 +55,20 @@ def test_shims_fail_loudly_without_device_tensors():
         _lib.shencoder_backend.sh_encode_forward(t, torch.zeros(4, 16), 4, 3, 4, None)
     with pytest.raises(RuntimeError, match="CUDA tensor"):
         _lib.raymarching_backend.morton3D(torch.zeros(4, 3, dtype=torch.int32), 4, torch.zeros(4, dtype=torch.int32))
+
+
+def test_bench_refuses_a_multi_gpu_request_it_cannot_serve():
+    """bench.py --gpus 2 on a box without two GPUs (and without the one-device rehearsal switches) exits non-zero before it
+    touches anything -- it never reports a one-GPU number under the two-GPU name."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("a multi-GPU box serves the request")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGP_LOCAL_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "{" not in out.stdout
+    assert "refusing" in out.stderr

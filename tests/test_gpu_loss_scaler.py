@@ -1,0 +1,252 @@
+"""The dynamic loss scale of the fused MLP backward: torch.cuda.amp.GradScaler's rule (the reference: nerf/train_utils.py:404,
+897-904 -- initial scale 2^16, x0.5 and the optimiser step skipped when a gradient is non-finite, x2 after 2000 clean steps)
+kept in eight device words and settled by the kernels of the step themselves (include/ngp_hip.h, "Dynamic loss scale").
+
+What is checked: the bookkeeping against torch's own GradScaler / a host model of it; that a step whose f16 deltas overflow
+changes NO parameter (table, MLP weights, Adam moments, operand image) and halves the scale; that without overflow the
+dynamic path trains the bits of the static one; and that at the DEFAULT scale the fused step's gradients agree with fp32
+autograd on an untrained field (where a scale of 1024 lost 12 % of the table gradient to f16 underflow)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from raw_ngp_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _trainer(num_rays=1024, views=6, **kw):
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=num_rays, iters=200, fused_mlp=True, **kw)
+    data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=views, H=64, W=64)
+    if opt.rfield:
+        from raw_ngp_amd.nerf import pose as P
+        data.ldirs = torch.from_numpy(P.synthetic_light_dirs(views)).cuda()
+    return opt, data, FusedTrainer(opt, NeRFNetwork(opt).cuda(), data, device="cuda", capacity=num_rays * 256)
+
+
+def test_step_begin_settles_the_previous_step_like_gradscaler(lib):
+    """ngp_x_step_begin with the scaler's words against a host model of GradScaler.update() + Adam's step count, through
+    clean steps, growth and overflows; the bias corrections follow the optimiser steps TAKEN, the learning rate the counter."""
+    e = lib.engine_backend
+    sc = lib.LossScaler("cuda", init_scale=1024.0, growth_interval=3)
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hyper = torch.zeros(4, device="cuda")
+    scale, tracker, taken, skipped = 1024.0, 0, 0, 0
+    overflow_at = {4, 5, 9, 10, 11, 17}         # steps (0-based) whose kernels raise the overflow word
+    b1, b2, lr0, decay = 0.9, 0.999, 1e-2, 30.0
+    for step in range(24):
+        e.step_begin(ctr, hyper, lr0, decay, b1, b2, scaling=sc)
+        if step > 0:                            # what step - 1 left behind is settled now
+            if (step - 1) in overflow_at:
+                scale, tracker, skipped = scale * 0.5, 0, skipped + 1
+            else:
+                taken, tracker = taken + 1, tracker + 1
+                if tracker >= 3:
+                    scale, tracker = scale * 2.0, 0
+        st = sc.state()
+        assert st == dict(scale=scale, found_inf=0, growth_tracker=tracker, steps_taken=taken, steps_skipped=skipped), (step, st)
+        np.testing.assert_allclose(float(sc.words[1]), 1.0 / scale, rtol=1e-7)
+        h = hyper.cpu().numpy()
+        t = taken + 1
+        np.testing.assert_allclose(h[:3], [lr0 * 0.1 ** min(step / decay, 1.0), 1 - b1 ** t, 1 / np.sqrt(1 - b2 ** t)], rtol=3e-7)
+        assert int(ctr) == step + 1
+        if step in overflow_at:
+            sc.found.fill_(1)                   # (what the weight-gradient reduction / the table reduce do on overflow)
+
+
+def test_gradscaler_is_the_model(lib):
+    """The same sequence through torch.cuda.amp.GradScaler itself (scale / found-inf bookkeeping is device-agnostic):
+    the scale after every update() equals the device words'."""
+    e = lib.engine_backend
+    sc = lib.LossScaler("cuda", init_scale=65536.0, growth_interval=4)
+    ref = torch.amp.GradScaler("cuda", init_scale=65536.0, growth_interval=4)
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hyper = torch.zeros(4, device="cuda")
+    p = torch.nn.Parameter(torch.zeros(4, device="cuda"))
+    optim = torch.optim.SGD([p], lr=0.1)
+    rng = np.random.default_rng(3)
+    e.step_begin(ctr, hyper, 1e-2, 100.0, 0.9, 0.999, scaling=sc)
+    for step in range(40):
+        bad = bool(rng.random() < 0.2)
+        ref.scale(torch.ones((), device="cuda"))        # (lazily creates the scale tensor; the gradient is set by hand)
+        p.grad = torch.full_like(p, float("inf") if bad else 1.0)
+        ref.step(optim)
+        ref.update()
+        if bad:
+            sc.found.fill_(1)
+        e.step_begin(ctr, hyper, 1e-2, 100.0, 0.9, 0.999, scaling=sc)
+        assert sc.state()["scale"] == ref.get_scale(), step
+
+
+def test_an_overflowing_step_changes_no_parameter_and_halves_the_scale(lib):
+    """Initial scale 2^40: the output deltas overflow f16 in every step until the scale has come down far enough.  While it
+    does, table, MLP weights, moments and the operand image keep their bits; afterwards training proceeds and everything
+    stays finite.  Eager launches and graph replay agree on when that happens."""
+    seen = []
+    for graph in (False, True):
+        opt, data, tr = _trainer(loss_scale=2.0 ** 40, capture_graph=graph)
+        assert tr.scaler is not None and tr.fuse_adam
+        tr.train_step()                         # (step 0 also refreshes the density grid and prepares the operand image)
+        torch.cuda.synchronize()
+        snap = lambda: [t.clone() for t in (tr.table, tr.w_flat, tr.t_m, tr.t_v, tr.w_m, tr.w_v, tr.mlp_image)]
+        history, before = [], snap()
+        for step in range(1, 40):
+            tr.train_step()
+            torch.cuda.synchronize()
+            st = tr.scaler.state()              # found_inf: this step's verdict (settled by the next step_begin)
+            after = snap()
+            same = all(torch.equal(a, b) for a, b in zip(before, after))
+            assert same == bool(st["found_inf"]), (step, st)
+            history.append(st["found_inf"])
+            before = after
+        st = tr.scaler.state()
+        assert st["steps_skipped"] >= 10 and st["steps_taken"] >= 5, st
+        assert st["scale"] == 2.0 ** (40 - st["steps_skipped"])
+        assert st["steps_taken"] + st["steps_skipped"] == 39                 # (the 40th step is not settled yet)
+        assert all(bool(torch.isfinite(t.float()).all()) for t in before)
+        assert history[-1] == 0 and sum(history) >= 10
+        seen.append((history, st))
+    assert seen[0] == seen[1]
+
+
+@pytest.mark.parametrize("mode", ["fused", "exchange", "rfield", "rfield-barf"])
+def test_without_overflow_the_dynamic_scale_trains_the_bits_of_the_static_one(lib, mode):
+    """Same scale, no overflow, no growth inside the run: deltas, gradients, Adam (t = steps taken = steps done) are the same
+    numbers whether the scale is a launch argument or a device word -- and whether the MLP weights' Adam step rides on the
+    fill launch (static) or on the reduce launch (dynamic).  40 steps, graphs, prefetch, refreshes: identical bits."""
+    kw = {"fused": dict(), "exchange": dict(fuse_adam=False), "rfield": dict(rfield=True),
+          "rfield-barf": dict(rfield=True, pose_opt="barf", noise=0.03)}[mode]
+    out = []
+    for dynamic in (True, False):
+        opt, data, tr = _trainer(dynamic_loss_scale=dynamic, loss_scale=4096.0, **kw)
+        assert (tr.scaler is not None) == dynamic
+        for _ in range(40):
+            tr.train_step()
+        torch.cuda.synchronize()
+        if dynamic:
+            st = tr.scaler.state()
+            assert st["steps_skipped"] == 0 and st["steps_taken"] == 39 and st["scale"] == 4096.0, st
+        out.append((tr.table.clone(), tr.w_flat.clone(), tr.mlp_image.clone(), tr.refined_poses()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
+def test_default_scale_has_left_the_underflow_behind_on_an_untrained_field(lib):
+    """4096 rays through an untrained field (per-sample gradients ~ 1e-7: where a static scale of 1024 put the f16 deltas into
+    the subnormals and cost ~ 10 % of the table gradient).  Three runs of the fused step on the same batch and weights: the
+    DEFAULT (dynamic, 2^16: GradScaler's start), static 2^24 (the same kernels with the deltas far above the subnormals) and
+    static 1024 (last round's default).  The default agrees with the 2^24 run to 3e-3 in the table and the weight gradients,
+    the 1024 run does not; against torch autograd over fp32 nn.Linear MLPs the default is as close as 2^24 is -- what is left
+    there (1.4e-2 on the table: features of ~ 1e-4 flip ReLUs of pre-activations that are ~ 0 when they become f16 operands,
+    as they do under the reference's autocast) does not depend on the scale any more (tools/loss_scale_probe.py)."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    res = {}
+    for scale in (None, 2.0 ** 24, 1024.0):
+        torch.manual_seed(0)
+        kw = {} if scale is None else dict(loss_scale=scale, dynamic_loss_scale=False)
+        opt = Options(bound=1.0, num_rays=4096, iters=100, fused_mlp=True, background="black", **kw)
+        assert scale is not None or (opt.loss_scale == 65536.0 and opt.dynamic_loss_scale)
+        data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=4, H=64, W=64)
+        model = NeRFNetwork(opt).cuda()
+        eng = FusedTrainer(opt, model, data, device="cuda", capacity=4096 * 256)
+        assert (eng.scaler is not None) == (scale is None)
+        model.train()
+        model.update_extra_state()
+        batch = data.sample_rays(opt.num_rays, torch.Generator(device="cuda").manual_seed(1))
+        gt = batch["images"]
+        eng.forward_backward(batch["rays_o"].contiguous(), batch["rays_d"].contiguous(), gt.contiguous(),
+                             torch.zeros(opt.num_rays, device="cuda"))
+        torch.cuda.synchronize()
+        if eng.scaler is not None:
+            assert eng.scaler.state()["found_inf"] == 0
+        M = int(eng.arena.counter[0])
+        # fp32 reference: the same module with nn.Linear MLPs (fused_mlp off), same weights, same samples
+        opt.fused_mlp = False
+        model.zero_grad()
+        out = model.render(batch["rays_o"], batch["rays_d"], bg_color=0, perturb=False)
+        assert out["num_points"] == M
+        loss = ((out["image"] - gt[:, :3] * gt[:, 3:]) ** 2).mean(-1).mean()
+        loss.backward()
+        ref_t = model.grid_encoder.embeddings.grad.clone()
+        ref_w = torch.cat([l.weight.grad.reshape(-1) for l in list(model.grid_mlp.net) + list(model.view_mlp.net)])
+        res[scale] = (eng.table_grad.clone(), eng.w_grad.clone(), ref_t, ref_w, float(eng.loss), float(loss.detach()))
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    (t0, w0, rt, rw, l0, lref), (t24, w24, rt24, rw24, _, _), (t10, w10, _, _, _, _) = res[None], res[2.0 ** 24], res[1024.0]
+    assert torch.equal(rt, rt24) or rel(rt, rt24) < 1e-5          # same weights, same batch in every run
+    line = (f"default vs 2^24: table {rel(t0, t24):.2e} weights {rel(w0, w24):.2e}; 1024 vs 2^24: table {rel(t10, t24):.2e} "
+            f"weights {rel(w10, w24):.2e}; vs fp32 autograd: default {rel(t0, rt):.2e} / {rel(w0, rw):.2e}, "
+            f"2^24 {rel(t24, rt):.2e} / {rel(w24, rw):.2e}, 1024 {rel(t10, rt):.2e} / {rel(w10, rw):.2e}")
+    print(line)
+    assert abs(l0 / lref - 1) < 2e-4
+    assert rel(t0, t24) < 3e-3 and rel(w0, w24) < 3e-3, line
+    assert rel(t10, t24) > 3e-2, line                             # (what the static 1024 cost)
+    assert rel(t0, rt) < 1.1 * rel(t24, rt) + 1e-3 and rel(w0, rw) < 1.1 * rel(w24, rw) + 1e-3, line
+    assert rel(t0, rt) < 2.5e-2 and rel(w0, rw) < 3e-3, line
+
+
+@pytest.mark.parametrize("rf", [False, True], ids=["plain", "rfield"])
+def test_kernels_read_the_scale_from_the_device_and_raise_the_overflow_word(lib, rf):
+    """ngp_x_mlp(_rf)_backward_list with the scaler's words: (1) the same scale as a device word or as a launch argument gives
+    the same bits; (2) an output gradient that overflows f16 is NOT clipped -- some weight gradient is non-finite and the
+    overflow word is raised (with the static scale everything stays finite: test_backward_saturates_instead_of_overflowing);
+    (3) an optimiser kernel handed the word leaves its tensors alone."""
+    from test_gpu_fused_mlp import make_weights
+    mb = lib.mlp_rf_backend if rf else lib.mlp_backend
+    M = 3000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    if rf:
+        from test_gpu_fused_mlp_rf import make_weights as make_rf
+        W = make_rf(4)
+    else:
+        W = make_weights(4)
+    enc = torch.randn(16, M, 2, device="cuda", generator=g) * 0.5
+    dirs, ldirs = torch.randn(M, 3, device="cuda", generator=g), torch.randn(M, 3, device="cuda", generator=g)
+    dsigma = torch.randn(M, device="cuda", generator=g) * 1e-4
+    drgb = torch.randn(M, 3, device="cuda", generator=g) * 1e-4
+    image = torch.empty(mb.image_bytes(), dtype=torch.uint8, device="cuda")
+    mb.prepare(W, image)
+
+    def run(dsig, scale_arg, scaler):
+        denc = torch.zeros(16, M, 2, device="cuda")
+        dws = [torch.zeros_like(w) for w in W]
+        if rf:
+            mb.backward(enc, M, dirs, ldirs, None, dsig, drgb, None, M, image, scale_arg, denc, None, dws, scaler=scaler)
+        else:
+            mb.backward(enc, M, dirs, dsig, drgb, None, M, image, scale_arg, denc, dws, scaler=scaler)
+        torch.cuda.synchronize()
+        return [denc] + dws
+
+    sc = lib.LossScaler("cuda", init_scale=8192.0)
+    for a, b in zip(run(dsigma, 8192.0, None), run(dsigma, 1.0, sc)):
+        assert torch.equal(a, b)
+    assert sc.state()["found_inf"] == 0
+    hot = dsigma.clone()
+    hot[1234] = 1e3                                     # x exp(raw) x 8192 is far beyond 65504
+    out = run(hot, 1.0, sc)
+    assert sc.state()["found_inf"] == 1
+    assert not all(bool(torch.isfinite(t).all()) for t in out[1:])
+    assert all(bool(torch.isfinite(t).all()) for t in run(hot, 8192.0, None))       # static: clipped, finite
+    # the optimiser kernels under the raised word
+    e = lib.engine_backend
+    p, gr, m, v = (torch.randn(4099, device="cuda") for _ in range(4))
+    v.abs_()
+    hyper = torch.tensor([1e-2, 0.1, 3.0, 0.0], device="cuda")
+    keep = [t.clone() for t in (p, m, v)]
+    e.adam_step_dev(p, gr, m, v, hyper, 0.9, 0.999, 1e-15, skip=sc.found)
+    assert all(torch.equal(a, b) for a, b in zip(keep, (p, m, v)))
+    sc.found.zero_()
+    e.adam_step_dev(p, gr, m, v, hyper, 0.9, 0.999, 1e-15, skip=sc.found)
+    assert not torch.equal(keep[0], p)
