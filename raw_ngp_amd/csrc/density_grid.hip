@@ -151,9 +151,15 @@ __device__ __forceinline__ void store_draw(uint32_t slot, int32_t index, uint32_
         return;
     }
     const float inv = (float)(H - 1u);
-    xyzs[(size_t)slot * 3] = ((2.0f * (float)cx) / inv - 1.0f) * span + (u01(q[0]) * 2.0f - 1.0f) * half;
-    xyzs[(size_t)slot * 3 + 1] = ((2.0f * (float)cy) / inv - 1.0f) * span + (u01(q[1]) * 2.0f - 1.0f) * half;
-    xyzs[(size_t)slot * 3 + 2] = ((2.0f * (float)cz) / inv - 1.0f) * span + (u01(q[2]) * 2.0f - 1.0f) * half;
+    // one 12-byte store (global_store_dwordx3) instead of three: the slots of a sorted draw are scattered
+    struct P3 {
+        float x, y, z;
+    };
+    P3 p;
+    p.x = ((2.0f * (float)cx) / inv - 1.0f) * span + (u01(q[0]) * 2.0f - 1.0f) * half;
+    p.y = ((2.0f * (float)cy) / inv - 1.0f) * span + (u01(q[1]) * 2.0f - 1.0f) * half;
+    p.z = ((2.0f * (float)cz) / inv - 1.0f) * span + (u01(q[2]) * 2.0f - 1.0f) * half;
+    reinterpret_cast<P3 *>(xyzs)[slot] = p;
 }
 
 __global__ __launch_bounds__(256) void grid_sample_cells_kernel(GridWs g, uint32_t n_words, uint32_t H, float span,
@@ -176,48 +182,110 @@ __global__ __launch_bounds__(256) void grid_sample_cells_kernel(GridWs g, uint32
 // ---- the same draws, delivered in Morton order -----------------------------------------------------------------------
 // The cells are evaluated by the hash-grid encoder, whose coarse and middle levels hit the caches only if neighbouring
 // points arrive together: 2^19 uniformly drawn cells in draw order cost the encoder 225 us, the same cells sorted 183 (and
-// the scatter of their densities 25 us instead of 44).  Counting sort of each half on a key that is UNIFORM over its 4096
-// bins, so that one global atomic per draw meets no contention: the uniform half by the top 12 bits of the cell's Morton
-// index, the occupied half by the top 12 bits of its random number -- the pick r = floor(u * n_pos) enumerates the occupied
-// cells in Morton order, so sorting by u sorts by cell.  Pass A draws the random numbers and counts, a scan turns counts
-// into offsets, pass B draws again (same counter-based numbers), resolves the cell (the occupied half's binary search
-// happens once, here) and writes draw i to the next free slot of its bin.  The order inside a bin depends on the atomics;
-// nothing downstream does (each point is evaluated on its own, duplicates of a cell resolve by maximum).
+// the scatter of their densities 25 us instead of 44).  Counting sort of each half on a 12-bit key that is UNIFORM over
+// its 4096 bins: the uniform half by the top 12 bits of the cell's Morton index, the occupied half by the top 12 bits of
+// its random number -- the pick r = floor(u * n_pos) enumerates the occupied cells in Morton order, so sorting by u sorts
+// by cell.
+// Round 3 counted and placed with one GLOBAL atomic per draw (2 x 2^20 of them per refresh: 66 + 101 us of kernels that run
+// on the side stream beside the step in front of the refresh -- whose MLP backward, list and fill kernels took 116 us
+// longer beside them: the atomics saturate the L2's atomic units for everybody).  Now every atomic is an LDS atomic:
+//   count   workgroup w owns draws [w T, (w + 1) T) (T = 2048, all of one half): histogram of their keys in LDS,
+//           written out as row w of wg_hist[workgroups][4096] (coalesced, no atomics)
+//   offsets one lane per (half, bin): the column's running sum over the half's workgroups -> wg_hist[w][bin] becomes the
+//           rank of workgroup w's first draw inside the bin; the column total goes to `hist`
+//   scan    exclusive scan of the totals (one workgroup) -> base[bin]
+//   place   workgroup w draws the same numbers again (counter-based), starts an LDS cursor per bin at base + its rank and
+//           hands out slots with LDS atomics; resolves the cell (the occupied half's binary search happens once, here) and
+//           writes the draw to its slot.
+// The order inside (workgroup, bin) depends on the order of the LDS atomics; nothing downstream does (each point is
+// evaluated on its own, duplicates of a cell resolve by maximum).
 constexpr uint32_t kSortBins = 8192;   // 4096 per half
+constexpr uint32_t kSortTile = 2048;   // draws per workgroup (a divisor of each half's size, or the launcher falls back)
+constexpr uint32_t kSortBlock = 512;   // ... of this many lanes: kSortPer draws each, their latency chains side by side
+constexpr uint32_t kSortPer = kSortTile / kSortBlock;
+constexpr uint32_t kSortHalf = kSortBins / 2u;
 struct SortWs {
-    uint32_t *hist, *base, *cursor;    // kSortBins words each
+    uint32_t *hist, *base;             // kSortBins words each: column totals, first slot of every bin
+    uint32_t *wg_hist;                 // [workgroups][kSortHalf]: counts, then ranks
 };
 __host__ __device__ inline SortWs sort_ws(void *ws, uint32_t n_words)
 {
     SortWs s;
     s.hist = grid_ws(ws, n_words).prefix + n_words + 1;
     s.base = s.hist + kSortBins;
-    s.cursor = s.base + kSortBins;
+    s.wg_hist = s.base + kSortBins;
     return s;
 }
+// 12-bit key inside the draw's half
 __device__ __forceinline__ uint32_t sort_key(uint32_t i, uint32_t n_uniform, uint32_t H, uint32_t shift, const uint32_t r[4])
 {
     if (i < n_uniform)
-        return min(morton3(__umulhi(r[0], H), __umulhi(r[1], H), __umulhi(r[2], H)) >> shift, kSortBins / 2u - 1u);
-    return kSortBins / 2u + (r[0] >> 20);
+        return min(morton3(__umulhi(r[0], H), __umulhi(r[1], H), __umulhi(r[2], H)) >> shift, kSortHalf - 1u);
+    return r[0] >> 20;
 }
 
-__global__ __launch_bounds__(256) void grid_sort_zero_kernel(SortWs s)
+__global__ __launch_bounds__(kSortBlock) void grid_sort_count_kernel(SortWs s, uint32_t H, uint32_t n_uniform, uint32_t n,
+                                                                    uint32_t shift, uint32_t seed_lo, uint32_t seed_hi,
+                                                                    const uint32_t *__restrict__ draw_dev, uint32_t draw)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < kSortBins) s.hist[i] = s.cursor[i] = 0u;
-}
-
-__global__ __launch_bounds__(256) void grid_sort_count_kernel(SortWs s, uint32_t H, uint32_t n_uniform, uint32_t n,
-                                                             uint32_t shift, uint32_t seed_lo, uint32_t seed_hi,
-                                                             const uint32_t *__restrict__ draw_dev, uint32_t draw)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
+    __shared__ uint32_t h[kSortHalf];
+    for (uint32_t k = threadIdx.x; k < kSortHalf; k += kSortBlock) h[k] = 0u;
+    __syncthreads();
     if (draw_dev) draw = draw_dev[0];
-    uint32_t r[4] = {i, draw, 2u, 0u};
-    philox4x32_10(r, seed_lo, seed_hi);
-    atomicAdd(&s.hist[sort_key(i, n_uniform, H, shift, r)], 1u);
+    const uint32_t i0 = blockIdx.x * kSortTile;
+#pragma unroll
+    for (uint32_t j = 0; j < kSortPer; j++) {
+        const uint32_t i = i0 + j * kSortBlock + threadIdx.x;
+        if (i < n) {
+            uint32_t r[4] = {i, draw, 2u, 0u};
+            philox4x32_10(r, seed_lo, seed_hi);
+            atomicAdd(&h[sort_key(i, n_uniform, H, shift, r)], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *row = s.wg_hist + (size_t)blockIdx.x * kSortHalf;
+    for (uint32_t k = threadIdx.x; k < kSortHalf; k += kSortBlock) row[k] = h[k];
+}
+
+// Column sums of wg_hist over a half's workgroups, made exclusive: 32 bins x 8 row segments per workgroup of 256 lanes.  A lane
+// takes its segment's rows in batches of 16 independent loads (consecutive lanes = consecutive bins: 128-byte rows), the eight
+// segment totals of a bin meet in LDS.  (One lane per column, walking it row by row, took 98 us: 256 dependent round trips.)
+__global__ __launch_bounds__(256) void grid_sort_offsets_kernel(SortWs s, uint32_t wg_uniform, uint32_t wg_total)
+{
+    __shared__ uint32_t seg_sum[8][32];
+    const uint32_t b = threadIdx.x & 31u, sg = threadIdx.x >> 5;
+    const uint32_t t = blockIdx.x * 32u + b;                       // (half, bin); kSortBins is a multiple of 32
+    const uint32_t half = t / kSortHalf, bin = t - half * kSortHalf;
+    const uint32_t w0 = half ? wg_uniform : 0u, w1 = half ? wg_total : wg_uniform;
+    const uint32_t per = (w1 - w0 + 7u) / 8u, r0 = min(w1, w0 + sg * per), r1 = min(w1, r0 + per);
+    uint32_t *col = s.wg_hist + bin;
+    uint32_t sum = 0;
+    for (uint32_t w = r0; w < r1; w += 16u) {
+        uint32_t c[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) c[k] = w + k < r1 ? col[(size_t)(w + k) * kSortHalf] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) sum += c[k];
+    }
+    seg_sum[sg][b] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        if (k < sg) run += seg_sum[k][b];
+        total += seg_sum[k][b];
+    }
+    for (uint32_t w = r0; w < r1; w += 16u) {
+        uint32_t c[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) c[k] = w + k < r1 ? col[(size_t)(w + k) * kSortHalf] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            if (w + k < r1) col[(size_t)(w + k) * kSortHalf] = run;
+            run += c[k];
+        }
+    }
+    if (sg == 0) s.hist[t] = total;
 }
 
 __global__ __launch_bounds__(1024) void grid_sort_scan_kernel(SortWs s)   // one workgroup: exclusive scan of the counts
@@ -248,23 +316,78 @@ __global__ __launch_bounds__(1024) void grid_sort_scan_kernel(SortWs s)   // one
     }
 }
 
-__global__ __launch_bounds__(256) void grid_sort_place_kernel(GridWs g, SortWs s, uint32_t n_words, uint32_t H, float span,
-                                                             float half, uint32_t n_uniform, uint32_t n_occupied,
-                                                             uint32_t shift, uint32_t seed_lo, uint32_t seed_hi,
-                                                             const uint32_t *__restrict__ draw_dev, uint32_t draw,
-                                                             int32_t *__restrict__ indices, float *__restrict__ xyzs)
+__global__ __launch_bounds__(kSortBlock) void grid_sort_place_kernel(GridWs g, SortWs s, uint32_t n_words, uint32_t H,
+                                                                    float span, float half, uint32_t n_uniform,
+                                                                    uint32_t n_occupied, uint32_t shift, uint32_t seed_lo,
+                                                                    uint32_t seed_hi, const uint32_t *__restrict__ draw_dev,
+                                                                    uint32_t draw, int32_t *__restrict__ indices,
+                                                                    float *__restrict__ xyzs)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_uniform + n_occupied) return;
+    __shared__ uint32_t cursor[kSortHalf];
+    const uint32_t i0 = blockIdx.x * kSortTile, n = n_uniform + n_occupied;
+    const bool occupied = i0 >= n_uniform;            // (a workgroup's draws are all of one half)
+    const uint32_t *rank = s.wg_hist + (size_t)blockIdx.x * kSortHalf, *base = s.base + (occupied ? kSortHalf : 0u);
+    for (uint32_t k = threadIdx.x; k < kSortHalf; k += kSortBlock) cursor[k] = base[k] + rank[k];
+    __syncthreads();
     if (draw_dev) draw = draw_dev[0];
-    uint32_t r[4] = {i, draw, 2u, 0u}, q[4] = {i, draw, 3u, 0u};
-    philox4x32_10(r, seed_lo, seed_hi);
-    philox4x32_10(q, seed_lo, seed_hi);
-    const uint32_t key = sort_key(i, n_uniform, H, shift, r);
-    const uint32_t slot = s.base[key] + atomicAdd(&s.cursor[key], 1u);   // (requested before the cell's binary search)
-    uint32_t cx, cy, cz;
-    const int32_t index = draw_cell(g, n_words, H, n_uniform, false, i, r, cx, cy, cz);
-    store_draw(slot, index, cx, cy, cz, H, span, half, q, indices, xyzs);
+    // kSortPer draws per lane, taken side by side: the occupied half's binary search is ~ 18 dependent loads per draw
+    uint32_t r[kSortPer][4], q[kSortPer][4], slot[kSortPer], lo[kSortPer], hi[kSortPer], pick[kSortPer];
+    bool on[kSortPer];
+    const uint32_t n_pos = occupied ? g.prefix[n_words] : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < kSortPer; j++) {
+        const uint32_t i = i0 + j * kSortBlock + threadIdx.x;
+        on[j] = i < n;
+        r[j][0] = q[j][0] = i;
+        r[j][1] = q[j][1] = draw;
+        r[j][2] = 2u;
+        q[j][2] = 3u;
+        r[j][3] = q[j][3] = 0u;
+        philox4x32_10(r[j], seed_lo, seed_hi);
+        philox4x32_10(q[j], seed_lo, seed_hi);
+        slot[j] = on[j] ? atomicAdd(&cursor[sort_key(i, n_uniform, H, shift, r[j])], 1u) : 0u;
+        pick[j] = __umulhi(r[j][0], n_pos);
+        lo[j] = 0;
+        hi[j] = n_words;
+    }
+    if (occupied && n_pos != 0u) {   // largest w with prefix[w] <= pick, kSortPer searches in step (as draw_cell does one)
+        bool more = true;
+        while (more) {
+            more = false;
+#pragma unroll
+            for (uint32_t j = 0; j < kSortPer; j++) {
+                if (hi[j] - lo[j] > 1u) {
+                    const uint32_t mid = (lo[j] + hi[j]) >> 1;
+                    if (g.prefix[mid] <= pick[j])
+                        lo[j] = mid;
+                    else
+                        hi[j] = mid;
+                    more = more || hi[j] - lo[j] > 1u;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kSortPer; j++) {
+        if (!on[j]) continue;
+        uint32_t cx = 0, cy = 0, cz = 0;
+        int32_t index;
+        if (!occupied) {
+            cx = __umulhi(r[j][0], H);
+            cy = __umulhi(r[j][1], H);
+            cz = __umulhi(r[j][2], H);
+            index = (int32_t)morton3(cx, cy, cz);
+        } else if (n_pos == 0u) {
+            index = -1;                                 // nothing occupied yet: the reference leaves this half out
+        } else {
+            const uint32_t cell = lo[j] * 64u + select_bit(g.mask[lo[j]], pick[j] - g.prefix[lo[j]]);
+            cx = compact_bits(cell);
+            cy = compact_bits(cell >> 1);
+            cz = compact_bits(cell >> 2);
+            index = (int32_t)cell;
+        }
+        store_draw(slot[j], index, cx, cy, cz, H, span, half, q[j], indices, xyzs);
+    }
 }
 
 __global__ __launch_bounds__(256) void grid_scatter_kernel(const int32_t *__restrict__ indices,
@@ -350,7 +473,9 @@ using namespace ngp;
 extern "C" size_t ngp_x_density_grid_workspace_bytes(uint32_t H)
 {
     const size_t n_words = (size_t)H * H * H / 64;
-    return n_words * 8 + (n_words + 1) * 4 + 3 * (size_t)kSortBins * 4 + 64;
+    // mask | prefix | sort: column totals, bases, one histogram row per workgroup of the two halves' draws (H^3 / 2 of them)
+    const size_t sort_wgs = ((size_t)H * H * H / 2 + kSortTile - 1) / kSortTile + 2;
+    return n_words * 8 + (n_words + 1) * 4 + 2 * (size_t)kSortBins * 4 + sort_wgs * kSortHalf * 4 + 64;
 }
 
 extern "C" int ngp_x_density_grid_sample(const float *grid_cas, uint32_t H, float span, float half, uint32_t n_uniform,
@@ -376,7 +501,10 @@ extern "C" int ngp_x_density_grid_sample(const float *grid_cas, uint32_t H, floa
     // random draws leave in Morton order of their cells (blocks of cells ascending, any order inside a block): what the
     // encoder that evaluates them wants.  NGP_REFRESH_SORT=0: in draw order (a full sweep is in Morton order as it is)
     static const bool sort_on = !(getenv("NGP_REFRESH_SORT") && getenv("NGP_REFRESH_SORT")[0] == '0');
-    if (full || !sort_on) {
+    // (the sort wants whole workgroups of one half and a workspace row for each: anything else is drawn unsorted)
+    const uint32_t wgs = ceil_div(n, kSortTile), wg_uniform = n_uniform / kSortTile;
+    const bool sortable = n_uniform % kSortTile == 0 && (size_t)wgs <= ((size_t)cells / 2 + kSortTile - 1) / kSortTile + 2;
+    if (full || !sort_on || !sortable) {
         grid_sample_cells_kernel<<<dim3(ceil_div(n, 256u)), dim3(256), 0, st>>>(
             g, n_words, H, span, half, n_uniform, n_occupied, full != 0, (uint32_t)seed, (uint32_t)(seed >> 32), draw_dev, draw,
             indices, xyzs);
@@ -385,14 +513,13 @@ extern "C" int ngp_x_density_grid_sample(const float *grid_cas, uint32_t H, floa
         uint32_t bits = 0;
         while ((1ull << bits) < cells) bits++;
         const uint32_t shift = bits > 12u ? bits - 12u : 0u;
-        grid_sort_zero_kernel<<<dim3(ceil_div(kSortBins, 256u)), dim3(256), 0, st>>>(s);
-        grid_sort_count_kernel<<<dim3(ceil_div(n, 256u)), dim3(256), 0, st>>>(s, H, n_uniform, n, shift, (uint32_t)seed,
-                                                                             (uint32_t)(seed >> 32), draw_dev, draw);
+        grid_sort_count_kernel<<<dim3(wgs), dim3(kSortBlock), 0, st>>>(s, H, n_uniform, n, shift, (uint32_t)seed,
+                                                               (uint32_t)(seed >> 32), draw_dev, draw);
+        grid_sort_offsets_kernel<<<dim3(kSortBins / 32u), dim3(256), 0, st>>>(s, wg_uniform, wgs);
         grid_sort_scan_kernel<<<dim3(1), dim3(1024), 0, st>>>(s);
-        grid_sort_place_kernel<<<dim3(ceil_div(n, 256u)), dim3(256), 0, st>>>(g, s, n_words, H, span, half, n_uniform,
-                                                                             n_occupied, shift, (uint32_t)seed,
-                                                                             (uint32_t)(seed >> 32), draw_dev, draw, indices,
-                                                                             xyzs);
+        grid_sort_place_kernel<<<dim3(wgs), dim3(kSortBlock), 0, st>>>(g, s, n_words, H, span, half, n_uniform, n_occupied, shift,
+                                                               (uint32_t)seed, (uint32_t)(seed >> 32), draw_dev, draw, indices,
+                                                               xyzs);
     }
     NGP_CHECK_LAUNCH("density_grid_sample");
     return NGP_OK;

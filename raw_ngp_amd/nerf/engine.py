@@ -917,6 +917,8 @@ class FusedTrainer:
         opt, model = self.opt, self.model
         model.train()
         step = self.global_step
+        if self._refresh_step_folded(step, batch):
+            return self.loss
         if step % opt.update_extra_interval == 0:
             if self.native_refresh:
                 from .. import _lib
@@ -977,6 +979,56 @@ class FusedTrainer:
         self.global_step += 1
         self.last_loss = self.loss
         return self.loss
+
+    def _refresh_step_folded(self, step, batch):
+        """Steady-state refresh step as ONE graph: the refresh (its cells were drawn ahead, beside the previous step), the
+        rest of this batch's march (it reads the new bitfield), the fork of the side stream for the next batch -- BEHIND the
+        refresh: that march reads the new bitfield too -- and the step.  Launched as three graphs in a row the same work
+        left ~ 40 us of gaps on the critical path (14 us in front of the refresh, 9 in front of the march, 15 in front of
+        the step).  Returns False when the step is not of that kind (train_step then takes it piece by piece)."""
+        from .. import _lib
+        opt, model = self.opt, self.model
+        every = opt.update_extra_interval
+        slot = self.slots[step % len(self.slots)]
+        if not (step % every == 0 and self.native_refresh and self.use_graph and self.prefetch and batch is None and step >= 2
+                and model.iter_density >= 16 and self._refresh_head_step == step and slot.head_step == step
+                and slot.step != step and self._image_ready and every > 1
+                and (self.xchg is None or self.xchg.capturable)
+                and os.environ.get("NGP_FOLD_REFRESH", "1") != "0"):
+            return False
+        probed = [n for n in _lib.probed_symbols() if n in self._main_symbols]
+        if probed and _lib.probe_next_timed():
+            return False
+        nxt = self.slots[(step + 1) % 2]
+        key = ("rstep", step % 2)
+        if key not in self.graphs:
+            if self.graph_pool is None:
+                self.graph_pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
+                main = torch.cuda.current_stream(self.device)
+                self._refresh_launches(0.95, False, 2)
+                self._load_slot(slot, stage=2)
+                self.side.wait_stream(main)             # fork: the next step's rays, marched through the NEW bitfield
+                with torch.cuda.stream(self.side):
+                    self._load_slot(nxt, stage=0)
+                self._run_ops(self._step_ops(slot), fork=bool(getattr(opt, "aux_stream", False)))
+                main.wait_stream(self.side)             # join
+            self._graphs_alive.append(g)
+            self.graphs[key] = [g.replay]
+        for part in self.graphs[key]:
+            part()
+        # (what refresh_density_grid, _load_slot_fast and train_step note down)
+        model.iter_density += 1
+        model.bitfield_version = getattr(model, "bitfield_version", 0) + 1
+        self._occ_version = model.bitfield_version
+        slot.step, nxt.step = step, step + 1
+        if probed:
+            _lib.probe_skip(probed)
+        self.global_step += 1
+        self.last_loss = self.loss
+        self.last_graph_key = key
+        return True
 
     @property
     def last_num_points(self):
