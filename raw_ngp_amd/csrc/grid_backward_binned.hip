@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_kernel(const float *__res
                                                          uint32_t gridtype, bool align_corners, uint32_t interp,
                                                          WsLayout w, uint32_t n_tail, MlpDwReduce tail)
 {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // The first n_tail workgroups are passengers: they reduce the tiny MLPs' weight gradients (two groups of 64 outputs
     // each, mlp_common.hpp) instead of filling records.  That reduction is 10 us of latency-bound loads which nothing
     // waits for until the next step's MLP forward; as a kernel of its own it sat on the step's critical path with the
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w, uint32_t *__restrict__ dir, uint32_t n_tail,
     MlpDwReduce tail, uint32_t snake_levels, const int32_t *__restrict__ sample_index)
 {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (blockIdx.x < n_tail) {   // passengers: the tiny MLPs' weight-gradient reduction (see bin_fill_kernel)
         float(*part)[64] = reinterpret_cast<float(*)[64]>(lds) + 4 * (threadIdx.x >> 8);
         mlp_reduce_dw_group(tail, blockIdx.x * 2u + (threadIdx.x >> 8), threadIdx.x & 255u, part);
@@ -462,23 +462,35 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
             }
         }
     }
+    // PAIRS.  On a hashed level whose table is a power of two the x term of the hash is the cell's x coordinate itself
+    // (kPrimes[0] = 1), below 2^12 for res <= 4096: the two x-neighbours of a corner pair differ in the low 12 bits only, i.e.
+    // they ALWAYS fall into the same 4096-row chunk.  So the eight records of a sample are four pairs: one histogram atomic,
+    // one offset read, one 16-byte payload store and one 4-byte key store per PAIR -- half the LDS instructions of the
+    // record-by-record path, which stays for the dense levels (their x-pairs straddle a chunk boundary now and then).
+    const bool pairs = g.hashed && g.mode == 1u && g.res <= kChunkRows && kPrimes[0] == 1u;
+    const uint32_t unit = pairs ? 2u : 1u;   // records per histogram count
     if (emit) {
         const AxisTerms<3> terms = axis_terms<3>(g, cl);
 #pragma unroll
-        for (uint32_t corner = 0; corner < 8; corner++) {
-            rows[corner] = row_from_terms<3>(g, terms, corner);
-            pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
+        for (uint32_t corner = 0; corner < 8; corner++) rows[corner] = row_from_terms<3>(g, terms, corner);
+        if (pairs) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) pos[q] = atomicAdd(&hist[rows[2 * q] >> kChunkShift], 1u);
+        } else {
+#pragma unroll
+            for (uint32_t corner = 0; corner < 8; corner++) pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
         }
     }
     NGP_FILL_STAMP(3);
     __syncthreads();
     NGP_FILL_STAMP(4);
 
-    // exclusive scan of the histogram (each chunk's count rounded up to a quad) -> staging offsets = offsets inside the
-    // tile's region; the directory words leave right here (plain stores, nothing waits for them) and the up to three
-    // slots of padding behind each run become null records.  Wave 0 scans the level's <= kLocalBins bins, kLocalBins / 64 per lane.
+    // exclusive scan of the histogram (each chunk's count rounded up to a quad of records) -> staging offsets = offsets
+    // inside the tile's region.  Wave 0 scans the level's <= kLocalBins bins, kLocalBins / 64 per lane, and leaves lbase[] (in
+    // histogram units); directory words and the null records that pad a run go out AFTER the barrier, one bin per lane of the
+    // whole workgroup -- the seven other waves used to wait while wave 0 issued up to 128 scattered 4-byte stores.
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    uint32_t *dcol = dir + (size_t)first * ntiles + tile;   // dir[chunk][tile]
+    const uint32_t quad = 4u / unit;          // histogram counts per quad of records
     if (wid == 0) {
         constexpr uint32_t K = kLocalBins / 64u;   // consecutive bins per lane
         uint32_t n[K], q[K], sum = 0;
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
         for (uint32_t j = 0; j < K; j++) {
             const uint32_t i = K * lane + j;
             n[j] = i < nbins ? hist[i] : 0u;
-            q[j] = (n[j] + 3u) & ~3u;
+            q[j] = (n[j] + quad - 1u) & ~(quad - 1u);
             sum += q[j];
         }
         uint32_t inc = sum;
@@ -499,29 +511,45 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
 #pragma unroll
         for (uint32_t j = 0; j < K; j++) {
             const uint32_t i = K * lane + j;
-            if (i < nbins) {
-                lbase[i] = run;
-                dcol[(size_t)i * ntiles] = run | (n[j] << 16);
-                for (uint32_t k = n[j]; k < q[j]; k++) {
-                    stage_key[run + k] = 0;
-                    stage_val[run + k] = make_float2(0.f, 0.f);
-                }
-            }
+            if (i < nbins) lbase[i] = run;
             run += q[j];
         }
-        if (lane == 63u) s_total = inc;
+        if (lane == 63u) s_total = inc * unit;
     }
-    NGP_FILL_STAMP(5);   // scan + directory stores (retired)
+    NGP_FILL_STAMP(5);   // scan
     __syncthreads();
 
+    uint32_t *dcol = dir + (size_t)first * ntiles + tile;   // dir[chunk][tile]
+    if (threadIdx.x < nbins) {   // (nbins <= kLocalBins <= kFillBlock)
+        const uint32_t i = threadIdx.x, n = hist[i], base = lbase[i];
+        dcol[(size_t)i * ntiles] = (base * unit) | ((n * unit) << 16);
+        if (n & (quad - 1u)) {   // pad the run to a quad with null records (key 0, value 0)
+            for (uint32_t k = n * unit; k < ((n + quad - 1u) & ~(quad - 1u)) * unit; k++) {
+                stage_key[base * unit + k] = 0;
+                stage_val[base * unit + k] = make_float2(0.f, 0.f);
+            }
+        }
+    }
     float gmax = nan ? __uint_as_float(0x7f800000u) : 0.0f;   // NaN -> inf
     if (emit) {
 #pragma unroll
-        for (uint32_t corner = 0; corner < 8; corner++) {
-            gmax = fmaxf(gmax, fmaxf(fabsf(vx[corner]), fabsf(vy[corner])));
-            const uint32_t slot = lbase[rows[corner] >> kChunkShift] + pos[corner];
-            stage_key[slot] = (uint16_t)(rows[corner] & (kChunkRows - 1u));
-            stage_val[slot] = make_float2(vx[corner], vy[corner]);
+        for (uint32_t corner = 0; corner < 8; corner++) gmax = fmaxf(gmax, fmaxf(fabsf(vx[corner]), fabsf(vy[corner])));
+        if (pairs) {
+            float4 *pv = reinterpret_cast<float4 *>(stage_val);
+            uint32_t *pk = reinterpret_cast<uint32_t *>(stage_key);
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t slot = lbase[rows[2 * q] >> kChunkShift] + pos[q];
+                pk[slot] = (rows[2 * q] & (kChunkRows - 1u)) | ((rows[2 * q + 1] & (kChunkRows - 1u)) << 16);
+                pv[slot] = make_float4(vx[2 * q], vy[2 * q], vx[2 * q + 1], vy[2 * q + 1]);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t corner = 0; corner < 8; corner++) {
+                const uint32_t slot = lbase[rows[corner] >> kChunkShift] + pos[corner];
+                stage_key[slot] = (uint16_t)(rows[corner] & (kChunkRows - 1u));
+                stage_val[slot] = make_float2(vx[corner], vy[corner]);
+            }
         }
     }
 #pragma unroll
