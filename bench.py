@@ -257,13 +257,16 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         in_sync = bool(torch.equal(lo, hi))
 
-    psnr = None
+    psnr, eval_check = None, None
     if args.psnr_iters > trainer.global_step:
         trainer.train(args.psnr_iters - trainer.global_step)
     psnr_step = trainer.global_step
     if args.psnr_iters > 0:
         val = SyntheticDataset(opt, dev, "val", n_views=4, H=args.res, W=args.res)
-        psnr = trainer.evaluate(val)
+        psnr = trainer.evaluate(val)        # (more than one rank: views dealt to the ranks, images all-gathered)
+        if world > 1 and fused:
+            # ... which must be the value ONE rank computes over all views from its replica of the parameters
+            eval_check = bool(psnr == trainer.evaluate(val, distributed=False))
     scaler_state = trainer.scaler.state() if fused and getattr(trainer, "scaler", None) is not None else None
 
     # ---- probe tail: the roofline kernels under HIP events, untimed --------------------------------------------
@@ -304,7 +307,7 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
 
     return dict(dt=dt, host=host, samples=samples, probe=probe, probe_fwd=probe_fwd, probed=probed, fwd_symbol=fwd_symbol,
                 bytes_per_sample=bytes_per_sample, in_sync=in_sync, psnr=psnr, trainer=trainer, fused=fused,
-                collective_ms=collective_ms, psnr_step=psnr_step, scaler_state=scaler_state,
+                collective_ms=collective_ms, psnr_step=psnr_step, scaler_state=scaler_state, eval_check=eval_check,
                 untrained_cells=untrained_cells, overflow=bool(fused and overflow), model=model)
 
 
@@ -317,8 +320,9 @@ def run_config4(args, dev):
     from raw_ngp_amd.nerf import pose as P
     torch.manual_seed(0)
     iters = 3000
+    # (adaptive_num_rays: `--lightstage` switches it on, main.py:142 -- the batch follows num_points = 2^18 samples per step)
     opt = Options(bound=2.0, num_rays=args.rays, iters=iters, rfield=True, pose_opt="barf", noise=0.03, image_mode="HDR",
-                  background="black")
+                  background="black", adaptive_num_rays=True)
     views, res = 40, 200
     data = SyntheticDataset(opt, dev, "train", n_views=views, H=res, W=res)
     data.ldirs = torch.from_numpy(P.synthetic_light_dirs(views)).to(dev)
@@ -334,16 +338,18 @@ def run_config4(args, dev):
         trainer.train(upto - trainer.global_step - args.warmup)
         trainer.train(args.warmup)
         torch.cuda.synchronize()
-        seen0 = int(trainer.samples_seen)
+        seen0, rays0 = int(trainer.samples_seen), int(trainer.rays_seen)
         t0 = time.perf_counter()
         trainer.train(args.steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        rays = int(trainer.rays_seen) - rays0           # adaptive batches: what the steps really carried
         out[tag] = {"at_step": upto, "ms_per_step": round(dt / args.steps * 1e3, 4),
-                    "value": round(args.rays * args.steps / dt, 1), "unit": "rays/s",
+                    "value": round(rays / dt, 1), "unit": "rays/s", "rays_per_step": round(rays / args.steps),
                     "samples_per_step": round((int(trainer.samples_seen) - seen0) / args.steps)}
     err1 = P.pose_error(co.get_refined_poses(data.poses), data.poses)
-    out.update({"workload": f"configs[3] stand-in: rfield + barf + HDR loss, bound 2, {args.rays} rays/batch, {views} views of "
+    out.update({"workload": f"configs[3] stand-in: rfield + barf + HDR loss, bound 2, adaptive ray batches towards {opt.num_points} "
+                            f"samples/step (first batch {args.rays} rays), {views} views of "
                             f"{res}x{res} (synthetic light directions, exposures, 0.03 se(3) noise), {iters} iterations",
                 "pose_error_deg_dist_start": [round(float(v), 4) for v in err0],
                 "pose_error_deg_dist_end": [round(float(v), 4) for v in err1],
@@ -463,6 +469,7 @@ def main():
                                                            res["in_sync"], res["psnr"])
     trainer, fused, untrained_cells, overflow = res["trainer"], res["fused"], res["untrained_cells"], res["overflow"]
     collective_ms, psnr_step, scaler_state = res["collective_ms"], res["psnr_step"], res["scaler_state"]
+    eval_check = res["eval_check"]
     # what the JSON line needs from the primary run's trainer (it is freed before the secondary runs)
     tinfo = {"fuse_adam": bool(fused and getattr(trainer, "fuse_adam", False)),
              "table_numel": int(trainer.table.numel()) if fused else 0,
@@ -563,6 +570,8 @@ def main():
         }
         if psnr is not None:
             line["psnr"] = {"iters": tinfo["step"], "value": round(float(psnr), 3)}
+            if eval_check is not None:      # distributed evaluation == one rank's evaluation of all views
+                line["psnr"]["distributed_equals_local"] = eval_check
         print(json.dumps(line), flush=True)
     if parallel.is_dist():
         torch.distributed.destroy_process_group()

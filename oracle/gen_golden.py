@@ -546,6 +546,24 @@ def main():
     tg = torch.from_numpy(gt)
     np.savez(os.path.join(args.out, "loss_weights.npz"), gt_rgb=gt, gaussian=RU.gaussian_weighting(tg).numpy(),
              planck=RU.planck_taper_weighting(tg).numpy(), hanning=RU.hanning_weighting(tg).numpy())
+    # ---------------------------------------------------------------- frequency encoder (encoding.py:6-50)
+    # FreqEncoder_torch -- the one encoder the reference also holds in Python -- as get_encoder('frequency_torch') builds it
+    # (max_freq_log2 = multires - 1, N_freqs = multires, log sampling: bands 2^0 .. 2^(multires-1)); its output layout
+    # [x | sin f0 x | cos f0 x | sin f1 x | ...] (blocks of input_dim) is the CUDA kernel's (freqencoder.cu:48-57: column
+    # c -> block c / D - 1 = 2 freq + (0 sin, 1 cos), component c % D): the layout map is the identity
+    import encoding as E
+    frng = np.random.default_rng(23)
+    fq = {}
+    for multires in (4, 6, 10):
+        enc, out_dim = E.get_encoder("frequency_torch", input_dim=3, multires=multires)
+        xin = torch.from_numpy(frng.uniform(-1.0, 1.0, (96, 3)).astype(np.float32)).requires_grad_(True)
+        yout = enc(xin)
+        assert yout.shape[-1] == out_dim == 3 + 3 * 2 * multires
+        gout = torch.from_numpy(frng.normal(size=yout.shape).astype(np.float32))
+        yout.backward(gout)
+        fq.update({f"x{multires}": xin.detach().numpy(), f"y{multires}": yout.detach().numpy(), f"g{multires}": gout.numpy(),
+                   f"gx{multires}": xin.grad.numpy()})
+    np.savez(os.path.join(args.out, "freq_torch.npz"), **fq)
     print("fixtures written to", args.out)
     for f in sorted(os.listdir(args.out)):
         print("  ", f, os.path.getsize(os.path.join(args.out, f)))

@@ -405,6 +405,19 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     }
     const uint32_t b0 = tile * kFillTile;
     if (b0 >= B) return;
+    const uint32_t b = b0 + threadIdx.x;
+    // position and gradient do not depend on each other: both requests leave before anything waits -- before the level's
+    // geometry is read, too (scalar loads the vector requests need not queue behind)
+    // (sample_index: the call runs over a LIST of B samples -- the position of entry b is that of sample sample_index[b],
+    // the gradient slab is in list order; ngp_x_mlp_backward_list wrote it that way)
+    float x[3] = {0.f, 0.f, 0.f};
+    float2 gr = make_float2(0.0f, 0.0f);
+    if (b < B) {
+        const size_t sb = sample_index ? (size_t)(uint32_t)sample_index[b] : (size_t)b;
+        gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * gstride + b];
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) x[d] = inputs[sb * 3 + d];
+    }
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
     // the level's chunks: the table's geometry, no workspace header involved
     uint32_t first = 0;
@@ -412,18 +425,6 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     const uint32_t nbins = (g.T + kChunkRows - 1) >> kChunkShift;
     NGP_FILL_STAMP_DECL;
     NGP_FILL_STAMP(0);
-    const uint32_t b = b0 + threadIdx.x;
-    // position and gradient do not depend on each other: both requests leave before anything waits
-    // (sample_index: the call runs over a LIST of B samples -- the position of entry b is that of sample sample_index[b],
-    // the gradient slab is in list order; ngp_x_mlp_backward_list wrote it that way)
-    float x[3] = {0.f, 0.f, 0.f};
-    float2 gr = make_float2(0.0f, 0.0f);
-    if (b < B) {
-        gr = reinterpret_cast<const float2 *>(grad)[(size_t)level * gstride + b];
-        const size_t sb = sample_index ? (size_t)(uint32_t)sample_index[b] : (size_t)b;
-#pragma unroll
-        for (uint32_t d = 0; d < 3; d++) x[d] = inputs[sb * 3 + d];
-    }
     for (uint32_t i = threadIdx.x; i < nbins; i += kFillBlock) hist[i] = 0;
     __syncthreads();
     NGP_FILL_STAMP(1);   // (diagnostic build: the stamp waits for the loads -> phase 1 = header + loads)

@@ -1191,9 +1191,13 @@ class FusedTrainer:
         return out, False
 
     @torch.no_grad()
-    def evaluate(self, dataset, max_views=None, chunk=1 << 16, fast=True):
+    def evaluate(self, dataset, max_views=None, chunk=1 << 16, fast=True, distributed=True):
         """PSNR over held-out views (train_utils.py:221-233).  fast: render with render_rays; a view whose samples do
-        not fit the arena falls back to the reference-shaped inference loop."""
+        not fit the arena falls back to the reference-shaped inference loop.
+        distributed (more than one rank): the views are dealt to the ranks round-robin, every round ends with an all-gather
+        of the ranks' predictions and targets, and every rank feeds the meter with all of them in view order -- the
+        reference's evaluate_one_epoch (train_utils.py:1033-1048: all_gather of preds / truths, then the metrics) with the
+        result on every rank instead of on rank 0 only.  Same images, same order: the value a single rank computes."""
         from . import utils
         from .trainer import Trainer
         if not fast:        # (the training background does not matter here: evaluation composites over a constant 0)
@@ -1201,7 +1205,9 @@ class FusedTrainer:
         self.model.eval()
         meter = utils.PSNRMeter()
         n = len(dataset) if max_views is None else min(max_views, len(dataset))
-        for v in range(n):
+        R, r = (self.world_size, self.rank) if (distributed and self.world_size > 1) else (1, 0)
+
+        def render(v):
             data = dataset.view(v)
             pred, overflow = self.render_rays(data["rays_o"].contiguous(), data["rays_d"].contiguous(), 0.0,
                                               ldir=data.get("rays_ldir"))
@@ -1212,5 +1218,17 @@ class FusedTrainer:
                 pred = torch.cat(preds, 0)
             img = data["images"]
             gt = img[..., :3] * img[..., 3:] if img.shape[-1] == 4 else img
-            meter.update(pred.view(data["H"], data["W"], 3).clamp(0, 1), gt)
+            return pred.view(data["H"], data["W"], 3).clamp(0, 1), gt.reshape(data["H"], data["W"], 3).float()
+
+        for base in range(0, n, R):
+            mine = min(base + r, n - 1)         # (a rank without a view in the last round renders the last one again: the
+            pred, gt = render(mine)             # collective wants equal shapes; its copy is not counted)
+            if R == 1:
+                meter.update(pred, gt)
+                continue
+            pair = torch.stack([pred, gt]).contiguous()
+            parts = [torch.empty_like(pair) for _ in range(R)]
+            torch.distributed.all_gather(parts, pair)
+            for k in range(min(R, n - base)):
+                meter.update(parts[k][0], parts[k][1])
         return meter.measure()

@@ -36,6 +36,9 @@ def test_two_ranks_stay_in_sync(wire, mode):
         assert res["config"]["collective_ms_per_step"] > 0
     assert res["config"]["replicas_in_sync"] is True
     assert res["value"] > 0 and res["psnr"]["value"] > 5.0
+    # the PSNR came from the DISTRIBUTED evaluation (views dealt to the ranks, images all-gathered: train_utils.py:1033-1048)
+    # and equals what one rank computes over all views
+    assert res["psnr"]["distributed_equals_local"] is True
 
 
 @pytest.mark.parametrize("mode,wire", [("shard", "f32"), ("allreduce", "f32"), ("shard", "bf16")])

@@ -224,3 +224,29 @@ def test_raymarching_wrappers_match_the_reference_wrappers(golden_dir):
     np.testing.assert_allclose(ws_i.cpu().numpy(), g["inf_weights_sum"], rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(dep_i.cpu().numpy(), g["inf_depth"], rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(img_i.cpu().numpy(), g["inf_image"], rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("deg", [4, 6, 10])
+def test_frequency_encoder_matches_the_references_torch_encoder(golden_dir, deg):
+    """The one encoder the reference ALSO holds in Python: FreqEncoder_torch (encoding.py:6-50), run on CPU by
+    oracle/gen_golden.py -> freq_torch.npz.  This repo's FreqEncoder module over ngp_freq_encode_forward / _backward
+    (the drop-in for freqencoder.cu) on the same inputs: the column layout is the CUDA kernel's, which is the torch
+    encoder's [x | sin 2^0 x | cos 2^0 x | sin 2^1 x | ...] -- the layout map is the identity (checked column by column);
+    values to float32 sin of a float32 argument (|argument| up to 2^(deg-1) + pi / 2, cos taken as sin(. + pi / 2) like the
+    reference kernel), input gradients through the module's autograd.Function."""
+    from raw_ngp_amd.freqencoder import FreqEncoder
+    g = np.load(os.path.join(golden_dir, "freq_torch.npz"))
+    x, y, go, gx = g[f"x{deg}"], g[f"y{deg}"], g[f"g{deg}"], g[f"gx{deg}"]
+    enc = FreqEncoder(input_dim=3, degree=deg).cuda()
+    assert enc.output_dim == y.shape[1] == 3 + 6 * deg
+    xin = dev(x).requires_grad_(True)
+    out = enc(xin)
+    got = out.detach().cpu().numpy()
+    tol = 2e-7 * 2.0 ** deg + 1e-6
+    for c in range(y.shape[1]):                                 # column by column: a layout mistake shows as one bad block
+        np.testing.assert_allclose(got[:, c], y[:, c], rtol=0, atol=tol, err_msg=f"column {c}")
+    (gi,) = torch.autograd.grad((out * dev(go)).sum(), [xin])
+    np.testing.assert_allclose(gi.cpu().numpy(), gx, rtol=2e-5, atol=2e-4 * 2.0 ** (deg - 4))
+    # leading dimensions pass through like the reference module's (encoding.py: cat along the last one)
+    out3 = enc(dev(x).reshape(4, 24, 3))
+    assert out3.shape == (4, 24, enc.output_dim) and torch.equal(out3.reshape(-1, enc.output_dim), out.detach())

@@ -1,4 +1,6 @@
 """Pins the oracle's SH (and frequency) encoder against scipy and finite differences."""
+import os
+
 import numpy as np
 import pytest
 from scipy import special
@@ -117,3 +119,19 @@ def test_freq_encoder(orc):
         c = g[:, D + 2 * f * D + D: D + 2 * f * D + 2 * D]
         expect += 2.0 ** f * (s * np.cos(x * 2.0 ** f) - c * np.sin(x * 2.0 ** f))
     np.testing.assert_allclose(gi, expect, rtol=1e-4, atol=1e-5)
+
+
+def test_freq_encoder_is_the_references_torch_encoder(orc, golden_dir):
+    """The reference holds ONE encoder in Python as well: FreqEncoder_torch (encoding.py:6-50).  Its outputs and autograd
+    gradients on seeded inputs (tests/golden/freq_torch.npz, written by oracle/gen_golden.py from the imported reference)
+    pin the oracle's restatement of freqencoder.cu -- same column layout [x | sin 2^0 x | cos 2^0 x | sin 2^1 x | ...], the
+    CUDA kernel's cos as sin(. + pi / 2)."""
+    g = np.load(os.path.join(golden_dir, "freq_torch.npz"))
+    for deg in (4, 6, 10):
+        x, y, go, gx = g[f"x{deg}"], g[f"y{deg}"], g[f"g{deg}"], g[f"gx{deg}"]
+        B, D, C = x.shape[0], 3, 3 + 6 * deg
+        out = orc.freq_encode_forward(x, B, D, deg, C)
+        # |argument| <= 2^(deg - 1) + pi / 2: float32 sin of a float32 argument, the phase shift rounds at the argument's ulp
+        np.testing.assert_allclose(out, y, rtol=0, atol=2e-7 * 2.0 ** deg + 1e-6)
+        gi = orc.freq_encode_backward(go, out, B, D, deg, C)
+        np.testing.assert_allclose(gi, gx, rtol=2e-5, atol=2e-4 * 2.0 ** (deg - 4))
