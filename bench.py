@@ -169,7 +169,7 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
                   aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
                   dp_rehearsal=args.dp_rehearsal, dp_exchange=args.dp_exchange, group_steps=args.group_steps,
-                  dp_mode=args.dp_mode, dynamic_loss_scale=not args.static_loss_scale,
+                  dp_mode=args.dp_mode, dynamic_loss_scale=not args.static_loss_scale, dp_split_level=args.dp_split_level,
                   **({"loss_scale": args.loss_scale} if args.loss_scale else {}))
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
     model = NeRFNetwork(opt)
@@ -433,6 +433,9 @@ def main():
     ap.add_argument("--dp-exchange", default=None, choices=["rccl", "torch"],
                     help="data parallel, carrier of the collectives: rccl = bare RCCL calls captured inside the step graphs "
                          "(default on an nccl process group), torch = torch.distributed, eager between graph segments")
+    ap.add_argument("--dp-split-level", type=int, default=None,
+                    help="data parallel (shard, f32 wire): exchange in two level groups split at this level (default: 8 with more "
+                         "than one rank, off on one; 0 = one group)")
     ap.add_argument("--dp-rehearsal", action="store_true",
                     help="one GPU: run the data-parallel step (separate Adam, RCCL collectives on a one-rank group)")
     ap.add_argument("--no-prefetch", action="store_true", help="fused step: march on the main stream (no overlap)")
@@ -476,7 +479,8 @@ def main():
              "graph": bool(fused and trainer.use_graph), "prefetch": bool(fused and trainer.prefetch),
              "device_sampler": bool(fused and trainer.device_sampler), "cap": trainer.cap if fused else 0,
              "step": psnr_step,
-             "dp_exchange": trainer.xchg.carrier if fused and getattr(trainer, "xchg", None) is not None else None}
+             "dp_exchange": trainer.xchg.carrier if fused and getattr(trainer, "xchg", None) is not None else None,
+             "dp_split_level": trainer.split["level"] if fused and getattr(trainer, "split", None) is not None else None}
     if fused:
         trainer.close()
     del res, trainer
@@ -504,7 +508,9 @@ def main():
     if rank == 0:
         launches, units, ksec = probe
         roof = None
-        if launches:
+        # (exchange in two level groups: the probed entry point is then the fill alone -- the reduce runs as one launch per
+        # group, each feeding its own collective -- so no table-backward roofline is formed from it)
+        if launches and tinfo["dp_split_level"] is None:
             # one GPU: the same launch also runs Adam on the table (inside the reduce kernel): its algorithmic bytes are
             # the read + write of parameter, exp_avg and exp_avg_sq -- 24 B per table entry, the gradient never
             # reaches HBM (SURVEY 8d prices a separate optimiser pass at 28 B)
@@ -554,7 +560,7 @@ def main():
                        "views": args.views, "resolution": args.res, "burnin_steps": args.burnin,
                        "parallelism": f"dp{world}", "grad_wire": args.grad_wire if (world > 1 or args.dp_rehearsal) else None,
                        "dp_mode": args.dp_mode if (world > 1 or args.dp_rehearsal) else None,
-                       "dp_exchange": tinfo["dp_exchange"], "ranks_seen": ranks_seen,
+                       "dp_exchange": tinfo["dp_exchange"], "dp_split_level": tinfo["dp_split_level"], "ranks_seen": ranks_seen,
                        "collective_ms_per_step": None if collective_ms is None else round(collective_ms, 4),
                        "multi_gpu_measured": "RCCL over >1 rank has not been measured by the builder (no multi-GPU box in reach): "
                                              "this line is the first measurement" if world > 1 else None,

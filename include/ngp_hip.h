@@ -287,6 +287,15 @@ int ngp_x_grid_backward_binned_apply_mlp_list(
     float *mlp_adam_param, const float *mlp_adam_grad, float *mlp_adam_exp_avg, float *mlp_adam_exp_avg_sq,
     uint32_t mlp_adam_n, const float *mlp_adam_hyper, float mlp_beta1, float mlp_beta2, float mlp_eps, void *mlp_adam_image,
     float *loss_scaler, ngp_stream_t stream);
+/* grad_embeddings == NULL without adam_param: FILL ONLY (records + directory, and the _mlp variants' passengers); the caller
+ * reduces afterwards, in chunk ranges of its own: */
+int ngp_x_grid_backward_binned_reduce_range(const int32_t *offsets, float *grad_embeddings, const int32_t *B_dev, uint32_t B,
+                                            uint32_t L, float S, uint32_t H, uint32_t n_rows_total, uint32_t max_level_rows,
+                                            void *workspace, size_t workspace_bytes, int overwrite, uint32_t chunk_lo,
+                                            uint32_t chunk_hi, float *loss_scaler, ngp_stream_t stream);
+/* ... the reduce half over the chunks [chunk_lo, chunk_hi) (level-major numbering: ceil(rows of level / chunk rows) chunks
+ * per level, ngp_x_grid_backward_binned_geometry) of a workspace a fill-only call has filled -- tile-local layout only.  The
+ * data-parallel step reduces the levels in two ranges so that the exchange of the first overlaps the second's reduction. */
 /* overwrite != 0 (workspace prepared with single_segment, max_level == L): grad_embeddings = sums for EVERY row of every
  * level (zeros where nothing landed) instead of +=, so the caller neither zeroes the gradient nor pays its read.
  * overwrite == 2: the same, stored as bfloat16 (round to nearest even) -- grad_embeddings then points to
@@ -444,6 +453,14 @@ int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound, const flo
                                        uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
                                        int align_corners, uint32_t interp, void *binned_workspace, uint32_t n_rows_total,
                                        float *dydx, ngp_stream_t stream);
+/* levels level_lo .. level_hi - 1 only (the other levels' slab rows stay untouched; inputs01 is written with level 0; dydx
+ * optional): the data-parallel step encodes the levels whose parameters have arrived while the all-gather of the others is
+ * still on the wire.  Same arithmetic per level, so two calls that cover [0, L) equal one call of the whole. */
+int ngp_x_grid_encode_forward_slab_levels(const float *xyzs, float bound, const float *embeddings, const int32_t *offsets,
+                                          float *out, float *inputs01, const int32_t *B_dev, uint32_t B_cap, uint32_t stride,
+                                          uint32_t L, uint32_t level_lo, uint32_t level_hi, float S, uint32_t H,
+                                          uint32_t gridtype, int align_corners, uint32_t interp, float *dydx,
+                                          ngp_stream_t stream);
 /* the same with the caller's level -> XCD placement: level_cost (HOST pointer, max_level floats > 0, or NULL) is the
  * relative cost of one 256-point tile of each level for the caller's points (ray-ordered samples: growing with the
  * level; scattered points: flat over the hashed levels).  The levels are dealt to the 8 XCDs in runs of equal cost

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "ngp_x_mlp_rf_backward_list": [_p, _u, _p, _p, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                    ctypes.c_size_t, _p],
     "ngp_x_grid_encode_forward_slab": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u],
+    "ngp_x_grid_encode_forward_slab_levels": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p],
+    "ngp_x_grid_backward_binned_reduce_range": [_p, _p, _p, _u, _u, _f, _u, _u, _u, _p, ctypes.c_size_t, _i, _u, _u, _p],
     "ngp_x_grid_encode_forward_slab_jac": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p],
     "ngp_x_grid_encode_forward_slab_placed": [_p, _f, _p, _p, _p, _p, _p, _u, _u, _u, _u, _f, _u, _u, _i, _u, _p, _u, _p, _p],
     "ngp_x_composite_hdr_train": [_p, _p, _f, _p, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p],
@@ -408,7 +410,7 @@ class _GridBackend:
     @staticmethod
     def grid_backward_binned_apply(grad, inputs, offsets, grad_embeddings, B_dev, B_cap, grad_stride, L, max_level, S, H,
                                    workspace, gridtype=0, align_corners=False, interp=0, adam=None, overwrite=False,
-                                   mlp_tail=None, sample_index=None, scaler=None):
+                                   mlp_tail=None, sample_index=None, scaler=None, n_rows=None):
         """Fill + reduce on a workspace prepared for the same positions.  adam = (param, exp_avg, exp_avg_sq, hyper,
         beta1, beta2, eps): apply the optimiser inside the reduce kernel instead of writing grad_embeddings.
         overwrite: grad_embeddings = sums for every row (no +=); a bfloat16 grad_embeddings selects the 16-bit store.
@@ -419,7 +421,11 @@ class _GridBackend:
         scaler: the eight device words of the dynamic loss scale (LossScaler.words); the reduce launch then settles the
         step -- overflow word, table untouched on overflow, the MLP weights' Adam step as ITS passengers."""
         sc = _scaler_ptr(scaler)
-        n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
+        # (grad_embeddings None without adam: FILL ONLY -- grid_backward_binned_reduce_range follows; n_rows = the table's rows)
+        if adam is not None or grad_embeddings is not None:
+            n_rows = (adam[0] if adam is not None else grad_embeddings).shape[0]
+        elif n_rows is None:
+            raise RuntimeError("grid_backward_binned_apply: a fill-only call needs n_rows")
         wire16 = grad_embeddings is not None and grad_embeddings.dtype == torch.bfloat16
         if wire16 and not overwrite:
             raise RuntimeError("a bfloat16 grad_embeddings needs overwrite=True")
@@ -429,7 +435,7 @@ class _GridBackend:
             extra = [_ptr(p_, "f", "adam_param"), _ptr(m_, "f", "adam_exp_avg"), _ptr(v_, "f", "adam_exp_avg_sq"),
                      _ptr(hyper, "f", "adam_hyper"), float(b1), float(b2), float(eps)]
         args = [_ptr(grad, "f", "grad"), _ptr(inputs, "f", "inputs"), _ptr(offsets, "i", "offsets"),
-                _ptr(grad_embeddings, "h" if wire16 else "f", "grad_embeddings", adam is not None),
+                _ptr(grad_embeddings, "h" if wire16 else "f", "grad_embeddings", True),
                 _ptr(B_dev, "i", "B_dev", True), B_cap, grad_stride, L, max_level, float(S), H, gridtype,
                 int(bool(align_corners)), interp, n_rows, _GridBackend._max_level_rows(offsets),
                 workspace.data_ptr(), workspace.numel(), *extra, 2 if wire16 else int(bool(overwrite))]
@@ -455,6 +461,27 @@ class _GridBackend:
                   *tail, probe_as="ngp_x_grid_backward_binned_apply_mlp", probe_shift=1)
         else:
             _call("ngp_x_grid_backward_binned_apply_mlp", grad, *args, *tail)
+
+    @staticmethod
+    def grid_backward_binned_reduce_range(offsets, grad_embeddings, B_dev, B_cap, L, S, H, workspace, chunk_lo, chunk_hi,
+                                          scaler=None):
+        """The reduce half over the chunks [chunk_lo, chunk_hi) of a workspace that grid_backward_binned_apply(...,
+        grad_embeddings=None, adam=None) -- fill only -- has filled: grad_embeddings[rows of those chunks] = sums
+        (bfloat16 grad_embeddings: the 16-bit store).  level_chunks() turns a level range into a chunk range."""
+        wire16 = grad_embeddings.dtype == torch.bfloat16
+        _call("ngp_x_grid_backward_binned_reduce_range", grad_embeddings, _ptr(offsets, "i", "offsets"),
+              _ptr(grad_embeddings, "h" if wire16 else "f", "grad_embeddings"), _ptr(B_dev, "i", "B_dev", True), B_cap, L, float(S),
+              H, grad_embeddings.shape[0], _GridBackend._max_level_rows(offsets), workspace.data_ptr(), workspace.numel(),
+              2 if wire16 else 1, int(chunk_lo), int(chunk_hi), _scaler_ptr(scaler))
+
+    @staticmethod
+    def level_chunks(offsets, level_lo, level_hi):
+        """(first chunk, one past the last chunk) of the levels [level_lo, level_hi): chunks are numbered level-major,
+        ceil(rows of the level / chunk rows) per level."""
+        rows = _GridBackend.binned_geometry()[0]
+        o = offsets.detach().cpu().tolist() if torch.is_tensor(offsets) else list(offsets)
+        per = [-(-(o[l + 1] - o[l]) // rows) for l in range(len(o) - 1)]
+        return sum(per[:level_lo]), sum(per[:level_hi])
 
     @staticmethod
     def backward_workspace_bytes(B, L, rows):
@@ -794,6 +821,18 @@ class _EngineBackend:
             if dydx.numel() < L * stride * 6:
                 raise RuntimeError("grid_encode_forward_slab: dydx must hold L * stride * 3 * 2 floats")
             _call("ngp_x_grid_encode_forward_slab_jac", xyzs, *args, _ptr(dydx, "f", "dydx"))
+
+    @staticmethod
+    def grid_encode_forward_slab_levels(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L, level_lo,
+                                        level_hi, S, H, gridtype=0, align_corners=False, interp=0, dydx=None):
+        """grid_encode_forward_slab for the levels [level_lo, level_hi) only; the other levels' slab rows stay as they are
+        (inputs01 is written by the call that covers level 0)."""
+        if dydx is not None and dydx.numel() < L * stride * 6:
+            raise RuntimeError("grid_encode_forward_slab_levels: dydx must hold L * stride * 3 * 2 floats")
+        _call("ngp_x_grid_encode_forward_slab_levels", xyzs, _ptr(xyzs, "f", "xyzs"), float(bound),
+              _ptr(embeddings, "f", "embeddings"), _ptr(offsets, "i", "offsets"), _ptr(out, "f", "out"),
+              _ptr(inputs01, "f", "inputs01", True), _ptr(B_dev, "i", "B_dev", True), B_cap, stride, L, int(level_lo),
+              int(level_hi), float(S), H, gridtype, int(bool(align_corners)), interp, _ptr(dydx, "f", "dydx", True))
 
     @staticmethod
     def composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh, weights, weights_sum, depth, image):

@@ -29,8 +29,10 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     const float *__restrict__ xyzs, float bound, const float *__restrict__ table, const int32_t *__restrict__ offsets,
     float *__restrict__ out, float *__restrict__ inputs01, const int32_t *__restrict__ B_dev, uint32_t B_cap,
     uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w,
-    float *__restrict__ dydx = nullptr, uint32_t snake_levels = 0, uint32_t placed_levels = 0, LevelPlacement place = {})
+    float *__restrict__ dydx = nullptr, uint32_t snake_levels = 0, uint32_t placed_levels = 0, LevelPlacement place = {},
+    uint32_t level_lo = 0)
 {
+    // level_lo: the launch covers levels level_lo .. level_lo + (levels of the grid) - 1 (ngp_x_grid_encode_forward_slab_levels)
     extern __shared__ uint32_t hist[];
     uint32_t level, tile_;
     if (placed_levels) {
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
         level = item / nchunks;
         tile_ = item - level * nchunks;
     }
+    level += level_lo;
     const uint32_t b0 = tile_ * kBlock, b = b0 + threadIdx.x;
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
     if (b0 >= B) return;   // whole workgroup
@@ -749,6 +752,38 @@ extern "C" int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, co
     return ngp_x_grid_encode_forward_slab_jac(xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, L,
                                               max_level, S, H, gridtype, align_corners, interp, binned_workspace,
                                               n_rows_total, nullptr, stream);
+}
+
+// Levels level_lo .. level_hi - 1 only (the others' slab rows stay as they are): the data-parallel step encodes the levels
+// whose parameters have arrived while the all-gather of the others is still on the wire.  x01 is written with level 0.
+extern "C" int ngp_x_grid_encode_forward_slab_levels(const float *xyzs, float bound, const float *embeddings,
+                                                     const int32_t *offsets, float *out, float *inputs01,
+                                                     const int32_t *B_dev, uint32_t B_cap, uint32_t stride, uint32_t L,
+                                                     uint32_t level_lo, uint32_t level_hi, float S, uint32_t H,
+                                                     uint32_t gridtype, int align_corners, uint32_t interp, float *dydx,
+                                                     ngp_stream_t stream)
+{
+    if (B_cap == 0 || level_hi <= level_lo) return NGP_OK;
+    NGP_REQUIRE(xyzs && embeddings && offsets && out, "grid_encode_forward_slab_levels: null tensor");
+    NGP_REQUIRE(stride >= B_cap, "grid_encode_forward_slab_levels: stride smaller than B_cap");
+    NGP_REQUIRE(bound > 0.0f, "grid_encode_forward_slab_levels: bound must be positive");
+    LevelRes lv;
+    NGP_REQUIRE(fill_levels(lv, S, H, L), "grid_encode_forward_slab_levels: L must be in [1, %u]", kMaxLevels);
+    NGP_REQUIRE(level_hi <= L, "grid_encode_forward_slab_levels: level_hi > L");
+    const uint32_t nchunks = ceil_div(B_cap, kBlock), n = level_hi - level_lo;
+    static const bool snake_on = !(getenv("NGP_SNAKE") && getenv("NGP_SNAKE")[0] == '0');
+    const uint32_t snake_levels = (snake_on && n >= 8) ? n : 0u;
+    const dim3 grid(snake_levels ? snake_blocks(n, nchunks) : nchunks * n);
+    if (dydx)
+        grid_forward_slab_kernel<false, true><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
+            xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype, align_corners != 0,
+            interp, WsLayout{}, dydx, snake_levels, 0u, LevelPlacement{}, level_lo);
+    else
+        grid_forward_slab_kernel<false><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
+            xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype, align_corners != 0,
+            interp, WsLayout{}, nullptr, snake_levels, 0u, LevelPlacement{}, level_lo);
+    NGP_CHECK_LAUNCH("grid_encode_forward_slab_levels");
+    return NGP_OK;
 }
 
 extern "C" int ngp_x_grid_encode_forward_slab_jac(const float *xyzs, float bound, const float *embeddings,

@@ -606,6 +606,7 @@ struct LocalRecords {
     const uint32_t *dir = nullptr;    // [n_chunks][ntiles]: first slot | count << 16
     const int32_t *B_dev = nullptr;
     uint32_t B_cap = 0, ntiles = 0;
+    uint32_t chunk_lo = 0, chunk_hi = 0xffffffffu;   // the launch's chunks (level-major numbering); default: all
 };
 // Dynamic loss scale (mlp_common.hpp: LossScalerWord).  The reduce launch is the first one that knows whether the step saw a
 // non-finite gradient anywhere: the weight-gradient reduction (passengers of the fill launch in front of it) has raised
@@ -662,9 +663,9 @@ __global__ __launch_bounds__(kReduceBlock) __attribute__((amdgpu_waves_per_eu(kR
     for (uint32_t i = threadIdx.x; i < kChunkRows * 2; i += kReduceBlock) acc[i] = 0ull;
     __syncthreads();
     const uint32_t n_chunks = s_base[L];
-    const uint32_t item = blockIdx.x - st.n_pass;
+    const uint32_t item = blockIdx.x - st.n_pass + loc.chunk_lo;
     if (ALL) {   // one segment per chunk: the work item IS the chunk
-        if (item >= n_chunks) return;
+        if (item >= min(n_chunks, loc.chunk_hi)) return;
     } else {
         if (item >= w.seg_base[n_chunks]) return;
     }
@@ -1083,7 +1084,10 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
     const bool fused = adam_param != nullptr;
     NGP_REQUIRE(!(fused && overwrite), "grid_backward_binned_apply: overwrite and fused Adam exclude each other");
     NGP_REQUIRE(!overwrite || max_level == L, "grid_backward_binned_apply: overwrite needs max_level == L");
-    NGP_REQUIRE(grad && inputs && (grad_embeddings || fused), "grid_backward_binned_apply: null tensor");
+    NGP_REQUIRE(grad && inputs, "grid_backward_binned_apply: null tensor");
+    // grad_embeddings NULL without the fused Adam: FILL ONLY (+ the passengers) -- the caller reduces the chunks in ranges of
+    // its own afterwards (ngp_x_grid_backward_binned_reduce_range; tile-local layout)
+    const bool fill_only = !grad_embeddings && !fused;
     NGP_REQUIRE(!fused || (adam_exp_avg && adam_exp_avg_sq && adam_hyper && max_level == L),
                 "grid_backward_binned_apply: fused Adam needs exp_avg, exp_avg_sq, hyper and max_level == L");
     NGP_REQUIRE(grad_stride >= B, "grid_backward_binned_apply: grad_stride smaller than B");
@@ -1130,6 +1134,10 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
         // (levels >= max_level have no records: their directory columns are not read -- the reduce walks L levels only when
         // every level was filled, otherwise max_level of them)
         const uint32_t Lr = max_level;
+        if (fill_only) {
+            NGP_CHECK_LAUNCH("grid_backward_binned_apply");
+            return NGP_OK;
+        }
         if (fused)
             bin_reduce_kernel<1, true><<<c.n_chunks_max + np, kReduceBlock, 0, st>>>(offsets, grad_embeddings, Lr, wl, opt, loc, stl);
         else if (overwrite == 2)
@@ -1142,6 +1150,7 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
         return NGP_OK;
     }
     NGP_REQUIRE(!sample_index, "grid_backward_binned_apply: a sample list needs the tile-local layout (see ..._binned_counts)");
+    NGP_REQUIRE(!fill_only, "grid_backward_binned_apply: fill-only needs the tile-local layout (see ..._binned_counts)");
     bin_fill_kernel<<<ft * max_level + n_tail, kFillBlock, c.fill_lds, st>>>(grad, inputs, offsets, B_dev, B, grad_stride, ft,
                                                                             c.nbins_cap, c.lv, gridtype, align_corners != 0,
                                                                             interp, c.w, n_tail, tail ? *tail : MlpDwReduce{});
@@ -1234,6 +1243,48 @@ extern "C" int ngp_x_grid_backward_binned_apply_mlp_list(
                         grad_stride, L, max_level, S, H, gridtype, align_corners, interp, n_rows_total, max_level_rows, workspace,
                         workspace_bytes, adam_param, adam_exp_avg, adam_exp_avg_sq, adam_hyper, beta1, beta2, eps, overwrite,
                         stream, loss_scaler);
+}
+
+// The reduce half on its own, over the chunks [chunk_lo, chunk_hi) of a workspace a fill-only apply call has filled (same B,
+// B_dev, L, geometry): grad_embeddings[rows of those chunks] = sums (overwrite 1; 2: bfloat16; 0: +=).  Chunks are numbered
+// level-major, ceil(rows of the level / chunk rows) per level (ngp_x_grid_backward_binned_geometry).  The data-parallel step
+// reduces the table's levels in two ranges and lets the gradient exchange of the first overlap the reduction of the second.
+extern "C" int ngp_x_grid_backward_binned_reduce_range(const int32_t *offsets, float *grad_embeddings, const int32_t *B_dev,
+                                                       uint32_t B, uint32_t L, float S, uint32_t H, uint32_t n_rows_total,
+                                                       uint32_t max_level_rows, void *workspace, size_t workspace_bytes,
+                                                       int overwrite, uint32_t chunk_lo, uint32_t chunk_hi,
+                                                       float *loss_scaler, ngp_stream_t stream)
+{
+    if (B == 0 || chunk_hi <= chunk_lo) return NGP_OK;
+    NGP_REQUIRE(offsets && grad_embeddings && workspace, "grid_backward_binned_reduce_range: null tensor");
+    BinnedCall c;
+    const int rc = binned_setup(c, "grid_backward_binned_reduce_range", offsets, B, L, L, S, H, n_rows_total, max_level_rows,
+                                workspace, workspace_bytes);
+    if (rc != NGP_OK) return rc;
+    NGP_REQUIRE(binned_local(B, c.nbins_cap), "grid_backward_binned_reduce_range: tile-local layout only (see ..._binned_counts)");
+    NGP_REQUIRE(chunk_hi <= c.n_chunks_max, "grid_backward_binned_reduce_range: chunk range beyond the table");
+    const size_t rec_cap = ws_rec_cap_local(B, L);
+    const WsLayout wl = ws_layout(workspace, c.n_chunks_max, rec_cap);
+    LocalRecords loc;
+    loc.dir = ws_dir(wl, rec_cap);
+    loc.B_dev = B_dev;
+    loc.B_cap = B;
+    loc.ntiles = ceil_div(B, kFillTile);
+    loc.chunk_lo = chunk_lo;
+    loc.chunk_hi = chunk_hi;
+    ScalerTail stl;
+    stl.scaler = loss_scaler;   // (every range's first workgroup raises the overflow word on a non-finite batch maximum)
+    const AdamArgs opt{};
+    hipStream_t st = as_stream(stream);
+    const uint32_t n = chunk_hi - chunk_lo;
+    if (overwrite == 2)
+        bin_reduce_kernel<3, true><<<n, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, wl, opt, loc, stl);
+    else if (overwrite)
+        bin_reduce_kernel<2, true><<<n, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, wl, opt, loc, stl);
+    else
+        bin_reduce_kernel<0, true><<<n, kReduceBlock, 0, st>>>(offsets, grad_embeddings, L, wl, opt, loc, stl);
+    NGP_CHECK_LAUNCH("grid_backward_binned_reduce_range");
+    return NGP_OK;
 }
 
 extern "C" int ngp_x_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets,

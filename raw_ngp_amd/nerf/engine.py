@@ -126,7 +126,7 @@ class FusedTrainer:
         # 16-bit wire format of the table gradient: the reduce kernel stores bfloat16, RCCL averages it in place, Adam
         # reads it -- no conversion passes, half the bytes on xGMI (the MLP gradients then travel on their own, in f32)
         self.wire16 = self.dp_mode is not None and getattr(opt, "grad_wire", "f32") == "bf16" and plain
-        self.xchg, self.flat, self.gflat = None, None, None
+        self.xchg, self.flat, self.gflat, self.split, self.comm = None, None, None, None, None
         self.collective_events = None           # bench.py: [(start, stop)] HIP events around the collectives of timed steps
         self.collective_steps = 0               # ... and how many steps they cover
         if self.dp_mode is not None:
@@ -145,6 +145,28 @@ class FusedTrainer:
                 self.xchg = parallel.Exchange(dev, carrier=want)
             # f32 wire: table and MLP weights share ONE flat parameter (and one flat gradient): one collective each way
             n_flat = parallel.padded_numel(n_t + (0 if self.wire16 else n_w))
+            # The exchange in TWO LEVEL GROUPS ("shard", f32 wire, tile-local records): levels [0, a) and [a, L) + MLP weights.
+            # The table's levels are independent, so the reduce-scatter of group A can run on a second stream while the table
+            # backward still reduces group B, and the all-gather of group B while the next step's encoder already works on
+            # group A's levels -- communication the one-group exchange leaves exposed between two steps.  Each
+            # group is sharded over the ranks on its own; group A's tail that does not fill a multiple of 4 R floats (level
+            # boundaries are multiples of 16 floats: 16 floats at R = 8, nothing at R <= 4) is the SEAM: all-reduced, and
+            # stepped by every rank with replicated moments.
+            self.split = None
+            # (default: with more than one rank; on one rank -- rehearsal, --no-fuse-adam -- there is no communication to hide and
+            # the two-launch forms of encoder, reduce and Adam cost ~ 25 us: 0.352 against 0.325 ms/step)
+            a = getattr(opt, "dp_split_level", None)
+            a = int(a) if a is not None else (8 if self.world_size > 1 else 0)
+            if self.dp_mode == "shard" and not self.wire16 and 0 < a < self.L and dev.type == "cuda" \
+                    and os.environ.get("NGP_DP_SPLIT", "1") != "0" \
+                    and not gb.backward_needs_counts(cap, self.L, enc.offsets):
+                offs = enc.offsets.detach().cpu().tolist()
+                q = 4 * self.xchg.R
+                bA = 2 * int(offs[a])                       # floats of the levels in front of the split
+                sA = bA // q * q                            # ... of them sharded; [sA, bA) is the seam
+                n_flat = bA + parallel.padded_numel(n_t + n_w - bA)
+                self.split = dict(level=a, bA=bA, sA=sA, chunks_a=gb.level_chunks(enc.offsets, 0, a),
+                                  chunks_b=gb.level_chunks(enc.offsets, a, self.L))
             self.flat = torch.zeros(n_flat, **f32)
             self.flat[:n_t].copy_(self.table.reshape(-1))
             self.table = self.flat[:n_t].view(self.rows, 2)
@@ -171,6 +193,17 @@ class FusedTrainer:
             self.t_m, self.t_v = torch.zeros_like(self.table), torch.zeros_like(self.table)
             self.w_m, self.w_v = torch.zeros_like(self.w_flat), torch.zeros_like(self.w_flat)
             self.table_grad = torch.zeros_like(self.table)
+        elif self.split is not None:
+            # moments of what this rank updates: [its shard of group A | the seam (replicated) | its shard of group B]
+            sp, R = self.split, self.xchg.R
+            nA, nS, nB = sp["sA"] // R, sp["bA"] - sp["sA"], (self.flat.numel() - sp["bA"]) // R
+            self.t_m, self.t_v = torch.zeros(nA + nS + nB, **f32), torch.zeros(nA + nS + nB, **f32)
+            sp.update(nA=nA, nS=nS, nB=nB)
+            self.w_m = self.w_v = None
+            self.table_grad = self.gflat[:n_t].view(self.rows, 2)
+            # the collectives of the two groups live on a stream of their own when they can be captured with the step
+            self.comm = torch.cuda.Stream(device=dev) if self.xchg.capturable else None
+            self._ev = {k: torch.cuda.Event() for k in ("rsA", "rsB", "agA", "agB")}
         else:
             own = self.xchg.shard_of(self.flat) if self.dp_mode == "shard" else self.flat
             self.t_m, self.t_v = torch.zeros_like(own), torch.zeros_like(own)      # moments of what this rank updates
@@ -401,7 +434,7 @@ class FusedTrainer:
             op()
 
     def _field_ops(self, slot, gt_rgba, bg_rgb, bg_const, zero_loss=True, fused_adam=False, split_weights=False,
-                   overwrite=False, fuse_composite=False, mlp_tail=None):
+                   overwrite=False, fuse_composite=False, mlp_tail=None, split=None):
         """The field part of the step as (C entry point, thunk) pairs, in launch order.  split_weights: the step path --
         the f16 weight image was prepared at the end of the previous step and the weight-gradient reduction is left to
         the caller (it goes to the aux stream together with the MLP's Adam step)."""
@@ -497,6 +530,31 @@ class FusedTrainer:
                 self.L, self.L, self.S, self.H, slot.ws_grid, adam=adam, overwrite=overwrite, mlp_tail=mlp_tail,
                 sample_index=back_idx, scaler=self.scaler)),
         ]
+        if split is not None:
+            # the exchange in two level groups: the encoder runs group by group (each group's parameters arrive with their own
+            # all-gather) and the table backward is a fill followed by one reduce per group (each feeds its own reduce-scatter)
+            a, ca, cb = split["level"], split["chunks_a"], split["chunks_b"]
+            jac = self.dydx if self.pose or self.orient else None
+
+            def fwd(lo, hi):
+                return lambda: eb.grid_encode_forward_slab_levels(ar.xyzs, m.bound, self.table, offsets, self.enc, self.x01, cnt,
+                                                                  cap, cap, self.L, lo, hi, self.S, self.H, dydx=jac)
+
+            def red(c):
+                return lambda: gb.grid_backward_binned_reduce_range(offsets, self.table_grad, back_n, cap, self.L, self.S, self.H,
+                                                                    slot.ws_grid, c[0], c[1], scaler=self.scaler)
+            out = []
+            for o in ops:
+                if o[0] == "ngp_x_grid_encode_forward_slab":     # (group b first, on both ends of the step: see _split_step_ops)
+                    out += [("fwd_b", fwd(a, self.L)), ("fwd_a", fwd(0, a))]
+                elif o[0].startswith("ngp_x_grid_backward_binned_apply"):
+                    out += [(o[0], lambda: gb.grid_backward_binned_apply(
+                                self.denc, self.x01, offsets, None, back_n, cap, cap, self.L, self.L, self.S, self.H, slot.ws_grid,
+                                mlp_tail=mlp_tail, sample_index=back_idx, scaler=self.scaler, n_rows=self.rows)),
+                            ("reduce_b", red(cb)), ("reduce_a", red(ca))]
+                else:
+                    out.append(o)
+            ops = out
         if split_weights:
             ops = [o for o in ops if o[0] != "ngp_x_mlp_prepare"]
         assert fuse_composite or not (self.hdr or self.orient), "the HDR loss / the orientation term live in the fused compositor step"
@@ -653,6 +711,71 @@ class FusedTrainer:
         else:
             eb.adam_step_dev(own_p, own_g, self.t_m, self.t_v, self.hyper, *self.betas, self.eps, skip=self._skip())
 
+    # ---- ... in two level groups (self.split): collectives on the comm stream, events between the two streams ------------
+    def _group(self, which):
+        """(parameter span, gradient span, seam parameter, seam gradient, moment offsets) of level group "a" / "b"."""
+        sp = self.split
+        if which == "a":
+            return self.flat[:sp["sA"]], self.gflat[:sp["sA"]], self.flat[sp["sA"]:sp["bA"]], self.gflat[sp["sA"]:sp["bA"]], 0
+        return self.flat[sp["bA"]:], self.gflat[sp["bA"]:], None, None, sp["nA"] + sp["nS"]
+
+    def _on_comm(self, fn, done, inline=False):
+        """fn() behind everything the main stream has queued so far -- on the comm stream when there is one (capturable
+        carrier: the main stream carries on), in line otherwise -- then `done` marks its end."""
+        main = torch.cuda.current_stream(self.device)
+        if self.comm is None or inline:         # (same stream: the order is the dependency)
+            self._timed(fn)
+            return
+        self.comm.wait_stream(main)
+        with torch.cuda.stream(self.comm):
+            self._timed(fn)
+            self._ev[done].record(self.comm)
+
+    def _split_reduce_scatter(self, which, inline=False, first=None):
+        """Average group `which`'s gradient over the ranks (shards by reduce-scatter, the seam by all-reduce); group b's goes
+        first and carries the loss scaler's overflow word (MAX) along."""
+        x = self.xchg
+        _, g, _, gs, _ = self._group(which)
+        if which == "b" and self.collective_events is not None and not torch.cuda.is_current_stream_capturing():
+            self.collective_steps += 1
+
+        def run():
+            if first is not None:       # group b's table reduction: on the comm stream too, BESIDE group a's on the main one
+                first()                 # (one after the other the two launches take 73 us, side by side what one launch takes)
+            if x.carrier == "none":
+                return
+            if which == "b" and self.scaler is not None:     # (the step's first collective: the word is final after the fill)
+                x.all_reduce_max(self.scaler.found)
+            x.reduce_scatter_avg(g)
+            if gs is not None and gs.numel():
+                x.all_reduce_avg(gs)
+        self._on_comm(run, "rs" + which.upper(), inline)
+
+    def _split_adam(self, which, inline=False):
+        """Adam on this rank's shard of group `which` (+ the seam, on every rank alike), once its gradient has arrived."""
+        x, sp = self.xchg, self.split
+        p, g, ps, gs, at = self._group(which)
+        if self.comm is not None and not inline:
+            torch.cuda.current_stream(self.device).wait_event(self._ev["rs" + which.upper()])
+        lo, hi = x.shard_bounds(p)
+        n = hi - lo
+        own = (p[lo:hi], x.shard_of(g), self.t_m[at:at + n], self.t_v[at:at + n], False)
+        if ps is not None and ps.numel():
+            k = ps.numel()
+            eb.adam_step_dev2(own, (ps, gs, self.t_m[at + n:at + n + k], self.t_v[at + n:at + n + k], False), self.hyper,
+                              *self.betas, self.eps, skip=self._skip())
+        else:
+            eb.adam_step_dev(*own[:4], self.hyper, *self.betas, self.eps, skip=self._skip())
+
+    def _split_all_gather(self, which, inline=False):
+        """Publish group `which`'s updated shards (behind its Adam step)."""
+        p = self._group(which)[0]
+        self._on_comm(lambda: self.xchg.all_gather(p) if self.xchg.carrier != "none" else None, "ag" + which.upper(), inline)
+
+    def _wait_gather(self, which, inline=False):
+        if self.comm is not None and not inline:
+            torch.cuda.current_stream(self.device).wait_event(self._ev["ag" + which.upper()])
+
     def _xchg_post(self):
         """Publish the updated shards (shard mode)."""
         if self.dp_mode == "shard" and self.xchg.carrier != "none":
@@ -724,8 +847,13 @@ class FusedTrainer:
                 slot.noises.copy_(noises)
         self.march(slot, slot.rays_o, slot.rays_d, slot.noises, stage=stage)
 
-    def _step_ops(self, slot):
-        """Everything one step does after the rays are marched, as (name, thunk, lane) triples.  Lane "aux" marks the
+    def _step_ops(self, slot, gathered=True, gather=True, inline=False):
+        """Everything one step does after the rays are marched, as (name, thunk, lane) triples.
+        Exchange in two level groups only -- gathered: the parameters are complete when the step starts (False: the
+        previous step of the same graph left its all-gathers in flight; the encoder waits group by group); gather: wait for
+        this step's all-gathers at its end and rebuild the MLP's operand image (False: the next step of the graph does);
+        inline: the collectives stay on the main stream (they are launched outside the step's graphs: eager carrier, or a
+        step whose collectives bench.py times).  Lane "aux" marks the
         MLP-weight tail (gradient reduction, Adam, next step's f16 weight image): it depends only on the MLP backward,
         so on one GPU it runs on a third stream beside the table's fill + reduce instead of after them."""
         opt = self.opt
@@ -749,7 +877,7 @@ class FusedTrainer:
         self.table_backward_symbol = "ngp_x_grid_backward_binned_apply" + ("_mlp" if ride else "")   # (what bench.py times)
         field = self._field_ops(slot, slot.gt, slot.bg if opt.background == "random" else None, bg_const, zero_loss=False,
                                 fused_adam=self.fuse_adam, split_weights=True, overwrite=not self.fuse_adam,
-                                fuse_composite=True, mlp_tail=mlp_tail)
+                                fuse_composite=True, mlp_tail=mlp_tail, split=self.split)
         field = self._without(field, "ngp_x_grid_backward_binned_prepare")          # folded into step_begin
         if not self.rfield and not self.pose and os.environ.get("NGP_STEP_BEGIN_RIDES", "1") != "0":
             # ... which in turn is one more workgroup of the MLP forward's launch (nothing reads its results before the
@@ -810,6 +938,8 @@ class FusedTrainer:
                     ops += [(n, o, "main") for n, o in tail]
             ops += [(n, o, "main") for n, o in pose_tail]
             return ops
+        if self.split is not None:
+            return self._split_step_ops(field, pose_tail, ride, gathered, gather, inline)
         # ---- the exchange step: gradients -> collectives -> ONE Adam launch -> collectives -> next step's operand image
         ops += [(n, o, "main") for n, o in field]
         if not ride and not self.rfield:            # (the light-conditioned backward reduces its weight gradients itself)
@@ -824,6 +954,42 @@ class FusedTrainer:
         ops.append(("ngp_x_adam_step_dev", lambda: self.optimizer_step(device_hyper=True), "main"))
         ops.append(("xchg_post", self._xchg_post, "main"))
         ops.append(("ngp_x_mlp_prepare", self._mlp_prepare, "main"))
+        return ops
+
+    def _split_step_ops(self, field, pose_tail, ride, gathered, gather, inline):
+        """The exchange step in two level groups (see __init__): a = levels [0, split), b = the finer levels + the MLP weights
+        (69 % of the bytes at the default split of 8).  Main stream: encoder b, encoder a, field, compositor, field backward,
+        fill, reduce b, reduce a, Adam b, Adam a; the collectives go to the comm stream as soon as their inputs exist --
+        reduce-scatter b beside reduce a (the dense levels' heavy chunks: the longer of the two), all-gather b beside Adam a --
+        and the NEXT step of the same graph starts its encoder on group b's levels while the (small) all-gather of group a is
+        still running.  The order of the collectives is the same on every rank: rs b, rs a, ag b, ag a."""
+        opt = self.opt
+        ops = []
+        for name, op in field:
+            if name in ("fwd_a", "fwd_b") and not gathered:
+                g = name[-1]
+                ops.append(("wait_ag_" + g, lambda g=g: self._wait_gather(g, inline), "main"))
+            ops.append((name, op, "main"))
+            if name == "fwd_b" and not gathered:        # the MLP weights travel with group b: their operand image follows
+                ops.append(("ngp_x_mlp_prepare", self._mlp_prepare, "main"))
+            if name == "reduce_b":                      # (runs inside xchg_rs_b, on the comm stream: see _split_reduce_scatter)
+                ops.pop()
+                if not ride and not self.rfield:        # (weight gradients not reduced by the fill launch's passengers)
+                    ops.append(("ngp_x_mlp_reduce_dw", lambda: self.mb.reduce_dw(self.cap, opt.loss_scale, self.dws, self.ws_mlp,
+                                                                                 scaler=self.scaler), "main"))
+                ops.append(("xchg_rs_b", lambda op=op: self._split_reduce_scatter("b", inline, first=op), "main"))
+            if name == "reduce_a":
+                ops.append(("xchg_rs_a", lambda: self._split_reduce_scatter("a", inline), "main"))
+        if self.pose:
+            pose_tail.insert(2, ("xchg_pose", lambda: self.xchg.all_reduce_avg(self.grad_pose.view(-1))))
+            ops += [(n, o, "main") for n, o in pose_tail if n != "xchg_pose" or self.xchg.carrier != "none"]
+        ops += [("adam_b", lambda: self._split_adam("b", inline), "main"),
+                ("xchg_ag_b", lambda: self._split_all_gather("b", inline), "main"),
+                ("adam_a", lambda: self._split_adam("a", inline), "main"),
+                ("xchg_ag_a", lambda: self._split_all_gather("a", inline), "main")]
+        if gather:
+            ops += [("wait_ag", lambda: (self._wait_gather("a", inline), self._wait_gather("b", inline)), "main"),
+                    ("ngp_x_mlp_prepare", self._mlp_prepare, "main")]
         return ops
 
     def _run_ops(self, ops, fork=True):
@@ -885,8 +1051,9 @@ class FusedTrainer:
         # the collectives stay outside when their carrier cannot be captured (gloo, torch.distributed) and on the steps
         # bench.py times (HIP events around them)
         loose = self._loose_collectives(timed)
-        eager = {*(("xchg_pre", "xchg_post", "xchg_pose") if loose else ()), *(_lib.probed_symbols() if timed else ())}
-        ops = self._step_ops(slot)
+        eager = {*(("xchg_pre", "xchg_post", "xchg_pose", "xchg_rs_a", "xchg_rs_b", "xchg_ag_a", "xchg_ag_b") if loose else ()),
+                 *(_lib.probed_symbols() if timed else ())}
+        ops = self._step_ops(slot, inline=loose)
         # one graph: the aux lane may fork inside it
         whole = not any(name in eager for name, _, _ in ops) and bool(getattr(self.opt, "aux_stream", False))
         parts, run = [], []
@@ -1092,7 +1259,8 @@ class FusedTrainer:
                 cur = self.slots[(parity + k) % 2]
                 whole = k + 1 < G or last_ahead         # (else a refresh follows: only the bitfield-independent part)
                 nxt = self.slots[(parity + k + 1) % 2] if (whole or self._split_march) else None
-                ops = self._step_ops(cur)
+                # (exchange in two level groups: inside the graph a step's all-gathers run into the next step's encoder)
+                ops = self._step_ops(cur, gathered=k == 0, gather=k + 1 == G)
                 at = min(max(int(os.environ.get("NGP_SIDE_FORK_AT", "0")), 0), len(ops) - 1) if nxt is not None else 0
                 self._run_ops(ops[:at], fork=False)
                 if nxt is not None:         # fork: the next step's rays, on the side stream

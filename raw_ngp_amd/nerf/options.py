@@ -76,6 +76,10 @@ class Options:
                                   # the cross-rank sum is then formed in bfloat16, narrower than anything the reference does)
     dp_mode: str = "shard"        # data parallel: "shard" = reduce_scatter -> Adam on 1/R of the table -> all_gather
                                   # (SURVEY 8e), "allreduce" = gradient all-reduce + full Adam on every rank
+    dp_split_level: int = None    # data parallel, "shard", f32 wire: exchange the table in two level groups -- levels below this
+                                  # one, and the finer ones + the MLP weights -- so that reduce-scatter / all-gather of one group
+                                  # overlap the table reduction / the next step's encoder of the other (engine.py).  None: 8 with
+                                  # more than one rank, off on one; 0: off
     aux_stream: bool = False      # fused engine: MLP-weight tail (dW reduction, Adam, f16 image) on a third stream
                                   # (measured slower: the fork/join costs more than the ~20 us it takes off the main stream)
     fuse_adam: bool = True        # fused engine, one rank: Adam on the table inside the gradient reduction kernel

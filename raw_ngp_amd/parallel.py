@@ -264,6 +264,40 @@ class Exchange:
                     g.replay()
                     torch.cuda.synchronize(self.device)
                     ok = ok and right(a) and right(b)
+                # ... and the shape the step's exchange in two level groups has: collectives on a SECOND stream forked
+                # from the capturing one, compute on both, event edges back (engine.py: _on_comm / _split_adam)
+                if ok:
+                    side, ev1, ev2 = torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event()
+                    c = fill()
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                        main = torch.cuda.current_stream(self.device)
+                        a.mul_(2.0)                             # "reduce b"
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            self.reduce_scatter_avg(a)
+                            ev1.record(side)
+                        c.mul_(3.0)                             # "reduce a", beside the collective
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            self.all_reduce_avg(c)
+                            ev2.record(side)
+                        main.wait_event(ev1)
+                        lo, hi = self.shard_bounds(a)
+                        a[lo:hi].add_(1.0)                      # "Adam b"
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            self.all_gather(a)
+                        main.wait_event(ev2)
+                        c.add_(1.0)
+                        main.wait_stream(side)
+                    for _ in range(2):
+                        a.fill_(float(self.r + 1))
+                        c.fill_(float(self.r + 1))
+                        g2.replay()
+                        torch.cuda.synchronize(self.device)
+                        ok = ok and bool(torch.allclose(a, torch.full_like(a, 2.0 * want + 1.0), rtol=1e-6)) \
+                            and bool(torch.allclose(c, torch.full_like(c, 3.0 * want + 1.0), rtol=1e-6))
         except Exception as e:      # noqa: BLE001 -- any failure means "do not use this carrier"
             print(f"[rank {self.r}] Exchange.self_test({self.carrier}) failed: {e}", flush=True)
             ok = False

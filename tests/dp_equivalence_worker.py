@@ -36,19 +36,26 @@ def draw(data, n, seed, dev):
 
 def main():
     out_dir, mode, wire = sys.argv[1], sys.argv[2], sys.argv[3]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     from raw_ngp_amd import _lib, parallel
     rank, world, local = parallel.init_from_env("cuda")
     dev = torch.device("cuda", local)
     _lib.load()
     opt, data, tr = setup(2048, dev, dp_mode=mode, grad_wire=wire)
     assert tr.dp and tr.xchg is not None and tr.xchg.R == world
-    batch, noises = draw(data, 2048, 100 + rank, dev)
-    tr.train_step(batch, noises)
+    flat0 = tr.flat.clone()
+    for k in range(steps):
+        batch, noises = draw(data, 2048, 100 + rank + 10 * k, dev)
+        tr.train_step(batch, noises)
     torch.cuda.synchronize()
     x = tr.xchg
-    lo, hi = x.shard_bounds(tr.gflat) if mode == "shard" else (0, tr.gflat.numel())
-    own = x.shard_of(tr.gflat) if mode == "shard" else tr.gflat
+    if tr.split is not None:                # (two level groups: the test that reads `grad` runs the one-group exchange)
+        lo, hi, own = 0, 0, tr.gflat[:0]
+    else:
+        lo, hi = x.shard_bounds(tr.gflat) if mode == "shard" else (0, tr.gflat.numel())
+        own = x.shard_of(tr.gflat) if mode == "shard" else tr.gflat
     torch.save({"lo": lo, "hi": hi, "grad": own.float().cpu(), "flat": tr.flat.cpu(), "w": tr.w_flat.cpu(),
+                "flat0": flat0.cpu(), "split": tr.split is not None, "n_params": tr.table.numel() + tr.w_flat.numel(),
                 "loss": float(tr.loss), "samples": int(tr.arena.counter[0])}, os.path.join(out_dir, f"dp{rank}.pt"))
     parallel.barrier()
     torch.distributed.destroy_process_group()

@@ -49,7 +49,8 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mode, wire
     bfloat16 wire: 1e-2 (three significant digits per rank, by construction)."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import dp_equivalence_worker as W
-    env = dict(os.environ, NGP_DIST_BACKEND="gloo", NGP_LOCAL_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    # (the gradient shards are read back: the one-group exchange; the two-group one is compared with it bit for bit below)
+    env = dict(os.environ, NGP_DIST_BACKEND="gloo", NGP_LOCAL_DEVICE="0", MASTER_ADDR="127.0.0.1", NGP_DP_SPLIT="0")
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
     port = 29850 + (os.getpid() % 100) + {"shard": 0, "allreduce": 1}[mode] + (2 if wire == "bf16" else 0)
@@ -132,4 +133,33 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1                                      # rank 0 prints, once
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["ranks_seen"] == 2 and res["config"]["parallelism"] == "dp2"
-    assert res["config"]["replicas_in_sync"] is True and res["roofline"]["launches"] >= 2
+    assert res["config"]["replicas_in_sync"] is True and res["config"]["dp_split_level"] == 8
+    assert res["roofline_forward"] is None or res["roofline_forward"]["launches"] >= 1
+
+
+def test_exchange_in_two_level_groups_trains_the_bits_of_the_single_exchange(tmp_path):
+    """The data-parallel exchange in two level groups (reduce-scatter of levels 0-7 beside the reduction of levels 8-15,
+    all-gather of the second group into the next step's encoder; group a's seam all-reduced and stepped on every rank) is a
+    re-partition of the same averages: two ranks end a step with exactly the parameters of the one-group exchange --
+    gradient shards, Adam, every bit."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for split in ("1", "0"):
+        env = dict(os.environ, NGP_DIST_BACKEND="gloo", NGP_LOCAL_DEVICE="0", MASTER_ADDR="127.0.0.1", NGP_DP_SPLIT=split)
+        env.pop("RANK", None)
+        env.pop("WORLD_SIZE", None)
+        d = tmp_path / f"split{split}"
+        d.mkdir()
+        port = 29700 + (os.getpid() % 100) + int(split)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_equivalence_worker.py"), str(d),
+               "shard", "f32", "3"]
+        res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        out[split] = [torch.load(os.path.join(d, f"dp{r}.pt"), weights_only=True) for r in range(2)]
+    a, b = out["1"], out["0"]
+    assert a[0]["split"] is True and b[0]["split"] is False
+    n = a[0]["n_params"]
+    assert torch.equal(a[0]["flat"][:n], a[1]["flat"][:n])                  # replicas
+    assert torch.equal(a[0]["flat"][:n], b[0]["flat"][:n])                  # ... and the one-group exchange's bits
+    assert float((a[0]["flat"][:n] - a[0]["flat0"][:n]).abs().max()) > 0    # (it trained)

@@ -38,4 +38,19 @@ dist.all_reduce(lo, op=dist.ReduceOp.MIN)
 dist.all_reduce(hi, op=dist.ReduceOp.MAX)
 assert torch.equal(lo, hi)
 print("rccl ok: bf16 AVG, f32 AVG (async), f64 MIN/MAX, interleaved with graph replays")
+
+# the carrier of the data-parallel step: bare RCCL calls, set up and self-tested the way a multi-rank job does it
+# (unique id through the store, worker thread under a deadline, eager + captured + two-stream captured known answers)
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raw_ngp_amd import parallel  # noqa: E402
+xchg = parallel.guarded_rccl_exchange(dev, timeout_s=120)
+assert xchg is not None and xchg.carrier == "rccl" and xchg.capturable
+assert xchg.self_test()
+flag = torch.tensor([3], dtype=torch.int32, device=dev)
+xchg.all_reduce_max(flag)
+torch.cuda.synchronize()
+assert int(flag) == 3
+xchg.close()
+print("raw_ngp_amd.parallel: guarded RCCL exchange passed its self-test (eager, graph, two-stream graph) on one rank")
 dist.destroy_process_group()
