@@ -445,8 +445,12 @@ def main():
         def forward(self, d):
             return sh16(d)
 
-    for tag, rfield in (("plain", False), ("rfield", True)):
-        fopt = types.SimpleNamespace(**{**base, "rfield": rfield, "pose_opt": "none"})
+    # (the plain field also with the reference's other OUTPUT activations, network.py:115,131-135: softplus density with
+    # beta = 2, exp and sigmoid colour -- what ngp_x_mlp_forward_act / ngp_x_mlp_backward_act implement)
+    for tag, rfield, acts in (("plain", False, {}), ("rfield", True, {}),
+                              ("plain_exp_softplus", False, dict(color_activation="exp", density_activation="softplus", beta=2.0)),
+                              ("plain_sigmoid", False, dict(color_activation="sigmoid"))):
+        fopt = types.SimpleNamespace(**{**base, "rfield": rfield, "pose_opt": "none", **acts})
         torch.manual_seed(3 if rfield else 2)
         net = NW.NeRFNetwork(fopt)
         Mf = 96

@@ -61,6 +61,9 @@ _SIGNATURES = {
     "ngp_x_grid_encode_forward_jac": [_p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _p, _u, _i, _u, _i],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
+    "ngp_x_mlp_forward_act": [_p, _u, _p, _p, _u, _p, _p, _p, _u, _u, _f],
+    "ngp_x_mlp_backward_act": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t,
+                               _p, _u, _u, _f],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_mlp_backward_dirs": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_mlp_backward_list": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t,
@@ -659,6 +662,14 @@ class _RayBackend:
         _call("ngp_x_build_occupancy_index", grid, _ptr(grid, "b", "grid"), C, H, _ptr(index, "i", "index"))
 
 
+def field_activations(opt):
+    """(color_act, density_act, beta) of an options object for the fused MLP kernels, or None for a configuration they do not
+    implement (network.py:111-135: colour clamped_exp / exp / sigmoid, density clamped_exp (= trunc_exp) / softplus)."""
+    color = {"clamped_exp": 0, "exp": 1, "sigmoid": 2}.get(getattr(opt, "color_activation", "clamped_exp"))
+    density = 0 if getattr(opt, "density_activation", "clamped_exp") == "clamped_exp" else 1
+    return None if color is None else (color, density, float(getattr(opt, "beta", 1.0)))
+
+
 class _MlpBackend:
     """Fused tiny-MLP field (extension; no counterpart among the reference's bindings)."""
 
@@ -673,12 +684,18 @@ class _MlpBackend:
               image.data_ptr())
 
     @staticmethod
-    def forward(enc, stride, dirs, M_dev, M, image, sigma, rgb, step_begin=None):
+    def forward(enc, stride, dirs, M_dev, M, image, sigma, rgb, step_begin=None, act=None):
         """step_begin = (step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out, samples_seen, sample_counter,
         binned_workspace, L, n_rows_total, single_segment), the arguments of engine_backend.step_begin: that bookkeeping
-        rides along as one more workgroup of this launch (ngp_x_mlp_forward_step_begin)."""
+        rides along as one more workgroup of this launch (ngp_x_mlp_forward_step_begin).
+        act = (color_act, density_act, beta): the field's non-default output activations (field_activations())."""
         args = [_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs", True), _ptr(M_dev, "i", "M_dev", True), M,
                 image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb", True)]
+        if act is not None and tuple(act[:2]) != (0, 0):
+            if step_begin is not None:
+                raise RuntimeError("mlp forward: the step_begin passenger rides on the default activations only")
+            _call("ngp_x_mlp_forward_act", enc, *args, int(act[0]), int(act[1]), float(act[2]), probe_as="ngp_x_mlp_forward")
+            return
         if step_begin is None:
             _call("ngp_x_mlp_forward", enc, *args)
             return
@@ -698,7 +715,7 @@ class _MlpBackend:
 
     @staticmethod
     def backward(enc, stride, dirs, dsigma, drgb, M_dev, M, image, loss_scale, denc, dws, workspace=None, ddirs=None,
-                 sample_index=None, scaler=None):
+                 sample_index=None, scaler=None, act=None):
         """dws: six pre-allocated fp32 tensors shaped like the weights (overwritten), or None to leave the partial
         sums in `workspace` for reduce_dw().  workspace: uint8 tensor of backward_workspace_bytes(M) (allocated per
         call when omitted).  ddirs [M,3] (optional): d loss / d (un-normalised view direction).  sample_index (int32,
@@ -711,7 +728,11 @@ class _MlpBackend:
         grads = [_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)] if dws is not None else [None] * 6
         head = (_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"), _ptr(dsigma, "f", "dsigma"), _ptr(drgb, "f", "drgb"),
                 _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"))
-        if sample_index is not None or scaler is not None:
+        if act is not None and tuple(act[:2]) != (0, 0):        # the field's non-default output activations
+            _call("ngp_x_mlp_backward_act", enc, *head[:7], _ptr(sample_index, "i", "sample_index", True), *head[7:],
+                  _ptr(ddirs, "f", "ddirs", True), *grads, ws.data_ptr(), nbytes, _scaler_ptr(scaler), int(act[0]), int(act[1]),
+                  float(act[2]), probe_as="ngp_x_mlp_backward")
+        elif sample_index is not None or scaler is not None:
             _call("ngp_x_mlp_backward_list", enc, *head[:7], _ptr(sample_index, "i", "sample_index", True), *head[7:],
                   _ptr(ddirs, "f", "ddirs", True), *grads, ws.data_ptr(), nbytes, _scaler_ptr(scaler))
         elif ddirs is not None:

@@ -20,8 +20,12 @@ constexpr uint32_t kMaxChunks = (1u << 23) >> kChunkShift;   // LDS histogram bo
 constexpr uint32_t kSegBig = 8 * kSeg;   // ... of a heavy chunk (coarse dense levels): fewer, longer items
 constexpr uint32_t kReduceBlock = 512;
 constexpr int kHeadroomBits = 25;        // records that may land on one row without overflowing the int64 sum
-constexpr uint32_t kFillTile = 512;      // samples per fill workgroup
-constexpr uint32_t kFillBlock = 512;     // ... one per lane
+#ifndef NGP_FILL_TILE
+#define NGP_FILL_TILE 512
+#endif
+constexpr uint32_t kFillTile = NGP_FILL_TILE;   // samples per fill workgroup (a multiple of 256; -DNGP_FILL_TILE=256 to try)
+constexpr uint32_t kFillBlock = kFillTile;      // ... one per lane
+constexpr uint32_t kFillTailPer = kFillBlock / 256u;   // passenger groups (256 lanes each) per fill workgroup
 constexpr uint32_t kCountTile = 2048;    // samples per count workgroup (8 per lane)
 
 // workspace header (uint32 words); arrays sized for n_chunks_max

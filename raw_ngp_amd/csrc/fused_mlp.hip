@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, kFwdWgPerCu) void mlp_forward_kernel(const flo
                                                             const int32_t *__restrict__ M_dev, uint32_t M_host,
                                                             const half8 *__restrict__ image,
                                                             float *__restrict__ sigma, float *__restrict__ rgb,
-                                                            StepBegin begin)
+                                                            StepBegin begin, FieldAct act = FieldAct{})
 {
     if (PASSENGER && blockIdx.x == 0) {
         step_begin_block(begin);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, kFwdWgPerCu) void mlp_forward_kernel(const flo
             for (int s = 0; s < 2; s++) o = mfma(wf[F_W3 + kb * 2 + s], x[kb][s], o);
         const float sigma_raw = o[0];
         if (rgb == nullptr) {   // density-only query (density-grid refresh): skip the colour MLP
-            if (valid && h == 0) sigma[row] = __expf(sigma_raw);
+            if (valid && h == 0) sigma[row] = act_sigma(sigma_raw, act);
             continue;
         }
         // layer 4: [sigma row (zero weight), 15 features, SH16] -> 64
@@ -189,10 +189,10 @@ __global__ __launch_bounds__(256, kFwdWgPerCu) void mlp_forward_kernel(const flo
             for (int s = 0; s < 2; s++) c = mfma(lds_w[(L_W6 + kb * 2 + s) * 64 + lane], x[kb][s], c);
 
         if (valid && h == 0) {   // rows 0..3 of a tile live in registers 0..3 of the h = 0 lanes
-            sigma[row] = __expf(sigma_raw);
-            rgb[(size_t)row * 3 + 0] = fminf(__expf(c[0] - 5.0f), 5.0f);
-            rgb[(size_t)row * 3 + 1] = fminf(__expf(c[1] - 5.0f), 5.0f);
-            rgb[(size_t)row * 3 + 2] = fminf(__expf(c[2] - 5.0f), 5.0f);
+            sigma[row] = act_sigma(sigma_raw, act);
+            rgb[(size_t)row * 3 + 0] = act_color(c[0], act);
+            rgb[(size_t)row * 3 + 1] = act_color(c[1], act);
+            rgb[(size_t)row * 3 + 2] = act_color(c[2], act);
         }
     }
 }
@@ -218,14 +218,26 @@ extern "C" int ngp_x_mlp_prepare(const float *w1, const float *w2, const float *
 extern "C" int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
                                  const void *image, float *sigma, float *rgb, ngp_stream_t stream)
 {
+    return ngp_x_mlp_forward_act(enc, stride, dirs, M_dev, M, image, sigma, rgb, 0, 0, 1.0f, stream);
+}
+
+// ... with the field's non-default output activations (network.py:111-135): color_act 0 clamped_exp / 1 exp / 2 sigmoid,
+// density_act 0 trunc_exp / 1 softplus(beta, threshold 20)
+extern "C" int ngp_x_mlp_forward_act(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
+                                     const void *image, float *sigma, float *rgb, uint32_t color_act, uint32_t density_act,
+                                     float beta, ngp_stream_t stream)
+{
     if (M == 0) return NGP_OK;
+    NGP_REQUIRE(color_act <= 2u && density_act <= 1u && beta > 0.0f, "mlp_forward: unknown activation or beta <= 0");
     NGP_REQUIRE(enc && image && sigma, "mlp_forward: null tensor");
     NGP_REQUIRE(rgb == nullptr || dirs != nullptr, "mlp_forward: dirs missing");
     NGP_REQUIRE(stride >= M, "mlp_forward: encoder slab stride smaller than M");
     const uint32_t tiles = ceil_div(M, 32u);
     const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * kFwdWgPerCu);
+    FieldAct act;
+    act.color = color_act, act.density = density_act, act.beta = beta;
     mlp_forward_kernel<false><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(
-        enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, StepBegin{});
+        enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, StepBegin{}, act);
     NGP_CHECK_LAUNCH("mlp_forward");
     return NGP_OK;
 }

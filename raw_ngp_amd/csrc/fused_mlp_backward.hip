@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
     const float *__restrict__ enc, uint32_t stride, const float *__restrict__ dirs, const float *__restrict__ dsigma,
     const float *__restrict__ drgb, const int32_t *__restrict__ M_dev, uint32_t M_host,
     const half8 *__restrict__ image, float loss_scale_host, half8 *__restrict__ d3buf, float *__restrict__ partial,
-    float *__restrict__ ddirs, const int32_t *__restrict__ live_idx, const float *__restrict__ scaler)
+    float *__restrict__ ddirs, const int32_t *__restrict__ live_idx, const float *__restrict__ scaler, FieldAct act)
 {
     extern __shared__ half8 lds_w[];   // fragments 0..45 (46 KiB); reused as the f32 reduction image at the end
     // scaler: the loss scale lives on the device and adapts (mlp_common.hpp: LossScalerWord); deltas then overflow to inf
@@ -347,11 +347,10 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
         // ---------------- output deltas (scaled by loss_scale so that they survive f16)
         const float gs = cur.gs, gr0 = cur.gr[0], gr1 = cur.gr[1], gr2 = cur.gr[2];
         f32x16 d6 = zero16();
-        if (h == 0) {   // rows 0..2 of the tile: d rgb / d raw = exp(raw - 5) where the clamp at 5 is inactive
-            const float e0 = __expf(c[0] - 5.0f), e1 = __expf(c[1] - 5.0f), e2 = __expf(c[2] - 5.0f);
-            d6[0] = e0 <= 5.0f ? gr0 * e0 * loss_scale : 0.0f;
-            d6[1] = e1 <= 5.0f ? gr1 * e1 * loss_scale : 0.0f;
-            d6[2] = e2 <= 5.0f ? gr2 * e2 * loss_scale : 0.0f;
+        if (h == 0) {   // rows 0..2 of the tile: d rgb / d raw (default: exp(raw - 5) where the clamp at 5 is inactive)
+            d6[0] = gr0 * act_dcolor(c[0], act) * loss_scale;
+            d6[1] = gr1 * act_dcolor(c[1], act) * loss_scale;
+            d6[2] = gr2 * act_dcolor(c[2], act) * loss_scale;
         }
         const half8 p6 = pack_sat<0>(d6, lim);
 
@@ -431,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 #pragma unroll
             for (int s = 0; s < 2; s++) dx3 = mfma(NGP_FRAG(T_W4 + kb * 2 + s), p4[kb][s], dx3);
         // delta3: rows 1..15 = d features, row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp)
-        if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
+        if (h == 0) dx3[0] = gs * act_dsigma(sigma_raw, act) * loss_scale;
         if (valid) d3buf[(size_t)c_idx * 2 + h] = pack_sat<0>(dx3, lim);
         if constexpr (DDIRS) {
             float dx = 0.f, dy = 0.f, dz = 1.f;
@@ -814,6 +813,21 @@ extern "C" int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const 
                                        float *dw2, float *dw3, float *dw4, float *dw5, float *dw6, void *workspace,
                                        size_t workspace_bytes, float *loss_scaler, ngp_stream_t stream)
 {
+    return ngp_x_mlp_backward_act(enc, stride, dirs, dsigma, drgb, M_dev, M, sample_index, image, loss_scale, denc, ddirs, dw1,
+                                  dw2, dw3, dw4, dw5, dw6, workspace, workspace_bytes, loss_scaler, 0, 0, 1.0f, stream);
+}
+
+// ... with the field's non-default output activations (as ngp_x_mlp_forward_act)
+extern "C" int ngp_x_mlp_backward_act(const float *enc, uint32_t stride, const float *dirs, const float *dsigma,
+                                      const float *drgb, const int32_t *M_dev, uint32_t M, const int32_t *sample_index,
+                                      const void *image, float loss_scale, float *denc, float *ddirs, float *dw1,
+                                      float *dw2, float *dw3, float *dw4, float *dw5, float *dw6, void *workspace,
+                                      size_t workspace_bytes, float *loss_scaler, uint32_t color_act, uint32_t density_act,
+                                      float beta, ngp_stream_t stream)
+{
+    NGP_REQUIRE(color_act <= 2u && density_act <= 1u && beta > 0.0f, "mlp_backward: unknown activation or beta <= 0");
+    FieldAct act;
+    act.color = color_act, act.density = density_act, act.beta = beta;
     const bool reduce_now = dw1 != nullptr;   // all NULL: leave the per-workgroup partials for ngp_x_mlp_reduce_dw
     NGP_REQUIRE(image && workspace, "mlp_backward: null tensor");
     NGP_REQUIRE(reduce_now ? (dw2 && dw3 && dw4 && dw5 && dw6) : (!dw2 && !dw3 && !dw4 && !dw5 && !dw6),
@@ -833,11 +847,11 @@ extern "C" int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const 
     if (ddirs)
         mlp_backward_view_kernel<true><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
                                                                                   loss_scale, d3buf, part_view, ddirs,
-                                                                                  sample_index, loss_scaler);
+                                                                                  sample_index, loss_scaler, act);
     else
         mlp_backward_view_kernel<false><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M,
                                                                                    img, loss_scale, d3buf, part_view, nullptr,
-                                                                                   sample_index, loss_scaler);
+                                                                                   sample_index, loss_scaler, act);
     mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
                                                                                d3buf, denc, part_grid, nullptr, T_W3,
                                                                                sample_index, loss_scaler);

@@ -101,6 +101,41 @@ struct MlpWeights {
     const float *w1, *w2, *w3, *w4, *w5, *w6;
 };
 
+// ---- output activations of the field (nerf/network.py:111-135 of the reference) ------------------------------------------
+// density: 0 = trunc_exp (exp forward, exp(clamp(x, -80?, 80)) backward: activation.py; `clamped_exp`, the default),
+//          1 = softplus(beta, threshold 20);   colour: 0 = clamp(exp(x - 5), max 5) (default), 1 = exp(x - 5), 2 = sigmoid
+struct FieldAct {
+    uint32_t color = 0, density = 0;
+    float beta = 1.0f;
+};
+__device__ __forceinline__ float act_sigma(float h, const FieldAct &a)
+{
+    if (a.density == 0u) return __expf(h);
+    const float z = a.beta * h;                                  // F.softplus(h, beta, threshold = 20)
+    return z > 20.0f ? h : log1pf(__expf(z)) / a.beta;
+}
+__device__ __forceinline__ float act_dsigma(float h, const FieldAct &a)   // d sigma / d h
+{
+    if (a.density == 0u) return __expf(fminf(fmaxf(h, -80.0f), 80.0f));   // trunc_exp's backward
+    const float z = a.beta * h;
+    return z > 20.0f ? 1.0f : 1.0f / (1.0f + __expf(-z));
+}
+__device__ __forceinline__ float act_color(float c, const FieldAct &a)
+{
+    if (a.color == 2u) return 1.0f / (1.0f + __expf(-c));
+    const float e = __expf(c - 5.0f);
+    return a.color == 1u ? e : fminf(e, 5.0f);
+}
+__device__ __forceinline__ float act_dcolor(float c, const FieldAct &a)   // d colour / d c
+{
+    if (a.color == 2u) {
+        const float s = 1.0f / (1.0f + __expf(-c));
+        return s * (1.0f - s);
+    }
+    const float e = __expf(c - 5.0f);
+    return (a.color == 1u || e <= 5.0f) ? e : 0.0f;              // (the clamp's gradient is zero where it is active)
+}
+
 // ------------------------------------------------------------------ weight image
 __device__ __forceinline__ float frag_elem(uint32_t f, uint32_t r, uint32_t h, uint32_t t, const MlpWeights &W)
 {

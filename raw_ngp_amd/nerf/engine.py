@@ -93,6 +93,12 @@ class FusedTrainer:
         opt.fused_mlp = True
         assert model._fused(), "fused step needs the default field configuration"
         self.mb = mb = _mlp_rf if self.rfield else _mlp_plain
+        # the field's output activations (network.py:115,131-135); None = the defaults (trunc_exp density, clamped_exp colour)
+        from .._lib import field_activations
+        act = field_activations(opt)
+        self.act = act if act[:2] != (0, 0) else None
+        assert self.act is None or not (self.rfield or float(getattr(opt, "lambda_orientation", 0.0)) > 0), \
+            "fused step: softplus density / exp, sigmoid colour are built for the plain field without the orientation term"
         self.rank, self.world_size = parallel.rank(), parallel.world_size()
         # data-parallel step (separate Adam pass, gradient collectives); `dp_rehearsal` runs it on one rank as well
         self.dp = self.world_size > 1 or (bool(getattr(opt, "dp_rehearsal", False)) and parallel.is_dist())
@@ -400,7 +406,7 @@ class FusedTrainer:
         else:
             if self.pose:           # the plain field kernels carry no level window: BARF scale / BAA blend on the slab
                 eb.slab_window(self.enc, stride, self.L, self.level_w, cnt, M, scale_only=not self.baa)
-            self.mb.forward(self.enc, stride, dirs, cnt, M, self.mlp_image, sigma, rgb, step_begin=step_begin)
+            self.mb.forward(self.enc, stride, dirs, cnt, M, self.mlp_image, sigma, rgb, step_begin=step_begin, act=self.act)
 
     def march(self, slot, rays_o, rays_d, noises, aabb=None, plan=True, stage=0):
         """rays -> sample arena of `slot` (near/far, count, scan, expand); runs on the current stream.
@@ -505,7 +511,8 @@ class FusedTrainer:
             else:
                 self.mb.backward(self.enc, cap, ar.dirs, self.dsigma, self.drgb, back_n, cap, self.mlp_image, opt.loss_scale,
                                  self.denc, None if split_weights else self.dws, self.ws_mlp,
-                                 ddirs=self.ddirs if self.pose else None, sample_index=back_idx, scaler=self.scaler)
+                                 ddirs=self.ddirs if self.pose else None, sample_index=back_idx, scaler=self.scaler,
+                                 act=self.act)
                 if self.pose:       # the window's adjoint: d enc' -> d enc
                     eb.slab_window(self.denc, cap, self.L, self.level_w, back_n, cap, backward=True, scale_only=not self.baa)
 
@@ -879,7 +886,7 @@ class FusedTrainer:
                                 fused_adam=self.fuse_adam, split_weights=True, overwrite=not self.fuse_adam,
                                 fuse_composite=True, mlp_tail=mlp_tail, split=self.split)
         field = self._without(field, "ngp_x_grid_backward_binned_prepare")          # folded into step_begin
-        if not self.rfield and not self.pose and os.environ.get("NGP_STEP_BEGIN_RIDES", "1") != "0":
+        if not self.rfield and not self.pose and self.act is None and os.environ.get("NGP_STEP_BEGIN_RIDES", "1") != "0":
             # ... which in turn is one more workgroup of the MLP forward's launch (nothing reads its results before the
             # compositor): one kernel and one dependent-launch gap fewer on the critical path
             ar, cap = slot.arena, self.cap

@@ -129,12 +129,17 @@ class NeRFNetwork(NeRFRenderer):
 
     # -- fused MFMA path (extension; Options.fused_mlp) ------------------------------------------
     def _fused(self, plain_only=False):
-        """The field configuration the MFMA kernels implement (ReLU, trunc_exp density, clamped_exp colour).
+        """The field configuration the MFMA kernels implement: ReLU hidden layers; trunc_exp density and clamped_exp colour,
+        and -- for the plain field -- the reference's other OUTPUT activations (softplus density, exp / sigmoid colour:
+        network.py:115,131-135; internal_activation = softplus runs on the per-op path).
         plain_only: additionally the 31-input view MLP without level windows -- what the autograd op `fused_field`
         covers; the light-conditioned / BARF variants exist for the fused training step only (nerf/engine.py)."""
+        from .._lib import field_activations
         o = self.opt
-        ok = (getattr(o, "fused_mlp", False) and o.internal_activation == "relu" and o.density_activation == "clamped_exp"
-              and o.color_activation == "clamped_exp" and self.grid_encoder.embeddings.is_cuda)
+        act = field_activations(o)
+        default = act is not None and act[:2] == (0, 0)
+        ok = (getattr(o, "fused_mlp", False) and o.internal_activation == "relu" and act is not None
+              and (default or not o.rfield) and self.grid_encoder.embeddings.is_cuda)
         if plain_only:
             ok = ok and not o.rfield and o.pose_opt == "none"
         return ok
@@ -157,8 +162,9 @@ class NeRFNetwork(NeRFRenderer):
         if self._fused(plain_only=True) and not d.requires_grad:
             from .fused_field import fused_field
             enc = self.grid_encoder(x.reshape(-1, 3), bound=self.bound, slab=True)
+            from .._lib import field_activations
             sigma, color = fused_field(enc, d.reshape(-1, 3), self._mlp_weights(),
-                                       getattr(self.opt, "loss_scale", 65536.0))
+                                       getattr(self.opt, "loss_scale", 65536.0), field_activations(self.opt))
             return {"sigma": sigma.view(x.shape[:-1]), "color": color.view(*x.shape[:-1], 3)}
         sigma, feat = self.common_forward(x)
         parts = [feat, self.view_encoder(d)]
@@ -178,7 +184,8 @@ class NeRFNetwork(NeRFRenderer):
         if self._fused(plain_only=True) and not torch.is_grad_enabled() and not (0 <= proposal < len(getattr(self, "prop_encoders", ()))):
             from .fused_field import fused_density
             enc = self.grid_encoder(x.reshape(-1, 3), bound=self.bound, slab=True)
-            return {"sigma": fused_density(enc, self._mlp_weights()).view(x.shape[:-1])}
+            from .._lib import field_activations
+            return {"sigma": fused_density(enc, self._mlp_weights(), field_activations(self.opt)).view(x.shape[:-1])}
         if 0 <= proposal < len(getattr(self, "prop_encoders", ())):
             h = self.prop_encoders[proposal](x, bound=self.bound)
             sigma = trunc_exp(self.prop_mlp[proposal](h).squeeze(-1))

@@ -250,3 +250,47 @@ def test_kernels_read_the_scale_from_the_device_and_raise_the_overflow_word(lib,
     sc.found.zero_()
     e.adam_step_dev(p, gr, m, v, hyper, 0.9, 0.999, 1e-15, skip=sc.found)
     assert not torch.equal(keep[0], p)
+
+
+@pytest.mark.parametrize("acts", [dict(color_activation="exp", density_activation="softplus", beta=2.0),
+                                  dict(color_activation="sigmoid")], ids=["exp+softplus", "sigmoid"])
+def test_fused_step_with_the_other_output_activations_matches_the_per_op_path(lib, acts):
+    """The reference's non-default OUTPUT activations (network.py:115,131-135) inside the fused step: loss and gradients of
+    one batch against the per-op autograd path over fp32 nn.Linear MLPs with the same activations (torch's own softplus /
+    sigmoid / exp), f16-operand tolerance."""
+    from raw_ngp_amd.nerf.engine import FusedTrainer
+    from raw_ngp_amd.nerf.network import NeRFNetwork
+    from raw_ngp_amd.nerf.options import Options
+    from raw_ngp_amd.nerf.scene import SyntheticDataset
+    torch.manual_seed(0)
+    opt = Options(bound=1.0, num_rays=1024, iters=100, fused_mlp=True, background="black", **acts)
+    data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=4, H=64, W=64)
+    model = NeRFNetwork(opt).cuda()
+    with torch.no_grad():
+        model.grid_encoder.embeddings.uniform_(-0.5, 0.5)
+    eng = FusedTrainer(opt, model, data, device="cuda", capacity=1024 * 256)
+    assert eng.act is not None
+    model.train()
+    model.update_extra_state()
+    batch = data.sample_rays(opt.num_rays, torch.Generator(device="cuda").manual_seed(1))
+    gt = batch["images"]
+    eng.forward_backward(batch["rays_o"].contiguous(), batch["rays_d"].contiguous(), gt.contiguous(),
+                         torch.zeros(opt.num_rays, device="cuda"))
+    M = int(eng.arena.counter[0])
+    opt.fused_mlp = False                       # the per-op path: nn.Linear MLPs + torch activations (network.py line by line)
+    model.zero_grad()
+    out = model.render(batch["rays_o"], batch["rays_d"], bg_color=0, perturb=False)
+    assert out["num_points"] == M
+    loss = ((out["image"] - gt[:, :3] * gt[:, 3:]) ** 2).mean(-1).mean()
+    loss.backward()
+    ref_t = model.grid_encoder.embeddings.grad
+    ref_w = torch.cat([l.weight.grad.reshape(-1) for l in list(model.grid_mlp.net) + list(model.view_mlp.net)])
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    np.testing.assert_allclose(float(eng.loss), float(loss.detach()), rtol=2e-3)
+    assert rel(eng.table_grad, ref_t) < 3e-2 and rel(eng.w_grad, ref_w) < 3e-2, (rel(eng.table_grad, ref_t), rel(eng.w_grad, ref_w))
+    # ... and a few fused training steps run (graphs, refresh with the softplus density) and stay finite
+    opt.fused_mlp = True
+    for _ in range(20):
+        eng.train_step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.table).all()) and bool(torch.isfinite(eng.w_flat).all()) and np.isfinite(float(eng.loss))

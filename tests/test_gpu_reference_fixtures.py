@@ -40,11 +40,15 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-@pytest.mark.parametrize("tag", ["plain", "rfield"])
+@pytest.mark.parametrize("tag", ["plain", "rfield", "plain_exp_softplus", "plain_sigmoid"])
 def test_fused_field_matches_the_reference_network(golden_dir, tag):
+    """The reference's NeRFNetwork.forward + autograd on CPU (oracle/gen_golden.py: its own MLP class and activations) against
+    the fused MFMA kernels.  plain_exp_softplus / plain_sigmoid: the reference's other OUTPUT activations (network.py:115,
+    131-135: softplus density with beta = 2 + exp colour; sigmoid colour) through ngp_x_mlp_forward_act / _backward_act."""
     from raw_ngp_amd import _lib
     g = np.load(os.path.join(golden_dir, f"field_{tag}.npz"))
     rf = tag == "rfield"
+    act = {"plain_exp_softplus": (1, 1, 2.0), "plain_sigmoid": (2, 0, 1.0)}.get(tag)
     mb = _lib.mlp_rf_backend if rf else _lib.mlp_backend
     W = [dev(g[f"w{i}"]) for i in range(1, 7)]
     assert tuple(W[3].shape) == ((80, 47) if rf else (64, 31))
@@ -57,7 +61,7 @@ def test_fused_field_matches_the_reference_network(golden_dir, tag):
     if rf:
         mb.forward(enc, M, dirs, ldirs, None, None, M, image, sigma, rgb)
     else:
-        mb.forward(enc, M, dirs, None, M, image, sigma, rgb)
+        mb.forward(enc, M, dirs, None, M, image, sigma, rgb, act=act)
     np.testing.assert_allclose(sigma.cpu().numpy(), g["sigma"], rtol=3e-2, atol=1e-4)
     np.testing.assert_allclose(rgb.cpu().numpy(), g["color"], rtol=3e-2, atol=1e-4)
     denc = torch.empty(16, M, 2, device="cuda")
@@ -65,7 +69,7 @@ def test_fused_field_matches_the_reference_network(golden_dir, tag):
     if rf:
         mb.backward(enc, M, dirs, ldirs, None, dev(g["dsigma"]), dev(g["drgb"]), None, M, image, 1024.0, denc, None, dws)
     else:
-        mb.backward(enc, M, dirs, dev(g["dsigma"]), dev(g["drgb"]), None, M, image, 1024.0, denc, dws)
+        mb.backward(enc, M, dirs, dev(g["dsigma"]), dev(g["drgb"]), None, M, image, 1024.0, denc, dws, act=act)
     got = denc.permute(1, 0, 2).reshape(M, 32).cpu().numpy()
     assert rel_l2(got, g["dfeat"]) < 5e-2, rel_l2(got, g["dfeat"])
     for i in range(6):
