@@ -49,21 +49,20 @@ METRIC = "training rays/sec + PSNR@5k-iters, NeRF-synthetic Lego 800², 1/2/4/8 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 # HBM-side traffic of the hash-grid kernels, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE ON THIS SCRIPT's own
-# steady state (tools/pmc_bench.sh, profiles/r03_pmc_bench_traffic.csv: last 30 steps before iteration 5000, 136.6 k live
-# samples per step, --no-graph; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950 -- full-line reads are tallied
-# at 64 B).  Counters cannot be read while this script times itself, so the per-sample figures are carried as constants and
-# scaled by the samples of the run.  Round 3, end of round = the tile-local record layout, the backward over the list of
-# samples in front of the compositor's early stop (143.5 k samples/step in these passes, ~ 2/3 of them listed):
-#   binned backward, Adam fused (one GPU):  fill 2 x 21.8 + 33.3 MB, reduce 2 x 117.1 + 149.3 MB = 460.4 MB per launch, of
-#     which 292.7 MB are the optimiser state (24 B x 12.2 M table entries, independent of the samples) -> 1 169 B/sample +
-#     292.7 MB (before the list: 1 677 B/sample; round 2, global bins: 723 B/sample -- the reduce collects ~ 20-record runs
-#     and fetches their partial lines)
-#   binned backward, gradient written (data parallel / --no-fuse-adam): fill 76.6 MB + reduce 2 x 40.8 + 47.6 MB = 205.9 MB
-#     -> 1 435 B/sample (the separate Adam launch, 2 x 95.4 + 143.1 MB, is not part of the probed entry point)
-#   slab forward: 60.5 + 25.7 MB = 86.2 MB per launch -> 601 B/sample (gathers of 8 / 16 bytes, counted as reported)
+# steady state (tools/pmc_bench.sh, profiles/r04_pmc_bench_traffic.csv: last 30 steps before iteration 5000, 140.4 k samples
+# per step, --no-graph; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950 -- full-line reads are tallied at
+# 64 B).  Counters cannot be read while this script times itself, so the per-sample figures are carried as constants and
+# scaled by the samples of the run.  Round 4 (tile-local records, pair records on the hashed levels, backward over the list
+# of samples in front of the compositor's early stop):
+#   binned backward, Adam fused (one GPU):  fill 2 x 24.1 + 51.0 MB, reduce 2 x 129.7 + 149.6 MB = 508.2 MB per launch, of
+#     which 292.7 MB are the optimiser state (24 B x 12.2 M table entries, independent of the samples) -> 1 535 B/sample +
+#     292.7 MB (round 3: 1 169 B/sample at 143.5 k samples; round 2, global bins: 723 B/sample)
+#   binned backward, gradient written (data parallel / --no-fuse-adam; round 3's pass): fill 76.6 MB + reduce 2 x 40.8 + 47.6
+#     MB = 205.9 MB -> 1 435 B/sample (the separate Adam launch, 2 x 95.4 + 143.1 MB, is not part of the probed entry point)
+#   slab forward: 59.6 + 25.4 MB = 85.0 MB per launch -> 605 B/sample (gathers of 8 / 16 bytes, counted as reported)
 PMC_TRAFFIC_BYTES_PER_SAMPLE = {"ngp_x_grid_backward_binned": 1435.0}
-PMC_FUSED_TRAFFIC_BYTES_PER_SAMPLE = 1169.0
-PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 601.0
+PMC_FUSED_TRAFFIC_BYTES_PER_SAMPLE = 1535.0
+PMC_FWD_TRAFFIC_BYTES_PER_SAMPLE = 605.0
 FWD_BYTES_PER_SAMPLE = 12 + 16 * (64 + 8)      # 1164 B/sample, SURVEY.md section 8d
 # What the forward's ADDRESS STREAM can reach with the arithmetic taken away: tools/ubench/gather_lines.hip issues exactly the
 # slab forward's loads (same table, same ray-ordered samples, same level -> XCD placement) and nothing else.  Best variant
@@ -525,7 +524,7 @@ def main():
             roof = {"bound": "hbm", "kernel": args.roofline_kernel + (" + Adam on the table (fused)" if fused_adam else ""),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_source": ("FETCH_SIZE + WRITE_SIZE measured on this script's steady state (profiles/r03_pmc_bench_"
+                    "traffic_source": ("FETCH_SIZE + WRITE_SIZE measured on this script's steady state (profiles/r04_pmc_bench_"
                                        "traffic.csv), per-sample part scaled to this run's samples"
                                        + (", plus the optimiser's 24 B per table entry" if fused_adam else "")),
                     "launches": launches, "timed": f"probe tail after the timed region and the PSNR evaluation, one step in "
