@@ -340,12 +340,12 @@ int ngp_x_mlp_prepare(const float *w1, const float *w2, const float *w3, const f
 /* sigma [M], rgb [M,3]; rgb == NULL (then dirs may be NULL too) evaluates the density only */
 int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
                       const void *image, float *sigma, float *rgb, ngp_stream_t stream);
-/* ... with the field's other output activations (nerf/network.py:111-135): color_act 0 = clamp(exp(x - 5), max 5) (the
- * default above), 1 = exp(x - 5), 2 = sigmoid; density_act 0 = trunc_exp (default), 1 = softplus(beta, threshold 20).  The
- * hidden layers stay ReLU (internal_activation softplus runs on the per-op path). */
+/* ... with the field's other activations (nerf/network.py:31-34,111-135): color_act 0 = clamp(exp(x - 5), max 5) (the
+ * default above), 1 = exp(x - 5), 2 = sigmoid; density_act 0 = trunc_exp (default), 1 = softplus(beta, threshold 20);
+ * internal_act 0 = ReLU hidden layers (default), 1 = softplus(beta, threshold 20) (opt.internal_activation). */
 int ngp_x_mlp_forward_act(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
-                          const void *image, float *sigma, float *rgb, uint32_t color_act, uint32_t density_act, float beta,
-                          ngp_stream_t stream);
+                          const void *image, float *sigma, float *rgb, uint32_t color_act, uint32_t density_act,
+                          uint32_t internal_act, float beta, ngp_stream_t stream);
 
 /* Backward of the fused field.  dsigma [M], drgb [M,3] = dL/d(sigma, rgb); outputs d(enc) in the slab
  * layout of `enc` (rows >= M untouched) and the six weight gradients (fp32, torch layout, OVERWRITTEN).
@@ -386,12 +386,13 @@ int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const float *dirs
                             const void *image, float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2,
                             float *dw3, float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
                             float *loss_scaler, ngp_stream_t stream);
-/* ... with the output activations of ngp_x_mlp_forward_act: their derivatives enter the output deltas */
+/* ... with the activations of ngp_x_mlp_forward_act: their derivatives enter the deltas (hidden softplus: sigmoid(beta x)
+ * recovered from the recomputed activation as 1 - exp(-beta softplus(x))) */
 int ngp_x_mlp_backward_act(const float *enc, uint32_t stride, const float *dirs, const float *dsigma, const float *drgb,
                            const int32_t *M_dev, uint32_t M, const int32_t *sample_index, const void *image, float loss_scale,
                            float *denc, float *ddirs, float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6,
                            void *workspace, size_t workspace_bytes, float *loss_scaler, uint32_t color_act,
-                           uint32_t density_act, float beta, ngp_stream_t stream);
+                           uint32_t density_act, uint32_t internal_act, float beta, ngp_stream_t stream);
 /* d h0 / d enc for samples 0 .. M - 1 (level-major slab like `enc`), h0 = the density network's first output, sigma =
  * trunc_exp(h0) (nerf/network.py:111-118): the MLP's part of torch.autograd.grad(sigma, pos) in the orientation term
  * (nerf/renderer.py:558-566).  The f16 chain of the backward's density kernel with delta = e_0; no weight gradients. */

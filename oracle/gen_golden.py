@@ -446,10 +446,13 @@ def main():
             return sh16(d)
 
     # (the plain field also with the reference's other OUTPUT activations, network.py:115,131-135: softplus density with
-    # beta = 2, exp and sigmoid colour -- what ngp_x_mlp_forward_act / ngp_x_mlp_backward_act implement)
+    # beta = 2, exp and sigmoid colour, and softplus HIDDEN layers (network.py:31-34) -- what ngp_x_mlp_forward_act /
+    # ngp_x_mlp_backward_act implement)
     for tag, rfield, acts in (("plain", False, {}), ("rfield", True, {}),
                               ("plain_exp_softplus", False, dict(color_activation="exp", density_activation="softplus", beta=2.0)),
-                              ("plain_sigmoid", False, dict(color_activation="sigmoid"))):
+                              ("plain_sigmoid", False, dict(color_activation="sigmoid")),
+                              ("plain_softplus_hidden", False, dict(internal_activation="softplus", density_activation="softplus",
+                                                                   beta=2.0))):
         fopt = types.SimpleNamespace(**{**base, "rfield": rfield, "pose_opt": "none", **acts})
         torch.manual_seed(3 if rfield else 2)
         net = NW.NeRFNetwork(fopt)

@@ -61,9 +61,9 @@ _SIGNATURES = {
     "ngp_x_grid_encode_forward_jac": [_p, _p, _p, _p, _u, _u, _u, _u, _u, _f, _u, _p, _u, _i, _u, _i],
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
-    "ngp_x_mlp_forward_act": [_p, _u, _p, _p, _u, _p, _p, _p, _u, _u, _f],
+    "ngp_x_mlp_forward_act": [_p, _u, _p, _p, _u, _p, _p, _p, _u, _u, _u, _f],
     "ngp_x_mlp_backward_act": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t,
-                               _p, _u, _u, _f],
+                               _p, _u, _u, _u, _f],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_mlp_backward_dirs": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
     "ngp_x_mlp_backward_list": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t,
@@ -663,11 +663,17 @@ class _RayBackend:
 
 
 def field_activations(opt):
-    """(color_act, density_act, beta) of an options object for the fused MLP kernels, or None for a configuration they do not
-    implement (network.py:111-135: colour clamped_exp / exp / sigmoid, density clamped_exp (= trunc_exp) / softplus)."""
+    """(color_act, density_act, beta, internal_act) of an options object for the fused MLP kernels, or None for a configuration
+    they do not implement (network.py:31-34,111-135: colour clamped_exp / exp / sigmoid, density clamped_exp (= trunc_exp) /
+    softplus, hidden layers relu / softplus)."""
     color = {"clamped_exp": 0, "exp": 1, "sigmoid": 2}.get(getattr(opt, "color_activation", "clamped_exp"))
     density = 0 if getattr(opt, "density_activation", "clamped_exp") == "clamped_exp" else 1
-    return None if color is None else (color, density, float(getattr(opt, "beta", 1.0)))
+    internal = {"relu": 0, "softplus": 1}.get(getattr(opt, "internal_activation", "relu"))
+    return None if color is None or internal is None else (color, density, float(getattr(opt, "beta", 1.0)), internal)
+
+
+def _default_act(act):
+    return act is None or (tuple(act[:2]) == (0, 0) and (len(act) < 4 or act[3] == 0))
 
 
 class _MlpBackend:
@@ -688,13 +694,14 @@ class _MlpBackend:
         """step_begin = (step_counter, hyper, lr0, decay_steps, beta1, beta2, loss_out, samples_seen, sample_counter,
         binned_workspace, L, n_rows_total, single_segment), the arguments of engine_backend.step_begin: that bookkeeping
         rides along as one more workgroup of this launch (ngp_x_mlp_forward_step_begin).
-        act = (color_act, density_act, beta): the field's non-default output activations (field_activations())."""
+        act = (color_act, density_act, beta[, internal_act]): the field's non-default activations (field_activations())."""
         args = [_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs", True), _ptr(M_dev, "i", "M_dev", True), M,
                 image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb", True)]
-        if act is not None and tuple(act[:2]) != (0, 0):
+        if not _default_act(act):
             if step_begin is not None:
                 raise RuntimeError("mlp forward: the step_begin passenger rides on the default activations only")
-            _call("ngp_x_mlp_forward_act", enc, *args, int(act[0]), int(act[1]), float(act[2]), probe_as="ngp_x_mlp_forward")
+            _call("ngp_x_mlp_forward_act", enc, *args, int(act[0]), int(act[1]), int(act[3]) if len(act) > 3 else 0,
+                  float(act[2]), probe_as="ngp_x_mlp_forward")
             return
         if step_begin is None:
             _call("ngp_x_mlp_forward", enc, *args)
@@ -728,10 +735,10 @@ class _MlpBackend:
         grads = [_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)] if dws is not None else [None] * 6
         head = (_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs"), _ptr(dsigma, "f", "dsigma"), _ptr(drgb, "f", "drgb"),
                 _ptr(M_dev, "i", "M_dev", True), M, image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"))
-        if act is not None and tuple(act[:2]) != (0, 0):        # the field's non-default output activations
+        if not _default_act(act):                               # the field's non-default activations
             _call("ngp_x_mlp_backward_act", enc, *head[:7], _ptr(sample_index, "i", "sample_index", True), *head[7:],
                   _ptr(ddirs, "f", "ddirs", True), *grads, ws.data_ptr(), nbytes, _scaler_ptr(scaler), int(act[0]), int(act[1]),
-                  float(act[2]), probe_as="ngp_x_mlp_backward")
+                  int(act[3]) if len(act) > 3 else 0, float(act[2]), probe_as="ngp_x_mlp_backward")
         elif sample_index is not None or scaler is not None:
             _call("ngp_x_mlp_backward_list", enc, *head[:7], _ptr(sample_index, "i", "sample_index", True), *head[7:],
                   _ptr(ddirs, "f", "ddirs", True), *grads, ws.data_ptr(), nbytes, _scaler_ptr(scaler))

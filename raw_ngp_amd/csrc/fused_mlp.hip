@@ -93,7 +93,7 @@ __device__ __forceinline__ TileIn load_tile(const float *__restrict__ enc, size_
 #define NGP_FWD_WG_PER_CU 3
 #endif
 constexpr uint32_t kFwdWgPerCu = NGP_FWD_WG_PER_CU;   // workgroups (4 waves) per CU the kernel is compiled and launched for
-template <bool PASSENGER>
+template <bool PASSENGER, bool SOFT = false>
 __global__ __launch_bounds__(256, kFwdWgPerCu) void mlp_forward_kernel(const float *__restrict__ enc, uint32_t stride,
                                                             const float *__restrict__ dirs,
                                                             const int32_t *__restrict__ M_dev, uint32_t M_host,
@@ -140,15 +140,15 @@ __global__ __launch_bounds__(256, kFwdWgPerCu) void mlp_forward_kernel(const flo
         }
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            x[kb][0] = pack<0, true>(a[kb]);
-            x[kb][1] = pack<1, true>(a[kb]);
+            x[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            x[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
         // layer 2: 64 -> 64
         NGP_LAYER64_LDS(a, lds_w, L_W2, x);
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            x[kb][0] = pack<0, true>(a[kb]);
-            x[kb][1] = pack<1, true>(a[kb]);
+            x[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            x[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
         // layer 3: 64 -> 16 (rows 0..15 of one tile): row 0 = raw density, rows 1..15 = geometry features
         f32x16 o = zero16();
@@ -171,15 +171,15 @@ __global__ __launch_bounds__(256, kFwdWgPerCu) void mlp_forward_kernel(const flo
         }
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            x[kb][0] = pack<0, true>(a[kb]);
-            x[kb][1] = pack<1, true>(a[kb]);
+            x[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            x[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
         // layer 5: 64 -> 64
         NGP_LAYER64_LDS(a, lds_w, L_W5, x);
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            x[kb][0] = pack<0, true>(a[kb]);
-            x[kb][1] = pack<1, true>(a[kb]);
+            x[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            x[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
         // layer 6: 64 -> 3
         f32x16 c = zero16();
@@ -218,26 +218,31 @@ extern "C" int ngp_x_mlp_prepare(const float *w1, const float *w2, const float *
 extern "C" int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
                                  const void *image, float *sigma, float *rgb, ngp_stream_t stream)
 {
-    return ngp_x_mlp_forward_act(enc, stride, dirs, M_dev, M, image, sigma, rgb, 0, 0, 1.0f, stream);
+    return ngp_x_mlp_forward_act(enc, stride, dirs, M_dev, M, image, sigma, rgb, 0, 0, 0, 1.0f, stream);
 }
 
 // ... with the field's non-default output activations (network.py:111-135): color_act 0 clamped_exp / 1 exp / 2 sigmoid,
 // density_act 0 trunc_exp / 1 softplus(beta, threshold 20)
 extern "C" int ngp_x_mlp_forward_act(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
                                      const void *image, float *sigma, float *rgb, uint32_t color_act, uint32_t density_act,
-                                     float beta, ngp_stream_t stream)
+                                     uint32_t internal_act, float beta, ngp_stream_t stream)
 {
     if (M == 0) return NGP_OK;
-    NGP_REQUIRE(color_act <= 2u && density_act <= 1u && beta > 0.0f, "mlp_forward: unknown activation or beta <= 0");
+    NGP_REQUIRE(color_act <= 2u && density_act <= 1u && internal_act <= 1u && beta > 0.0f,
+                "mlp_forward: unknown activation or beta <= 0");
     NGP_REQUIRE(enc && image && sigma, "mlp_forward: null tensor");
     NGP_REQUIRE(rgb == nullptr || dirs != nullptr, "mlp_forward: dirs missing");
     NGP_REQUIRE(stride >= M, "mlp_forward: encoder slab stride smaller than M");
     const uint32_t tiles = ceil_div(M, 32u);
     const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * kFwdWgPerCu);
     FieldAct act;
-    act.color = color_act, act.density = density_act, act.beta = beta;
-    mlp_forward_kernel<false><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(
-        enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, StepBegin{}, act);
+    act.color = color_act, act.density = density_act, act.beta = beta, act.internal = internal_act;
+    if (internal_act)
+        mlp_forward_kernel<false, true><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(
+            enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, StepBegin{}, act);
+    else
+        mlp_forward_kernel<false><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(
+            enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, StepBegin{}, act);
     NGP_CHECK_LAUNCH("mlp_forward");
     return NGP_OK;
 }

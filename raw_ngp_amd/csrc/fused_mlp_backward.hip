@@ -149,19 +149,6 @@ __device__ __forceinline__ TileInB<WANT_SH> convert_raw(const RawTile &r, uint32
     return in;
 }
 
-// registers 8S..8S+7 of `a`, zeroed where the matching post-ReLU activation (same tile, same k-step) is 0
-template <int S>
-__device__ __forceinline__ half8 pack_masked(const f32x16 &a, const half8 &act, _Float16 lim)
-{
-    // mask = all ones where act > 0, built with packed 16-bit integer ops on the f16 bit patterns (a positive f16 is
-    // a positive int16; -0 is negative): clamp to {0, 1}, multiply by 0xffff
-    typedef short short8 __attribute__((ext_vector_type(8)));
-    const half8 o = pack_sat<S>(a, lim);   // static loss scale: deltas saturate instead of overflowing (mlp_common.hpp)
-    short8 m = __builtin_bit_cast(short8, act);
-    m = __builtin_elementwise_min(__builtin_elementwise_max(m, (short8)0), (short8)1) * (short8)-1;
-    return __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, o) & m));
-}
-
 __device__ __forceinline__ half8 identity_frag(uint32_t s, uint32_t lane)
 {
     const uint32_t j = lane & 31u, h = lane >> 5;
@@ -216,7 +203,7 @@ __device__ unsigned long long ngp_dbg_stamps[16];
 // DDIRS: also d loss / d (un-normalised view direction) [M,3] -- pose refinement without the light-conditioned field: the
 // gradient with respect to the SH features is rows 16..31 of d x3; the SH Jacobian and the tangent projection of d / |d|
 // follow as in fused_mlp_rf.hip
-template <bool DDIRS>
+template <bool DDIRS, bool SOFT = false>
 __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
     const float *__restrict__ enc, uint32_t stride, const float *__restrict__ dirs, const float *__restrict__ dsigma,
     const float *__restrict__ drgb, const int32_t *__restrict__ M_dev, uint32_t M_host,
@@ -289,8 +276,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
         }
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            x[kb][0] = pack<0, true>(a[kb]);
-            x[kb][1] = pack<1, true>(a[kb]);
+            x[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            x[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
@@ -302,8 +289,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
         }
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            x[kb][0] = pack<0, true>(a[kb]);
-            x[kb][1] = pack<1, true>(a[kb]);
+            x[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            x[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
         f32x16 o = zero16();
 #pragma unroll
@@ -320,8 +307,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
         }
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            h3[kb][0] = pack<0, true>(a[kb]);
-            h3[kb][1] = pack<1, true>(a[kb]);
+            h3[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            h3[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
@@ -333,8 +320,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
         }
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            h4[kb][0] = pack<0, true>(a[kb]);
-            h4[kb][1] = pack<1, true>(a[kb]);
+            h4[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            h4[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
         f32x16 c = zero16();
 #pragma unroll
@@ -373,8 +360,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
             const f32x16 dh = mfma(NGP_FRAG(T_W6 + rb), p6, zero16());
-            p5[rb][0] = pack_masked<0>(dh, h4[rb][0], lim);
-            p5[rb][1] = pack_masked<1>(dh, h4[rb][1], lim);
+            p5[rb][0] = pack_delta<0, SOFT>(dh, h4[rb][0], lim, act.beta);
+            p5[rb][1] = pack_delta<1, SOFT>(dh, h4[rb][1], lim, act.beta);
         }
         NGP_STAMP_AT(3);      // deltas 6, dW6, delta 5
         // ---------------- layer 5: dW5 = delta5 x H3^T ; delta4 = W5^T delta5 (masked)
@@ -406,8 +393,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int s = 0; s < 2; s++) dh = mfma(NGP_FRAG(T_W5 + rb * 4 + kb * 2 + s), p5[kb][s], dh);
-            p4[rb][0] = pack_masked<0>(dh, h3[rb][0], lim);
-            p4[rb][1] = pack_masked<1>(dh, h3[rb][1], lim);
+            p4[rb][0] = pack_delta<0, SOFT>(dh, h3[rb][0], lim, act.beta);
+            p4[rb][1] = pack_delta<1, SOFT>(dh, h3[rb][1], lim, act.beta);
         }
         NGP_STAMP_AT(4);      // dW5, delta 4
         // ---------------- layer 4: dW4 = delta4 x X3^T ; dX3 = W4^T delta4
@@ -481,12 +468,12 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_view_kernel(
 // weight then scales d enc
 // UNIT: delta3 = e_0 for every sample instead of the view kernel's (d3buf NULL) and no weight gradients: d enc is then
 // d h0 / d enc, the gradient of the density network's first output (sigma = trunc_exp(h0)) -- ngp_x_mlp_density_gradient
-template <bool WINDOW, bool UNIT = false>
+template <bool WINDOW, bool UNIT = false, bool SOFT = false>
 __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
     const float *__restrict__ enc, uint32_t stride, const int32_t *__restrict__ M_dev, uint32_t M_host,
     const half8 *__restrict__ image, float inv_loss_scale_host, const half8 *__restrict__ d3buf,
     float *__restrict__ denc, float *__restrict__ partial, const float *__restrict__ level_w, uint32_t t3_base,
-    const int32_t *__restrict__ live_idx, const float *__restrict__ scaler)
+    const int32_t *__restrict__ live_idx, const float *__restrict__ scaler, FieldAct act)
 {
     extern __shared__ half8 lds_w[];   // local 0..11 = F_W1, F_W2 ; 12..25 = T_W3, T_W2, T_W1
     const float inv_loss_scale = scaler ? scaler[LS_INV] : inv_loss_scale_host;   // (see the view kernel)
@@ -568,8 +555,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
         }
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            h1[kb][0] = pack<0, true>(a[kb]);
-            h1[kb][1] = pack<1, true>(a[kb]);
+            h1[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            h1[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
@@ -581,8 +568,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
         }
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            h2[kb][0] = pack<0, true>(a[kb]);
-            h2[kb][1] = pack<1, true>(a[kb]);
+            h2[kb][0] = pack_hidden<0, SOFT>(a[kb], act.beta);
+            h2[kb][1] = pack_hidden<1, SOFT>(a[kb], act.beta);
         }
 
         half8 aT[2], bT[2];
@@ -604,8 +591,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
             const f32x16 dh = mfma(NGP_FRAG(LT_W3 + rb), p3, zero16());
-            p2[rb][0] = pack_masked<0>(dh, h2[rb][0], lim);
-            p2[rb][1] = pack_masked<1>(dh, h2[rb][1], lim);
+            p2[rb][0] = pack_delta<0, SOFT>(dh, h2[rb][0], lim, act.beta);
+            p2[rb][1] = pack_delta<1, SOFT>(dh, h2[rb][1], lim, act.beta);
         }
         // ---------------- layer 2: dW2 = delta2 x H1^T ; delta1 = W2^T delta2 (masked)
         if constexpr (!UNIT) {
@@ -636,8 +623,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_grid_kernel(
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int s = 0; s < 2; s++) dh = mfma(NGP_FRAG(LT_W2 + rb * 4 + kb * 2 + s), p2[kb][s], dh);
-            p1[rb][0] = pack_masked<0>(dh, h1[rb][0], lim);
-            p1[rb][1] = pack_masked<1>(dh, h1[rb][1], lim);
+            p1[rb][0] = pack_delta<0, SOFT>(dh, h1[rb][0], lim, act.beta);
+            p1[rb][1] = pack_delta<1, SOFT>(dh, h1[rb][1], lim, act.beta);
         }
         // ---------------- layer 1: dW1 = delta1 x X0^T ; d enc = W1^T delta1
         if constexpr (!UNIT) {
@@ -712,6 +699,12 @@ static bool mlp_backward_lds_ok()
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
         r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<true, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
+        r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_grid_kernel<false, false, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds) == hipSuccess;
+        r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_view_kernel<false, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kViewLds) == hipSuccess;
+        r = r && hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_view_kernel<true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kViewLds) == hipSuccess;
         return r;
     }();
     return ok;
@@ -720,17 +713,21 @@ static bool mlp_backward_lds_ok()
 int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
                              const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
                              float *partial, uint32_t blocks, hipStream_t st, const int32_t *sample_index,
-                             const float *scaler)
+                             const float *scaler, FieldAct act)
 {
     NGP_REQUIRE(mlp_backward_lds_ok(), "mlp_backward_grid: cannot raise the dynamic LDS limit");
-    if (level_w)
+    NGP_REQUIRE(!(level_w && act.internal), "mlp_backward_grid: the level window comes with ReLU hidden layers only");
+    if (act.internal)
+        mlp_backward_grid_kernel<false, false, true><<<dim3(blocks), dim3(256), kGridLds, st>>>(
+            enc, stride, M_dev, M, image, inv_loss_scale, d3buf, denc, partial, nullptr, t3_base, sample_index, scaler, act);
+    else if (level_w)
         mlp_backward_grid_kernel<true><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
                                                                                   d3buf, denc, partial, level_w, t3_base,
-                                                                                  sample_index, scaler);
+                                                                                  sample_index, scaler, act);
     else
         mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, image, inv_loss_scale,
                                                                                    d3buf, denc, partial, nullptr, t3_base,
-                                                                                   sample_index, scaler);
+                                                                                   sample_index, scaler, act);
     NGP_CHECK_LAUNCH("mlp_backward_grid");
     return NGP_OK;
 }
@@ -814,7 +811,7 @@ extern "C" int ngp_x_mlp_backward_list(const float *enc, uint32_t stride, const 
                                        size_t workspace_bytes, float *loss_scaler, ngp_stream_t stream)
 {
     return ngp_x_mlp_backward_act(enc, stride, dirs, dsigma, drgb, M_dev, M, sample_index, image, loss_scale, denc, ddirs, dw1,
-                                  dw2, dw3, dw4, dw5, dw6, workspace, workspace_bytes, loss_scaler, 0, 0, 1.0f, stream);
+                                  dw2, dw3, dw4, dw5, dw6, workspace, workspace_bytes, loss_scaler, 0, 0, 0, 1.0f, stream);
 }
 
 // ... with the field's non-default output activations (as ngp_x_mlp_forward_act)
@@ -823,11 +820,12 @@ extern "C" int ngp_x_mlp_backward_act(const float *enc, uint32_t stride, const f
                                       const void *image, float loss_scale, float *denc, float *ddirs, float *dw1,
                                       float *dw2, float *dw3, float *dw4, float *dw5, float *dw6, void *workspace,
                                       size_t workspace_bytes, float *loss_scaler, uint32_t color_act, uint32_t density_act,
-                                      float beta, ngp_stream_t stream)
+                                      uint32_t internal_act, float beta, ngp_stream_t stream)
 {
-    NGP_REQUIRE(color_act <= 2u && density_act <= 1u && beta > 0.0f, "mlp_backward: unknown activation or beta <= 0");
+    NGP_REQUIRE(color_act <= 2u && density_act <= 1u && internal_act <= 1u && beta > 0.0f,
+                "mlp_backward: unknown activation or beta <= 0");
     FieldAct act;
-    act.color = color_act, act.density = density_act, act.beta = beta;
+    act.color = color_act, act.density = density_act, act.beta = beta, act.internal = internal_act;
     const bool reduce_now = dw1 != nullptr;   // all NULL: leave the per-workgroup partials for ngp_x_mlp_reduce_dw
     NGP_REQUIRE(image && workspace, "mlp_backward: null tensor");
     NGP_REQUIRE(reduce_now ? (dw2 && dw3 && dw4 && dw5 && dw6) : (!dw2 && !dw3 && !dw4 && !dw5 && !dw6),
@@ -844,17 +842,21 @@ extern "C" int ngp_x_mlp_backward_act(const float *enc, uint32_t stride, const f
     float *part_view = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (((size_t)M * 32 + 255) & ~(size_t)255));
     float *part_grid = part_view + (size_t)256 * kAccFloats;
     const half8 *img = reinterpret_cast<const half8 *>(image);
-    if (ddirs)
-        mlp_backward_view_kernel<true><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M, img,
-                                                                                  loss_scale, d3buf, part_view, ddirs,
-                                                                                  sample_index, loss_scaler, act);
+#define NGP_VIEW_ARGS enc, stride, dirs, dsigma, drgb, M_dev, M, img, loss_scale, d3buf, part_view, ddirs, sample_index, loss_scaler, act
+    if (ddirs && act.internal)
+        mlp_backward_view_kernel<true, true><<<dim3(blocks), dim3(256), kViewLds, st>>>(NGP_VIEW_ARGS);
+    else if (ddirs)
+        mlp_backward_view_kernel<true><<<dim3(blocks), dim3(256), kViewLds, st>>>(NGP_VIEW_ARGS);
+    else if (act.internal)
+        mlp_backward_view_kernel<false, true><<<dim3(blocks), dim3(256), kViewLds, st>>>(NGP_VIEW_ARGS);
     else
-        mlp_backward_view_kernel<false><<<dim3(blocks), dim3(256), kViewLds, st>>>(enc, stride, dirs, dsigma, drgb, M_dev, M,
-                                                                                   img, loss_scale, d3buf, part_view, nullptr,
-                                                                                   sample_index, loss_scaler, act);
-    mlp_backward_grid_kernel<false><<<dim3(blocks), dim3(256), kGridLds, st>>>(enc, stride, M_dev, M, img, 1.0f / loss_scale,
-                                                                               d3buf, denc, part_grid, nullptr, T_W3,
-                                                                               sample_index, loss_scaler);
+        mlp_backward_view_kernel<false><<<dim3(blocks), dim3(256), kViewLds, st>>>(NGP_VIEW_ARGS);
+#undef NGP_VIEW_ARGS
+    {
+        const int rc = launch_mlp_backward_grid(enc, stride, nullptr, M_dev, M, img, T_W3, 1.0f / loss_scale, d3buf, denc, part_grid,
+                                                blocks, st, sample_index, loss_scaler, act);
+        if (rc != NGP_OK) return rc;
+    }
     if (reduce_now)
         mlp_reduce_dw_kernel<<<dim3(kDwGroups), dim3(256), 0, st>>>(
             MlpDwReduce{part_view, part_grid, blocks, 1.0f / loss_scale, dw1, dw2, dw3, dw4, dw5, dw6, MlpAdam{}, loss_scaler});
@@ -876,11 +878,11 @@ int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stri
     if (level_w)    // the window scales the features in front of the network and, as its adjoint, d enc behind it
         mlp_backward_grid_kernel<true, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, st>>>(
             enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, level_w, t3_base,
-            nullptr, nullptr);
+            nullptr, nullptr, FieldAct{});
     else
         mlp_backward_grid_kernel<false, true><<<dim3(mlp_bwd_blocks(M)), dim3(256), kGridLds, st>>>(
             enc, stride, M_dev, M, reinterpret_cast<const half8 *>(image), 1.0f, nullptr, denc, nullptr, nullptr, t3_base,
-            nullptr, nullptr);
+            nullptr, nullptr, FieldAct{});
     NGP_CHECK_LAUNCH(who);
     return NGP_OK;
 }

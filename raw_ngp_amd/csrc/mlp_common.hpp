@@ -104,10 +104,51 @@ struct MlpWeights {
 // ---- output activations of the field (nerf/network.py:111-135 of the reference) ------------------------------------------
 // density: 0 = trunc_exp (exp forward, exp(clamp(x, -80?, 80)) backward: activation.py; `clamped_exp`, the default),
 //          1 = softplus(beta, threshold 20);   colour: 0 = clamp(exp(x - 5), max 5) (default), 1 = exp(x - 5), 2 = sigmoid
+//          hidden layers (`internal`): 0 = ReLU (default), 1 = softplus(beta, threshold 20)   (network.py:31-34)
 struct FieldAct {
     uint32_t color = 0, density = 0;
     float beta = 1.0f;
+    uint32_t internal = 0;
 };
+// hidden activation of registers 8S..8S+7 of an accumulator tile, as an f16 operand fragment.  SOFT: F.softplus(x, beta,
+// threshold 20) evaluated in f32 before the conversion (the ReLU form clamps after it: four packed ops)
+template <int S, bool SOFT>
+__device__ __forceinline__ half8 pack_hidden(const f32x16 &a, float beta)
+{
+    if constexpr (!SOFT) {
+        return pack<S, true>(a);
+    } else {
+        half8 o;
+        const float inv = 1.0f / beta;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const float x = a[8 * S + t], z = beta * x;
+            o[t] = (_Float16)(z > 20.0f ? x : log1pf(__expf(z)) * inv);
+        }
+        return o;
+    }
+}
+// delta through a hidden activation: registers 8S..8S+7 of `a` times the activation's derivative, taken from the matching
+// post-activation fragment `act` -- ReLU: zero where act is 0 (a bit mask); softplus: sigmoid(beta x) = 1 - exp(-beta
+// softplus(x)) (1 in the linear region, where exp(-beta x) < 2e-9) -- then the saturating conversion of pack_sat
+template <int S, bool SOFT>
+__device__ __forceinline__ half8 pack_delta(const f32x16 &a, const half8 &act, _Float16 lim, float beta)
+{
+    if constexpr (!SOFT) {
+        // mask = all ones where act > 0, built with packed 16-bit integer ops on the f16 bit patterns (a positive f16 is
+        // a positive int16; -0 is negative): clamp to {0, 1}, multiply by 0xffff
+        typedef short short8 __attribute__((ext_vector_type(8)));
+        const half8 o = pack_sat<S>(a, lim);
+        short8 m = __builtin_bit_cast(short8, act);
+        m = __builtin_elementwise_min(__builtin_elementwise_max(m, (short8)0), (short8)1) * (short8)-1;
+        return __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, o) & m));
+    } else {
+        f32x16 d = a;
+#pragma unroll
+        for (int t = 0; t < 8; t++) d[8 * S + t] = a[8 * S + t] * (1.0f - __expf(-beta * (float)act[t]));
+        return pack_sat<S>(d, lim);
+    }
+}
 __device__ __forceinline__ float act_sigma(float h, const FieldAct &a)
 {
     if (a.density == 0u) return __expf(h);
@@ -264,7 +305,7 @@ constexpr size_t flush_lds_bytes(int NT) { return (size_t)4 * ((NT + 1) / 2) * 4
 int launch_mlp_backward_grid(const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev, uint32_t M,
                              const half8 *image, uint32_t t3_base, float inv_loss_scale, const half8 *d3buf, float *denc,
                              float *partial, uint32_t blocks, hipStream_t st, const int32_t *sample_index = nullptr,
-                             const float *scaler = nullptr);
+                             const float *scaler = nullptr, FieldAct act = FieldAct{});
 // ... with a unit delta on the first output and no weight gradients: denc <- d h0 / d enc (ngp_x_mlp_density_gradient)
 int launch_mlp_density_gradient(const char *who, const float *enc, uint32_t stride, const float *level_w, const int32_t *M_dev,
                                 uint32_t M, const void *image, uint32_t t3_base, float *denc, hipStream_t st);

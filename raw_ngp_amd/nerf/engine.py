@@ -94,11 +94,12 @@ class FusedTrainer:
         assert model._fused(), "fused step needs the default field configuration"
         self.mb = mb = _mlp_rf if self.rfield else _mlp_plain
         # the field's output activations (network.py:115,131-135); None = the defaults (trunc_exp density, clamped_exp colour)
-        from .._lib import field_activations
+        from .._lib import field_activations, _default_act
         act = field_activations(opt)
-        self.act = act if act[:2] != (0, 0) else None
-        assert self.act is None or not (self.rfield or float(getattr(opt, "lambda_orientation", 0.0)) > 0), \
-            "fused step: softplus density / exp, sigmoid colour are built for the plain field without the orientation term"
+        self.act = None if _default_act(act) else act
+        assert self.act is None or not (self.rfield or self.pose or float(getattr(opt, "lambda_orientation", 0.0)) > 0), \
+            "fused step: softplus hidden layers / density, exp / sigmoid colour are built for the plain field without pose " \
+            "refinement and without the orientation term"
         self.rank, self.world_size = parallel.rank(), parallel.world_size()
         # data-parallel step (separate Adam pass, gradient collectives); `dp_rehearsal` runs it on one rank as well
         self.dp = self.world_size > 1 or (bool(getattr(opt, "dp_rehearsal", False)) and parallel.is_dist())

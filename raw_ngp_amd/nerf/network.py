@@ -129,17 +129,16 @@ class NeRFNetwork(NeRFRenderer):
 
     # -- fused MFMA path (extension; Options.fused_mlp) ------------------------------------------
     def _fused(self, plain_only=False):
-        """The field configuration the MFMA kernels implement: ReLU hidden layers; trunc_exp density and clamped_exp colour,
-        and -- for the plain field -- the reference's other OUTPUT activations (softplus density, exp / sigmoid colour:
-        network.py:115,131-135; internal_activation = softplus runs on the per-op path).
+        """The field configuration the MFMA kernels implement: ReLU hidden layers, trunc_exp density and clamped_exp colour, and
+        -- for the plain field -- the reference's other activations (softplus hidden layers / density, exp / sigmoid colour:
+        network.py:31-34,115,131-135).
         plain_only: additionally the 31-input view MLP without level windows -- what the autograd op `fused_field`
         covers; the light-conditioned / BARF variants exist for the fused training step only (nerf/engine.py)."""
-        from .._lib import field_activations
+        from .._lib import field_activations, _default_act
         o = self.opt
         act = field_activations(o)
-        default = act is not None and act[:2] == (0, 0)
-        ok = (getattr(o, "fused_mlp", False) and o.internal_activation == "relu" and act is not None
-              and (default or not o.rfield) and self.grid_encoder.embeddings.is_cuda)
+        ok = (getattr(o, "fused_mlp", False) and act is not None and (_default_act(act) or not o.rfield)
+              and self.grid_encoder.embeddings.is_cuda)
         if plain_only:
             ok = ok and not o.rfield and o.pose_opt == "none"
         return ok

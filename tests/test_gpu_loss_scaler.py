@@ -253,7 +253,8 @@ def test_kernels_read_the_scale_from_the_device_and_raise_the_overflow_word(lib,
 
 
 @pytest.mark.parametrize("acts", [dict(color_activation="exp", density_activation="softplus", beta=2.0),
-                                  dict(color_activation="sigmoid")], ids=["exp+softplus", "sigmoid"])
+                                  dict(color_activation="sigmoid"),
+                                  dict(internal_activation="softplus", beta=2.0)], ids=["exp+softplus", "sigmoid", "softplus-hidden"])
 def test_fused_step_with_the_other_output_activations_matches_the_per_op_path(lib, acts):
     """The reference's non-default OUTPUT activations (network.py:115,131-135) inside the fused step: loss and gradients of
     one batch against the per-op autograd path over fp32 nn.Linear MLPs with the same activations (torch's own softplus /

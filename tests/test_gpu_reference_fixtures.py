@@ -40,7 +40,7 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-@pytest.mark.parametrize("tag", ["plain", "rfield", "plain_exp_softplus", "plain_sigmoid"])
+@pytest.mark.parametrize("tag", ["plain", "rfield", "plain_exp_softplus", "plain_sigmoid", "plain_softplus_hidden"])
 def test_fused_field_matches_the_reference_network(golden_dir, tag):
     """The reference's NeRFNetwork.forward + autograd on CPU (oracle/gen_golden.py: its own MLP class and activations) against
     the fused MFMA kernels.  plain_exp_softplus / plain_sigmoid: the reference's other OUTPUT activations (network.py:115,
@@ -48,7 +48,8 @@ def test_fused_field_matches_the_reference_network(golden_dir, tag):
     from raw_ngp_amd import _lib
     g = np.load(os.path.join(golden_dir, f"field_{tag}.npz"))
     rf = tag == "rfield"
-    act = {"plain_exp_softplus": (1, 1, 2.0), "plain_sigmoid": (2, 0, 1.0)}.get(tag)
+    # (colour, density, beta, hidden layers): plain_softplus_hidden = internal_activation softplus (network.py:31-34) + softplus density
+    act = {"plain_exp_softplus": (1, 1, 2.0, 0), "plain_sigmoid": (2, 0, 1.0, 0), "plain_softplus_hidden": (0, 1, 2.0, 1)}.get(tag)
     mb = _lib.mlp_rf_backend if rf else _lib.mlp_backend
     W = [dev(g[f"w{i}"]) for i in range(1, 7)]
     assert tuple(W[3].shape) == ((80, 47) if rf else (64, 31))
