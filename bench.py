@@ -168,6 +168,7 @@ def run_config(args, bound, background, rank, world, dev, probe_on=True):
                   capture_graph=not args.no_graph, device_sampler=not args.torch_sampler,
                   aux_stream=args.aux, grad_wire=args.grad_wire, fuse_adam=not args.no_fuse_adam,
                   dp_rehearsal=args.dp_rehearsal, dp_exchange=args.dp_exchange, group_steps=args.group_steps,
+                  group_any=not args.group_pow2, group_ramp=not args.no_group_ramp,
                   dp_mode=args.dp_mode, dynamic_loss_scale=not args.static_loss_scale, dp_split_level=args.dp_split_level,
                   **({"loss_scale": args.loss_scale} if args.loss_scale else {}))
     data = SyntheticDataset(opt, dev, "train", n_views=args.views, H=args.res, W=args.res)
@@ -405,8 +406,11 @@ def main():
                          "region if needed; 0 = skip)")
     ap.add_argument("--arena", type=int, default=0, help="sample arena capacity (0 = reference two-pass march)")
     ap.add_argument("--torch-mlp", action="store_true", help="fp32 nn.Linear MLPs instead of the fused f16 MFMA field")
-    ap.add_argument("--group-steps", type=int, default=8,
+    ap.add_argument("--group-steps", type=int, default=15,
                     help="fused step: consecutive steps per captured graph (1 = one graph launch per step)")
+    ap.add_argument("--group-pow2", action="store_true", help="step groups of 2, 4, 8 steps only (default: any length up to --group-steps)")
+    ap.add_argument("--no-group-ramp", action="store_true",
+                    help="let the first group of a train() call be long too (default: at most 2 steps -- the stream may be idle)")
     ap.add_argument("--precapture", action="store_true", help="capture step groups of every length up front instead of 2/4/8 on demand")
     ap.add_argument("--probe-every", type=int, default=16,
                     help="probe tail: time every N-th launch of the roofline entry points with HIP events (16 = the step half way "

@@ -1210,7 +1210,7 @@ class FusedTrainer:
         return int(self.arena.counter[0])          # host read: only for logging
 
     # ------------------------------------------------------------------ several steps per graph
-    def _multi_step(self, limit):
+    def _multi_step(self, limit, first=False):
         """Run up to `limit` (and at most self.group_steps) consecutive regular steps from ONE captured graph; returns how
         many it ran (0: the caller takes a single train_step).  Between two graph launches the GPU idles for ~ 20 us (the
         replay floor of a dependent launch); a step is ~ 0.4 ms, so one launch per step costs 5 %.  A group never contains
@@ -1230,8 +1230,13 @@ class FusedTrainer:
         # (longer groups save launch boundaries, but a graph launch costs host time in proportion to its nodes, which is
         # exposed whenever the GPU has nothing queued -- e.g. at the start of a short timed region)
         G = min(G, int(getattr(opt, "group_steps", 8)))
-        if not self._groups_precaptured:           # 2, 4, 8: a handful of graph variants, all captured early in a run
-            G = 1 << (G.bit_length() - 1)          # (a capture takes milliseconds: none may fall into a timed region)
+        # (`group_ramp`: the FIRST group of a train() call is short -- the stream may be idle, e.g. right after a synchronise,
+        # and the host time of a long graph's launch would be idle GPU time; behind it the launches run ahead of the GPU)
+        if first and getattr(opt, "group_ramp", False):
+            G = min(G, 2)
+        if not self._groups_precaptured and not getattr(opt, "group_any", False):
+            G = 1 << (G.bit_length() - 1)          # 2, 4, 8: a handful of graph variants, all captured early in a run
+                                                   # (a capture takes milliseconds: none may fall into a timed region)
         last_ahead = (s + G) % every != 0          # does the group's last step draw the rays of the step after it?
         head = not last_ahead and self._refresh_head_ok()      # ... or the cells of the refresh that follows it?
         key = ("multi", s % 2, G, last_ahead, head)
@@ -1306,7 +1311,7 @@ class FusedTrainer:
     def train(self, steps, log_every=0):
         done = 0
         while done < steps:
-            n = 0 if log_every else self._multi_step(steps - done)
+            n = 0 if log_every else self._multi_step(steps - done, first=done == 0)
             if n == 0:
                 self.train_step()
                 n = 1

@@ -86,5 +86,9 @@ class Options:
     march_mode: str = "chain"     # fused engine, march pass 1: chain | index | serial (see engine.py)
     device_sampler: bool = True   # fused engine: draw ray batches with one kernel (Philox) instead of torch ops
     capture_graph: bool = True    # fused engine: replay whole steps from captured hipGraphs
-    group_steps: int = 8          # fused engine: consecutive regular steps replayed from ONE graph (1 = a graph per step)
+    group_steps: int = 15         # fused engine: consecutive regular steps replayed from ONE graph (1 = a graph per step): a
+                                  # graph boundary costs ~ 26 us of idle GPU; 15 = everything between two grid refreshes
+    group_any: bool = True        # ... of any length up to group_steps (False: 2, 4, 8 only -- fewer variants to capture)
+    group_ramp: bool = True       # ... but the first group of a train() call at most 2 steps long (an idle stream waits for
+                                  # the host while it launches a long graph)
     prefetch_march: bool = True   # fused engine: march step i+1's rays on a second stream during step i's backward
