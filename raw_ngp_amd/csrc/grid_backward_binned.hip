@@ -429,158 +429,175 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     __syncthreads();
     NGP_FILL_STAMP(1);   // (diagnostic build: the stamp waits for the loads -> phase 1 = header + loads)
 
-    uint32_t rows[8], pos[8];
-    float vx[8], vy[8];
-    Cell<3> cl = {};
-    const bool live = b < B && locate<3>(x, g.res, align_corners, interp, cl);
-    if (!live) gr = make_float2(0.0f, 0.0f);
-    const bool nan = !(gr.x == gr.x && gr.y == gr.y);
-    const bool active = live && (gr.x != 0.0f || gr.y != 0.0f);
-#pragma unroll
-    for (uint32_t corner = 0; corner < 8; corner++) vx[corner] = vy[corner] = 0.0f;
-    if (active) {
-#pragma unroll
-        for (uint32_t corner = 0; corner < 8; corner++) {
-            float wgt = 1.0f;
-#pragma unroll
-            for (uint32_t d = 0; d < 3; d++) wgt *= (corner & (1u << d)) ? cl.f[d] : 1.0f - cl.f[d];
-            vx[corner] = wgt * gr.x;
-            vy[corner] = wgt * gr.y;
+    // Two compilations of the rest of the kernel, picked per workgroup (the level is uniform): FAST = a hashed level whose
+    // table is a power of two with res <= 4096 -- the geometry's kind is then a compile-time fact (no per-corner branches on
+    // hashed / dense / modulo), and the x-neighbours of a corner pair always share a chunk (the PAIRS below); the generic
+    // one serves the dense levels and every other table.
+    const bool fast = g.hashed && g.mode == 1u && g.res <= kChunkRows && kPrimes[0] == 1u;
+    auto body = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        Geom<3> gk = g;
+        if constexpr (FAST) {
+            gk.hashed = true;
+            gk.mode = 1u;
         }
-    }
-    bool emit = active;
-    if (mergeable(g, w)) {   // run merging, as in bin_fill_kernel
-        uint32_t dist;
-        const bool tail_lane = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
-        const RunFlags flags = run_flags(dist);
-        const float active_in_run = run_sum(active ? 1.0f : 0.0f, flags);
-        emit = tail_lane && active_in_run > 0.0f;
-        if (__ballot(active) != 0ull) {
-#pragma unroll
+        uint32_t rows[8], pos[8];
+        float vx[8], vy[8];
+        Cell<3> cl = {};
+        const bool live = b < B && locate<3>(x, gk.res, align_corners, interp, cl);
+        if (!live) gr = make_float2(0.0f, 0.0f);
+        const bool nan = !(gr.x == gr.x && gr.y == gr.y);
+        const bool active = live && (gr.x != 0.0f || gr.y != 0.0f);
+    #pragma unroll
+        for (uint32_t corner = 0; corner < 8; corner++) vx[corner] = vy[corner] = 0.0f;
+        if (active) {
+    #pragma unroll
             for (uint32_t corner = 0; corner < 8; corner++) {
-                vx[corner] = run_sum(vx[corner], flags);
-                vy[corner] = run_sum(vy[corner], flags);
+                float wgt = 1.0f;
+    #pragma unroll
+                for (uint32_t d = 0; d < 3; d++) wgt *= (corner & (1u << d)) ? cl.f[d] : 1.0f - cl.f[d];
+                vx[corner] = wgt * gr.x;
+                vy[corner] = wgt * gr.y;
             }
         }
-    }
-    // PAIRS.  On a hashed level whose table is a power of two the x term of the hash is the cell's x coordinate itself
-    // (kPrimes[0] = 1), below 2^12 for res <= 4096: the two x-neighbours of a corner pair differ in the low 12 bits only, i.e.
-    // they ALWAYS fall into the same 4096-row chunk.  So the eight records of a sample are four pairs: one histogram atomic,
-    // one offset read, one 16-byte payload store and one 4-byte key store per PAIR -- half the LDS instructions of the
-    // record-by-record path, which stays for the dense levels (their x-pairs straddle a chunk boundary now and then).
-    const bool pairs = g.hashed && g.mode == 1u && g.res <= kChunkRows && kPrimes[0] == 1u;
-    const uint32_t unit = pairs ? 2u : 1u;   // records per histogram count
-    if (emit) {
-        const AxisTerms<3> terms = axis_terms<3>(g, cl);
+        bool emit = active;
+        if (mergeable(gk, w)) {   // run merging, as in bin_fill_kernel
+            uint32_t dist;
+            const bool tail_lane = run_shape(live ? cell_key(cl) : kDeadKey, live, dist);
+            const RunFlags flags = run_flags(dist);
+            const float active_in_run = run_sum(active ? 1.0f : 0.0f, flags);
+            emit = tail_lane && active_in_run > 0.0f;
+            if (__ballot(active) != 0ull) {
 #pragma unroll
-        for (uint32_t corner = 0; corner < 8; corner++) rows[corner] = row_from_terms<3>(g, terms, corner);
-        if (pairs) {
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++) pos[q] = atomicAdd(&hist[rows[2 * q] >> kChunkShift], 1u);
-        } else {
-#pragma unroll
-            for (uint32_t corner = 0; corner < 8; corner++) pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
+                for (uint32_t corner = 0; corner < 8; corner++) {
+                    vx[corner] = run_sum(vx[corner], flags);
+                    vy[corner] = run_sum(vy[corner], flags);
+                }
+            }
         }
-    }
-    NGP_FILL_STAMP(3);
-    __syncthreads();
-    NGP_FILL_STAMP(4);
+        // PAIRS.  On a hashed level whose table is a power of two the x term of the hash is the cell's x coordinate itself
+        // (kPrimes[0] = 1), below 2^12 for res <= 4096: the two x-neighbours of a corner pair differ in the low 12 bits only, i.e.
+        // they ALWAYS fall into the same 4096-row chunk.  So the eight records of a sample are four pairs: one histogram atomic,
+        // one offset read, one 16-byte payload store and one 4-byte key store per PAIR -- half the LDS instructions of the
+        // record-by-record path, which stays for the dense levels (their x-pairs straddle a chunk boundary now and then).
+        constexpr bool pairs = FAST;
+        const uint32_t unit = pairs ? 2u : 1u;   // records per histogram count
+        if (emit) {
+            const AxisTerms<3> terms = axis_terms<3>(gk, cl);
+    #pragma unroll
+            for (uint32_t corner = 0; corner < 8; corner++) rows[corner] = row_from_terms<3>(gk, terms, corner);
+            if (pairs) {
+    #pragma unroll
+                for (uint32_t q = 0; q < 4; q++) pos[q] = atomicAdd(&hist[rows[2 * q] >> kChunkShift], 1u);
+            } else {
+    #pragma unroll
+                for (uint32_t corner = 0; corner < 8; corner++) pos[corner] = atomicAdd(&hist[rows[corner] >> kChunkShift], 1u);
+            }
+        }
+        NGP_FILL_STAMP(3);
+        __syncthreads();
+        NGP_FILL_STAMP(4);
 
-    // exclusive scan of the histogram (each chunk's count rounded up to a quad of records) -> staging offsets = offsets
-    // inside the tile's region.  Wave 0 scans the level's <= kLocalBins bins, kLocalBins / 64 per lane, and leaves lbase[] (in
-    // histogram units); directory words and the null records that pad a run go out AFTER the barrier, one bin per lane of the
-    // whole workgroup -- the seven other waves used to wait while wave 0 issued up to 128 scattered 4-byte stores.
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    const uint32_t quad = 4u / unit;          // histogram counts per quad of records
-    if (wid == 0) {
-        constexpr uint32_t K = kLocalBins / 64u;   // consecutive bins per lane
-        uint32_t n[K], q[K], sum = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < K; j++) {
-            const uint32_t i = K * lane + j;
-            n[j] = i < nbins ? hist[i] : 0u;
-            q[j] = (n[j] + quad - 1u) & ~(quad - 1u);
-            sum += q[j];
+        // exclusive scan of the histogram (each chunk's count rounded up to a quad of records) -> staging offsets = offsets
+        // inside the tile's region.  Wave 0 scans the level's <= kLocalBins bins, kLocalBins / 64 per lane, and leaves lbase[] (in
+        // histogram units); directory words and the null records that pad a run go out AFTER the barrier, one bin per lane of the
+        // whole workgroup -- the seven other waves used to wait while wave 0 issued up to 128 scattered 4-byte stores.
+        const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+        const uint32_t quad = 4u / unit;          // histogram counts per quad of records
+        if (wid == 0) {
+            constexpr uint32_t K = kLocalBins / 64u;   // consecutive bins per lane
+            uint32_t n[K], q[K], sum = 0;
+    #pragma unroll
+            for (uint32_t j = 0; j < K; j++) {
+                const uint32_t i = K * lane + j;
+                n[j] = i < nbins ? hist[i] : 0u;
+                q[j] = (n[j] + quad - 1u) & ~(quad - 1u);
+                sum += q[j];
+            }
+            uint32_t inc = sum;
+    #pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += up;
+            }
+            uint32_t run = inc - sum;
+    #pragma unroll
+            for (uint32_t j = 0; j < K; j++) {
+                const uint32_t i = K * lane + j;
+                if (i < nbins) lbase[i] = run;
+                run += q[j];
+            }
+            if (lane == 63u) s_total = inc * unit;
         }
-        uint32_t inc = sum;
-#pragma unroll
-        for (uint32_t d = 1; d < 64u; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += up;
-        }
-        uint32_t run = inc - sum;
-#pragma unroll
-        for (uint32_t j = 0; j < K; j++) {
-            const uint32_t i = K * lane + j;
-            if (i < nbins) lbase[i] = run;
-            run += q[j];
-        }
-        if (lane == 63u) s_total = inc * unit;
-    }
-    NGP_FILL_STAMP(5);   // scan
-    __syncthreads();
+        NGP_FILL_STAMP(5);   // scan
+        __syncthreads();
 
-    uint32_t *dcol = dir + (size_t)first * ntiles + tile;   // dir[chunk][tile]
-    if (threadIdx.x < nbins) {   // (nbins <= kLocalBins <= kFillBlock)
-        const uint32_t i = threadIdx.x, n = hist[i], base = lbase[i];
-        dcol[(size_t)i * ntiles] = (base * unit) | ((n * unit) << 16);
-        if (n & (quad - 1u)) {   // pad the run to a quad with null records (key 0, value 0)
-            for (uint32_t k = n * unit; k < ((n + quad - 1u) & ~(quad - 1u)) * unit; k++) {
-                stage_key[base * unit + k] = 0;
-                stage_val[base * unit + k] = make_float2(0.f, 0.f);
+        uint32_t *dcol = dir + (size_t)first * ntiles + tile;   // dir[chunk][tile]
+        if (threadIdx.x < nbins) {   // (nbins <= kLocalBins <= kFillBlock)
+            const uint32_t i = threadIdx.x, n = hist[i], base = lbase[i];
+            dcol[(size_t)i * ntiles] = (base * unit) | ((n * unit) << 16);
+            if (n & (quad - 1u)) {   // pad the run to a quad with null records (key 0, value 0)
+                for (uint32_t k = n * unit; k < ((n + quad - 1u) & ~(quad - 1u)) * unit; k++) {
+                    stage_key[base * unit + k] = 0;
+                    stage_val[base * unit + k] = make_float2(0.f, 0.f);
+                }
             }
         }
-    }
-    float gmax = nan ? __uint_as_float(0x7f800000u) : 0.0f;   // NaN -> inf
-    if (emit) {
-#pragma unroll
-        for (uint32_t corner = 0; corner < 8; corner++) gmax = fmaxf(gmax, fmaxf(fabsf(vx[corner]), fabsf(vy[corner])));
-        if (pairs) {
-            float4 *pv = reinterpret_cast<float4 *>(stage_val);
-            uint32_t *pk = reinterpret_cast<uint32_t *>(stage_key);
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
-                const uint32_t slot = lbase[rows[2 * q] >> kChunkShift] + pos[q];
-                pk[slot] = (rows[2 * q] & (kChunkRows - 1u)) | ((rows[2 * q + 1] & (kChunkRows - 1u)) << 16);
-                pv[slot] = make_float4(vx[2 * q], vy[2 * q], vx[2 * q + 1], vy[2 * q + 1]);
-            }
-        } else {
-#pragma unroll
-            for (uint32_t corner = 0; corner < 8; corner++) {
-                const uint32_t slot = lbase[rows[corner] >> kChunkShift] + pos[corner];
-                stage_key[slot] = (uint16_t)(rows[corner] & (kChunkRows - 1u));
-                stage_val[slot] = make_float2(vx[corner], vy[corner]);
+        float gmax = nan ? __uint_as_float(0x7f800000u) : 0.0f;   // NaN -> inf
+        if (emit) {
+    #pragma unroll
+            for (uint32_t corner = 0; corner < 8; corner++) gmax = fmaxf(gmax, fmaxf(fabsf(vx[corner]), fabsf(vy[corner])));
+            if (pairs) {
+                float4 *pv = reinterpret_cast<float4 *>(stage_val);
+                uint32_t *pk = reinterpret_cast<uint32_t *>(stage_key);
+    #pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t slot = lbase[rows[2 * q] >> kChunkShift] + pos[q];
+                    pk[slot] = (rows[2 * q] & (kChunkRows - 1u)) | ((rows[2 * q + 1] & (kChunkRows - 1u)) << 16);
+                    pv[slot] = make_float4(vx[2 * q], vy[2 * q], vx[2 * q + 1], vy[2 * q + 1]);
+                }
+            } else {
+    #pragma unroll
+                for (uint32_t corner = 0; corner < 8; corner++) {
+                    const uint32_t slot = lbase[rows[corner] >> kChunkShift] + pos[corner];
+                    stage_key[slot] = (uint16_t)(rows[corner] & (kChunkRows - 1u));
+                    stage_val[slot] = make_float2(vx[corner], vy[corner]);
+                }
             }
         }
-    }
-#pragma unroll
-    for (uint32_t d = 32; d >= 1; d >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, d, 64));
-    if (lane == 0) s_wmax[wid] = gmax;
-    __syncthreads();
-    // largest |gradient| of the call -> fixed-point scale of the reduce kernel: one word for the whole grid, touched by one
-    // lane per workgroup and only when the workgroup would raise it.  The current value is read with a device-scope atomic
-    // load: a plain (or "non-temporal") load of this uniform address becomes a scalar load, and the scalar cache never
-    // sees the other workgroups' atomics -- every wave then believes the word is still zero and the kernel degenerates
-    // into 50 000 serialised same-address atomics (600 us instead of 100).
-    if (threadIdx.x == 0) {
-        float m = s_wmax[0];
-#pragma unroll
-        for (uint32_t k = 1; k < kFillBlock / 64; k++) m = fmaxf(m, s_wmax[k]);
-        uint32_t *word = &w.chunk_base[kMaxLevels + 1];
-        if (__float_as_uint(m) > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(word, __float_as_uint(m));
-    }
-    NGP_FILL_STAMP(6);
-    // the region is the staging area, slot for slot: 16-byte stores of two payloads, 8-byte stores of four keys
-    const uint32_t total = s_total;
-    const size_t region = ((size_t)level * ntiles + tile) * kRegion;   // (kRegion: a multiple of 4 records)
-    float4 *dv = reinterpret_cast<float4 *>(w.vals + region);
-    const float4 *sv = reinterpret_cast<const float4 *>(stage_val);
-    for (uint32_t j = threadIdx.x; j < total / 2u; j += kFillBlock) dv[j] = sv[j];      // (total is a multiple of 4)
-    uint2 *dk = reinterpret_cast<uint2 *>(w.keys + region);
-    const uint2 *sk = reinterpret_cast<const uint2 *>(stage_key);
-    for (uint32_t j = threadIdx.x; j < total / 4u; j += kFillBlock) dk[j] = sk[j];
-    NGP_FILL_STAMP(7);
+    #pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, d, 64));
+        if (lane == 0) s_wmax[wid] = gmax;
+        __syncthreads();
+        // largest |gradient| of the call -> fixed-point scale of the reduce kernel: one word for the whole grid, touched by one
+        // lane per workgroup and only when the workgroup would raise it.  The current value is read with a device-scope atomic
+        // load: a plain (or "non-temporal") load of this uniform address becomes a scalar load, and the scalar cache never
+        // sees the other workgroups' atomics -- every wave then believes the word is still zero and the kernel degenerates
+        // into 50 000 serialised same-address atomics (600 us instead of 100).
+        if (threadIdx.x == 0) {
+            float m = s_wmax[0];
+    #pragma unroll
+            for (uint32_t k = 1; k < kFillBlock / 64; k++) m = fmaxf(m, s_wmax[k]);
+            uint32_t *word = &w.chunk_base[kMaxLevels + 1];
+            if (__float_as_uint(m) > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(word, __float_as_uint(m));
+        }
+        NGP_FILL_STAMP(6);
+        // the region is the staging area, slot for slot: 16-byte stores of two payloads, 8-byte stores of four keys
+        const uint32_t total = s_total;
+        const size_t region = ((size_t)level * ntiles + tile) * kRegion;   // (kRegion: a multiple of 4 records)
+        float4 *dv = reinterpret_cast<float4 *>(w.vals + region);
+        const float4 *sv = reinterpret_cast<const float4 *>(stage_val);
+        for (uint32_t j = threadIdx.x; j < total / 2u; j += kFillBlock) dv[j] = sv[j];      // (total is a multiple of 4)
+        uint2 *dk = reinterpret_cast<uint2 *>(w.keys + region);
+        const uint2 *sk = reinterpret_cast<const uint2 *>(stage_key);
+        for (uint32_t j = threadIdx.x; j < total / 4u; j += kFillBlock) dk[j] = sk[j];
+        NGP_FILL_STAMP(7);
+    };
+    if (fast)
+        body(std::true_type{});
+    else
+        body(std::false_type{});
 }
 
 // ------------------------------------------------------------------ reduce
