@@ -346,6 +346,11 @@ int ngp_x_mlp_forward(const float *enc, uint32_t stride, const float *dirs, cons
 int ngp_x_mlp_forward_act(const float *enc, uint32_t stride, const float *dirs, const int32_t *M_dev, uint32_t M,
                           const void *image, float *sigma, float *rgb, uint32_t color_act, uint32_t density_act,
                           uint32_t internal_act, float beta, ngp_stream_t stream);
+/* Density only, scattered (the density-grid refresh, nerf/renderer.py:874-880: evaluate the drawn cells, write them
+ * into the scratch grid; where a cell was drawn twice the larger density stays): row i's density goes to tmp_cas[cells[i]] by atomic max, cells[i] < 0 is dropped -- ngp_x_mlp_forward with rgb == NULL
+ * and ngp_x_density_grid_scatter as ONE launch, without the sigma array between them.  tmp_cas: the cascade's scratch grid. */
+int ngp_x_mlp_density_scatter(const float *enc, uint32_t stride, uint32_t M, const void *image, const int32_t *cells,
+                              float *tmp_cas, uint32_t density_act, uint32_t internal_act, float beta, ngp_stream_t stream);
 
 /* Backward of the fused field.  dsigma [M], drgb [M,3] = dL/d(sigma, rgb); outputs d(enc) in the slab
  * layout of `enc` (rows >= M untouched) and the six weight gradients (fp32, torch layout, OVERWRITTEN).

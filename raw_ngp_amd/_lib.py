@@ -62,6 +62,7 @@ _SIGNATURES = {
     "ngp_x_mlp_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_forward": [_p, _u, _p, _p, _u, _p, _p, _p],
     "ngp_x_mlp_forward_act": [_p, _u, _p, _p, _u, _p, _p, _p, _u, _u, _u, _f],
+    "ngp_x_mlp_density_scatter": [_p, _u, _u, _p, _p, _p, _u, _u, _f],
     "ngp_x_mlp_backward_act": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t,
                                _p, _u, _u, _u, _f],
     "ngp_x_mlp_backward": [_p, _u, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t],
@@ -688,6 +689,14 @@ class _MlpBackend:
         """weights: the six fp32 matrices (grid_mlp.net.0..2, view_mlp.net.0..2) in torch layout."""
         _call("ngp_x_mlp_prepare", image, *[_ptr(w, "f", f"w{i + 1}") for i, w in enumerate(weights)],
               image.data_ptr())
+
+    @staticmethod
+    def density_scatter(enc, stride, M, image, cells, tmp_cas, act=None):
+        """Density of the M rows of `enc`, max-scattered into tmp_cas[cells[i]] (cells[i] < 0: dropped): the refresh's field
+        evaluation and its scatter as one launch."""
+        act = act or (0, 0, 1.0, 0)
+        _call("ngp_x_mlp_density_scatter", enc, _ptr(enc, "f", "enc"), stride, M, image.data_ptr(), _ptr(cells, "i", "cells"),
+              _ptr(tmp_cas, "f", "tmp_cas"), int(act[1]), int(act[3]) if len(act) > 3 else 0, float(act[2]))
 
     @staticmethod
     def forward(enc, stride, dirs, M_dev, M, image, sigma, rgb, step_begin=None, act=None):

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256, kFwdWgPerCu) void mlp_forward_kernel(const flo
                                                             const int32_t *__restrict__ M_dev, uint32_t M_host,
                                                             const half8 *__restrict__ image,
                                                             float *__restrict__ sigma, float *__restrict__ rgb,
-                                                            StepBegin begin, FieldAct act = FieldAct{})
+                                                            StepBegin begin, FieldAct act = FieldAct{},
+                                                            const int32_t *__restrict__ scatter_cell = nullptr)
 {
     if (PASSENGER && blockIdx.x == 0) {
         step_begin_block(begin);
@@ -158,7 +159,16 @@ __global__ __launch_bounds__(256, kFwdWgPerCu) void mlp_forward_kernel(const flo
             for (int s = 0; s < 2; s++) o = mfma(wf[F_W3 + kb * 2 + s], x[kb][s], o);
         const float sigma_raw = o[0];
         if (rgb == nullptr) {   // density-only query (density-grid refresh): skip the colour MLP
-            if (valid && h == 0) sigma[row] = act_sigma(sigma_raw, act);
+            if (valid && h == 0) {
+                const float value = act_sigma(sigma_raw, act);
+                if (scatter_cell) {   // density-grid refresh: `sigma` is the cascade's scratch grid (starts at -1), max per cell.
+                    // sigma >= 0: as signed integers, float bit patterns of non-negative values order like the floats
+                    const int32_t cell = scatter_cell[row];
+                    if (cell >= 0) atomicMax(reinterpret_cast<int *>(sigma) + cell, __float_as_int(value));
+                } else {
+                    sigma[row] = value;
+                }
+            }
             continue;
         }
         // layer 4: [sigma row (zero weight), 15 features, SH16] -> 64
@@ -244,6 +254,30 @@ extern "C" int ngp_x_mlp_forward_act(const float *enc, uint32_t stride, const fl
         mlp_forward_kernel<false><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(
             enc, stride, dirs, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, StepBegin{}, act);
     NGP_CHECK_LAUNCH("mlp_forward");
+    return NGP_OK;
+}
+
+// Density only, scattered: the refresh's evaluate + ngp_x_density_grid_scatter as one launch.  Row i's density goes to
+// tmp_cas[cells[i]] by atomic max (cells[i] < 0: dropped), instead of to a sigma array that a second kernel would re-read.
+extern "C" int ngp_x_mlp_density_scatter(const float *enc, uint32_t stride, uint32_t M, const void *image,
+                                         const int32_t *cells, float *tmp_cas, uint32_t density_act, uint32_t internal_act,
+                                         float beta, ngp_stream_t stream)
+{
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(density_act <= 1u && internal_act <= 1u && beta > 0.0f, "mlp_density_scatter: unknown activation or beta <= 0");
+    NGP_REQUIRE(enc && image && cells && tmp_cas, "mlp_density_scatter: null tensor");
+    NGP_REQUIRE(stride >= M, "mlp_density_scatter: encoder slab stride smaller than M");
+    const uint32_t tiles = ceil_div(M, 32u);
+    const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * kFwdWgPerCu);
+    FieldAct act;
+    act.color = 0, act.density = density_act, act.beta = beta, act.internal = internal_act;
+    if (internal_act)
+        mlp_forward_kernel<false, true><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(
+            enc, stride, nullptr, nullptr, M, reinterpret_cast<const half8 *>(image), tmp_cas, nullptr, StepBegin{}, act, cells);
+    else
+        mlp_forward_kernel<false><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(
+            enc, stride, nullptr, nullptr, M, reinterpret_cast<const half8 *>(image), tmp_cas, nullptr, StepBegin{}, act, cells);
+    NGP_CHECK_LAUNCH("mlp_density_scatter");
     return NGP_OK;
 }
 

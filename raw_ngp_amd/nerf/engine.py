@@ -648,8 +648,15 @@ class FusedTrainer:
                 k = min(cap, total - s)
                 eb.grid_encode_forward_slab(self.dg_xyzs[s:s + k], m.bound, self.table, offsets, self.enc, None, None, k,
                                             cap, self.L, self.L, self.S, self.H, level_cost=self.level_cost_refresh)
-                self._mlp_forward(cap, None, None, None, k, self.dg_sigma[s:s + k], None)
-            eb.density_grid_scatter(self.dg_indices[:total], self.dg_sigma[:total], total, self.dg_tmp[cas])
+                if self.rfield:
+                    self._mlp_forward(cap, None, None, None, k, self.dg_sigma[s:s + k], None)
+                else:               # the scatter is the field kernel's epilogue: no sigma array, no second launch
+                    if self.pose:
+                        eb.slab_window(self.enc, cap, self.L, self.level_w, None, k, scale_only=not self.baa)
+                    self.mb.density_scatter(self.enc, cap, k, self.mlp_image, self.dg_indices[s:s + k], self.dg_tmp[cas],
+                                            act=self.act)
+            if self.rfield:
+                eb.density_grid_scatter(self.dg_indices[:total], self.dg_sigma[:total], total, self.dg_tmp[cas])
         eb.density_grid_update(m.density_grid, self.dg_tmp, decay, self.dg_stats)
         eb.packbits_mean(m.density_grid, self.dg_stats, m.density_thresh, m.density_bitfield)
         if self.occ_index is not None:              # the march's LDS copy of the bitfield: rebuilt with it

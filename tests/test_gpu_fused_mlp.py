@@ -56,6 +56,29 @@ def test_forward_matches_torch(M):
     np.testing.assert_allclose(rgb.cpu().numpy(), rc.cpu().numpy(), rtol=3e-2, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,act", [(1, None), (33, None), (50000, None), (4097, (0, 1, 2.0, 1))])
+def test_density_scatter_is_the_density_query_followed_by_the_scatter(M, act):
+    """ngp_x_mlp_density_scatter == ngp_x_mlp_forward(rgb = NULL) + ngp_x_density_grid_scatter, bit for bit (the maximum per
+    cell does not depend on the order of the atomics); negative cells are dropped, untouched cells keep their -1."""
+    from raw_ngp_amd import _lib
+    mb, eb = _lib.mlp_backend, _lib.engine_backend
+    W = make_weights(3)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    stride, cells = M + 5, 4096
+    enc = torch.randn(16, stride, 2, device="cuda", generator=g) * 0.5
+    idx = torch.randint(-1, cells // 2, (M,), device="cuda", generator=g, dtype=torch.int32)   # duplicates + dropped draws
+    image = torch.empty(mb.image_bytes(), dtype=torch.uint8, device="cuda")
+    mb.prepare(W, image)
+    sigma = torch.empty(M, device="cuda")
+    mb.forward(enc, stride, None, None, M, image, sigma, None, act=act)
+    want = torch.full((cells,), -1.0, device="cuda")
+    eb.density_grid_scatter(idx, sigma, M, want)
+    got = torch.full((cells,), -1.0, device="cuda")
+    mb.density_scatter(enc, stride, M, image, idx, got, act=act)
+    assert torch.equal(got, want)
+    assert torch.all(got[cells // 2:] == -1.0) and (M < 100 or torch.any(got[:cells // 2] >= 0))
+
+
 def test_forward_reads_count_from_device():
     from raw_ngp_amd import _lib
     mb = _lib.mlp_backend
