@@ -715,10 +715,15 @@ int ngp_x_near_far_from_aabb_v2(const float *rays_o, const float *rays_d, const 
  *                               n_uniform = H^3) then n_occupied cells drawn uniformly among those with density > 0
  *                               (index -1 when none is); xyz = (2 c/(H-1) - 1) * span + (2u - 1) * half with
  *                               span = bound_cas - half (renderer.py:868-872).  Philox4x32-10, counters (i, draw, 2|3, 0).
- *                               Random draws (full == 0) are DELIVERED half by half in Morton order of their cells, up
- *                               to the width of a sorting bin (4096 bins per half; any order inside a bin) -- the encoder
- *                               that evaluates them runs faster on neighbouring points; the multiset of (index, xyz)
- *                               pairs of each half is that of its draws i.
+ *                               Random draws (full == 0; H a power of two, H^3 >= 4096) are GENERATED half by half in
+ *                               Morton order of their cells, bin by bin (4096 bins per half) -- the encoder that
+ *                               evaluates them runs faster on neighbouring points.  n independent uniform draws are a
+ *                               multinomial count per bin and, inside every bin, that many independent uniform draws:
+ *                               the counts are those of the keys of the stream (i, draw, 2, 0); output slot j, in the
+ *                               bin whose slot range holds it, takes its position inside the bin from (j, draw, 4, 0)
+ *                               and its jitter from (j, draw, 5, 0).  Same law as the independent draws (what other
+ *                               sizes and NGP_REFRESH_SORT=0 deliver, in draw order), reproducible slot by slot
+ *                               (oracle.density_grid_sample(..., binned=True)).
  *   (caller evaluates the density at xyzs)
  *   ngp_x_density_grid_scatter  tmp[index] = max(tmp[index], sigma); tmp holds -1 where nothing was evaluated
  * then over all cascades:

@@ -346,9 +346,13 @@ def _compact_bits(v):
     return v
 
 
-def density_grid_sample(grid_cas, H, span, half, n_uniform, n_occupied, full, seed, draw):
+def density_grid_sample(grid_cas, H, span, half, n_uniform, n_occupied, full, seed, draw, binned=False):
     """ngp_x_density_grid_sample: the cell draws of update_extra_state (nerf/renderer.py:851-872) with Philox in
-    place of torch's generator.  Returns (indices int32 [n], xyzs f32 [n,3])."""
+    place of torch's generator.  Returns (indices int32 [n], xyzs f32 [n,3]).
+    binned: the draws as the device delivers them when it can (power-of-two H, >= 4096 cells, not a full sweep) -- generated
+    bin by bin, in Morton order (density_grid_sample_binned below); otherwise independent draws in draw order."""
+    if binned and not full:
+        return density_grid_sample_binned(grid_cas, H, span, half, n_uniform, n_occupied, seed, draw)
     n = n_uniform + n_occupied
     key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     i = np.arange(n, dtype=np.uint32)
@@ -378,6 +382,57 @@ def density_grid_sample(grid_cas, H, span, half, n_uniform, n_occupied, full, se
         c = _compact_bits(cell >> np.uint32(k)).astype(f32)
         xyz[:, k] = ((f32(2) * c) / f32(H - 1) - f32(1)) * f32(span) + (u01(q[:, k]) * f32(2) - f32(1)) * f32(half)
     xyz[~live] = 0
+    return index.astype(np.int32), xyz
+
+
+def density_grid_sample_binned(grid_cas, H, span, half, n_uniform, n_occupied, seed, draw):
+    """The same distribution, generated in Morton order (density_grid.hip, "draws that are born in Morton order"): n
+    independent uniform draws are a multinomial count per bin and, inside every bin, that many independent uniform draws
+    from the bin.  4096 bins per half.  (1) counts: histogram of the keys of the stream (i, draw, 2) -- uniform half: top
+    12 bits of the Morton index of cell (floor(r0 H / 2^32), floor(r1 H / 2^32), floor(r2 H / 2^32)); occupied half: top 12
+    bits of r0.  (2) output slot j lies in the bin whose [base, next base) holds it (base = exclusive running sum of the
+    counts, uniform bins first); a fresh number f = first word of the stream (j, draw, 4): uniform half: cell = bin <<
+    shift | f >> (32 - shift); occupied half: u = bin << 20 | f >> 12, pick = floor(u n_pos / 2^32) among the occupied
+    cells in Morton order.  Jitter from the stream (j, draw, 5)."""
+    n = n_uniform + n_occupied
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    cells = H ** 3
+    bits = int(np.ceil(np.log2(cells)))
+    assert H & (H - 1) == 0 and bits >= 12
+    shift = bits - 12
+    i = np.arange(n, dtype=np.uint32)
+    ctr = np.stack([i, np.full(n, draw, np.uint32), np.full(n, 2, np.uint32), np.zeros(n, np.uint32)], 1)
+    r = philox4x32_10(ctr, key).astype(np.uint64)
+    c = [((r[:n_uniform, k] * np.uint64(H)) >> np.uint64(32)).astype(np.uint32) for k in range(3)]
+    key_u = morton3D(np.stack(c, 1).astype(np.int32)).astype(np.int64) >> shift
+    key_o = (r[n_uniform:, 0] >> np.uint64(20)).astype(np.int64)
+    counts = np.concatenate([np.bincount(key_u, minlength=4096), np.bincount(key_o, minlength=4096)])
+    base = np.concatenate([[0], np.cumsum(counts)])                          # base[4096] == n_uniform
+    bins = np.repeat(np.arange(8192), counts)                                # bin of every output slot
+    ctr[:, 2] = 4
+    f = philox4x32_10(ctr, key).astype(np.uint64)[:, 0]
+    ctr[:, 2] = 5
+    q = philox4x32_10(ctr, key).astype(np.uint64)
+    index = np.empty(n, np.int64)
+    bu = bins[:n_uniform].astype(np.uint64)
+    index[:n_uniform] = (bu << np.uint64(shift)) | (f[:n_uniform] >> np.uint64(32 - shift) if shift else 0)
+    if n_occupied:
+        pos = np.flatnonzero(np.asarray(grid_cas).reshape(-1) > 0)
+        if len(pos):
+            u = ((bins[n_uniform:] - 4096).astype(np.uint64) << np.uint64(20)) | (f[n_uniform:] >> np.uint64(12))
+            index[n_uniform:] = pos[((u * np.uint64(len(pos))) >> np.uint64(32)).astype(np.int64)]
+        else:
+            index[n_uniform:] = -1
+    live = index >= 0
+    cell = np.where(live, index, 0).astype(np.uint32)
+    f32 = np.float32
+    u01 = lambda x: (x >> np.uint64(8)).astype(f32) * f32(2.0 ** -24)
+    xyz = np.zeros((n, 3), f32)
+    for k in range(3):
+        cc = _compact_bits(cell >> np.uint32(k)).astype(f32)
+        xyz[:, k] = ((f32(2) * cc) / f32(H - 1) - f32(1)) * f32(span) + (u01(q[:, k]) * f32(2) - f32(1)) * f32(half)
+    xyz[~live] = 0
+    assert base[4096] == n_uniform
     return index.astype(np.int32), xyz
 
 

@@ -179,34 +179,37 @@ __global__ __launch_bounds__(256) void grid_sample_cells_kernel(GridWs g, uint32
     store_draw(i, index, cx, cy, cz, H, span, half, q, indices, xyzs);
 }
 
-// ---- the same draws, delivered in Morton order -----------------------------------------------------------------------
+// ---- random draws that are BORN in Morton order ---------------------------------------------------------------------
 // The cells are evaluated by the hash-grid encoder, whose coarse and middle levels hit the caches only if neighbouring
 // points arrive together: 2^19 uniformly drawn cells in draw order cost the encoder 225 us, the same cells sorted 183 (and
-// the scatter of their densities 25 us instead of 44).  Counting sort of each half on a 12-bit key that is UNIFORM over
-// its 4096 bins: the uniform half by the top 12 bits of the cell's Morton index, the occupied half by the top 12 bits of
-// its random number -- the pick r = floor(u * n_pos) enumerates the occupied cells in Morton order, so sorting by u sorts
-// by cell.
-// Round 3 counted and placed with one GLOBAL atomic per draw (2 x 2^20 of them per refresh: 66 + 101 us of kernels that run
-// on the side stream beside the step in front of the refresh -- whose MLP backward, list and fill kernels took 116 us
-// longer beside them: the atomics saturate the L2's atomic units for everybody).  Now every atomic is an LDS atomic:
-//   count   workgroup w owns draws [w T, (w + 1) T) (T = 2048, all of one half): histogram of their keys in LDS,
-//           written out as row w of wg_hist[workgroups][4096] (coalesced, no atomics)
-//   offsets one lane per (half, bin): the column's running sum over the half's workgroups -> wg_hist[w][bin] becomes the
-//           rank of workgroup w's first draw inside the bin; the column total goes to `hist`
-//   scan    exclusive scan of the totals (one workgroup) -> base[bin]
-//   place   workgroup w draws the same numbers again (counter-based), starts an LDS cursor per bin at base + its rank and
-//           hands out slots with LDS atomics; resolves the cell (the occupied half's binary search happens once, here) and
-//           writes the draw to its slot.
-// The order inside (workgroup, bin) depends on the order of the LDS atomics; nothing downstream does (each point is
-// evaluated on its own, duplicates of a cell resolve by maximum).
+// the scatter of their densities 25 us instead of 44).  Rounds 3 and 4 SORTED the draws (counting sort on a 12-bit key:
+// first with one global atomic per draw, then with LDS atomics and a place pass of scattered 16-byte stores -- 101 us on
+// the side stream, beside a step whose MLP backward it slowed by ~ 35 us).  There is nothing to sort if the draws are
+// generated bin by bin.  n independent uniform draws are, exactly: (1) a multinomial count per bin, (2) inside every bin,
+// that many independent uniform draws from the bin.  So:
+//   count   (1) is taken from the draws themselves: workgroup w histograms the keys of draws [w T, (w + 1) T) of the
+//           counter-based stream (i, draw, 2) in LDS and writes row w of wg_hist[workgroups][4096]; no atomics leave the CU
+//   totals  column sums of the rows -> hist[half][bin]
+//   scan    exclusive scan -> base[bin]: the first output slot of every bin
+//   emit    (2): one lane per OUTPUT SLOT j.  Its bin is the one whose [base, next base) holds j; its position inside the
+//           bin comes from a fresh number of the stream (j, draw, 4); the jitter inside the cell from (j, draw, 5).
+//           Coalesced stores, no cursor, no atomics; the order inside a bin is the slot order -- reproducible.
+// Keys, 4096 bins per half, uniform over the bins:
+//   uniform half   the top 12 bits of the cell's Morton index; inside a bin the low bits of the index are uniform (H a
+//                  power of two: every cell equally likely) -> cell = bin << shift | fresh bits
+//   occupied half  the top 12 bits of the draw's random number u: the pick floor(u n_pos / 2^32) enumerates the occupied
+//                  cells in Morton order, so sorting by u sorts by cell; inside a bin the low 20 bits of u are uniform
+//                  -> u = bin << 20 | fresh bits, then the same pick and search as an unsorted draw
+// The multiset of cells has the distribution of the reference's independent draws (renderer.py:851-866); it is not the
+// multiset the unsorted kernel above draws from the same seed (oracle: density_grid_sample(..., binned=True)).
 constexpr uint32_t kSortBins = 8192;   // 4096 per half
-constexpr uint32_t kSortTile = 2048;   // draws per workgroup (a divisor of each half's size, or the launcher falls back)
-constexpr uint32_t kSortBlock = 512;   // ... of this many lanes: kSortPer draws each, their latency chains side by side
+constexpr uint32_t kSortTile = 2048;   // draws per counting workgroup (a divisor of each half's size, or the launcher falls back)
+constexpr uint32_t kSortBlock = 512;   // ... of this many lanes
 constexpr uint32_t kSortPer = kSortTile / kSortBlock;
 constexpr uint32_t kSortHalf = kSortBins / 2u;
 struct SortWs {
-    uint32_t *hist, *base;             // kSortBins words each: column totals, first slot of every bin
-    uint32_t *wg_hist;                 // [workgroups][kSortHalf]: counts, then ranks
+    uint32_t *hist, *base;             // kSortBins words each: bin totals, first slot of every bin
+    uint32_t *wg_hist;                 // [workgroups][kSortHalf]: counts
 };
 __host__ __device__ inline SortWs sort_ws(void *ws, uint32_t n_words)
 {
@@ -219,8 +222,7 @@ __host__ __device__ inline SortWs sort_ws(void *ws, uint32_t n_words)
 // 12-bit key inside the draw's half
 __device__ __forceinline__ uint32_t sort_key(uint32_t i, uint32_t n_uniform, uint32_t H, uint32_t shift, const uint32_t r[4])
 {
-    if (i < n_uniform)
-        return min(morton3(__umulhi(r[0], H), __umulhi(r[1], H), __umulhi(r[2], H)) >> shift, kSortHalf - 1u);
+    if (i < n_uniform) return morton3(__umulhi(r[0], H), __umulhi(r[1], H), __umulhi(r[2], H)) >> shift;
     return r[0] >> 20;
 }
 
@@ -247,10 +249,10 @@ __global__ __launch_bounds__(kSortBlock) void grid_sort_count_kernel(SortWs s, u
     for (uint32_t k = threadIdx.x; k < kSortHalf; k += kSortBlock) row[k] = h[k];
 }
 
-// Column sums of wg_hist over a half's workgroups, made exclusive: 32 bins x 8 row segments per workgroup of 256 lanes.  A lane
-// takes its segment's rows in batches of 16 independent loads (consecutive lanes = consecutive bins: 128-byte rows), the eight
-// segment totals of a bin meet in LDS.  (One lane per column, walking it row by row, took 98 us: 256 dependent round trips.)
-__global__ __launch_bounds__(256) void grid_sort_offsets_kernel(SortWs s, uint32_t wg_uniform, uint32_t wg_total)
+// Column sums of wg_hist over a half's workgroups: 32 bins x 8 row segments per workgroup of 256 lanes.  A lane takes its
+// segment's rows in batches of 16 independent loads (consecutive lanes = consecutive bins: 128-byte rows), the eight segment
+// totals of a bin meet in LDS.  (One lane per column, walking it row by row, took 98 us: 256 dependent round trips.)
+__global__ __launch_bounds__(256) void grid_sort_totals_kernel(SortWs s, uint32_t wg_uniform, uint32_t wg_total)
 {
     __shared__ uint32_t seg_sum[8][32];
     const uint32_t b = threadIdx.x & 31u, sg = threadIdx.x >> 5;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void grid_sort_offsets_kernel(SortWs s, uint32
     const uint32_t half = t / kSortHalf, bin = t - half * kSortHalf;
     const uint32_t w0 = half ? wg_uniform : 0u, w1 = half ? wg_total : wg_uniform;
     const uint32_t per = (w1 - w0 + 7u) / 8u, r0 = min(w1, w0 + sg * per), r1 = min(w1, r0 + per);
-    uint32_t *col = s.wg_hist + bin;
+    const uint32_t *col = s.wg_hist + bin;
     uint32_t sum = 0;
     for (uint32_t w = r0; w < r1; w += 16u) {
         uint32_t c[16];
@@ -269,23 +271,12 @@ __global__ __launch_bounds__(256) void grid_sort_offsets_kernel(SortWs s, uint32
     }
     seg_sum[sg][b] = sum;
     __syncthreads();
-    uint32_t run = 0, total = 0;
+    if (sg == 0) {
+        uint32_t total = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        if (k < sg) run += seg_sum[k][b];
-        total += seg_sum[k][b];
+        for (uint32_t k = 0; k < 8; k++) total += seg_sum[k][b];
+        s.hist[t] = total;
     }
-    for (uint32_t w = r0; w < r1; w += 16u) {
-        uint32_t c[16];
-#pragma unroll
-        for (uint32_t k = 0; k < 16; k++) c[k] = w + k < r1 ? col[(size_t)(w + k) * kSortHalf] : 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < 16; k++) {
-            if (w + k < r1) col[(size_t)(w + k) * kSortHalf] = run;
-            run += c[k];
-        }
-    }
-    if (sg == 0) s.hist[t] = total;
 }
 
 __global__ __launch_bounds__(1024) void grid_sort_scan_kernel(SortWs s)   // one workgroup: exclusive scan of the counts
@@ -316,78 +307,55 @@ __global__ __launch_bounds__(1024) void grid_sort_scan_kernel(SortWs s)   // one
     }
 }
 
-__global__ __launch_bounds__(kSortBlock) void grid_sort_place_kernel(GridWs g, SortWs s, uint32_t n_words, uint32_t H,
-                                                                    float span, float half, uint32_t n_uniform,
-                                                                    uint32_t n_occupied, uint32_t shift, uint32_t seed_lo,
-                                                                    uint32_t seed_hi, const uint32_t *__restrict__ draw_dev,
-                                                                    uint32_t draw, int32_t *__restrict__ indices,
-                                                                    float *__restrict__ xyzs)
+// one lane per output slot (see above)
+__global__ __launch_bounds__(256) void grid_sort_emit_kernel(GridWs g, SortWs s, uint32_t n_words, uint32_t H, float span,
+                                                            float half, uint32_t n_uniform, uint32_t n_occupied,
+                                                            uint32_t shift, uint32_t seed_lo, uint32_t seed_hi,
+                                                            const uint32_t *__restrict__ draw_dev, uint32_t draw,
+                                                            int32_t *__restrict__ indices, float *__restrict__ xyzs)
 {
-    __shared__ uint32_t cursor[kSortHalf];
-    const uint32_t i0 = blockIdx.x * kSortTile, n = n_uniform + n_occupied;
-    const bool occupied = i0 >= n_uniform;            // (a workgroup's draws are all of one half)
-    const uint32_t *rank = s.wg_hist + (size_t)blockIdx.x * kSortHalf, *base = s.base + (occupied ? kSortHalf : 0u);
-    for (uint32_t k = threadIdx.x; k < kSortHalf; k += kSortBlock) cursor[k] = base[k] + rank[k];
-    __syncthreads();
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x, n = n_uniform + n_occupied;
+    if (j >= n) return;
     if (draw_dev) draw = draw_dev[0];
-    // kSortPer draws per lane, taken side by side: the occupied half's binary search is ~ 18 dependent loads per draw
-    uint32_t r[kSortPer][4], q[kSortPer][4], slot[kSortPer], lo[kSortPer], hi[kSortPer], pick[kSortPer];
-    bool on[kSortPer];
-    const uint32_t n_pos = occupied ? g.prefix[n_words] : 0u;
-#pragma unroll
-    for (uint32_t j = 0; j < kSortPer; j++) {
-        const uint32_t i = i0 + j * kSortBlock + threadIdx.x;
-        on[j] = i < n;
-        r[j][0] = q[j][0] = i;
-        r[j][1] = q[j][1] = draw;
-        r[j][2] = 2u;
-        q[j][2] = 3u;
-        r[j][3] = q[j][3] = 0u;
-        philox4x32_10(r[j], seed_lo, seed_hi);
-        philox4x32_10(q[j], seed_lo, seed_hi);
-        slot[j] = on[j] ? atomicAdd(&cursor[sort_key(i, n_uniform, H, shift, r[j])], 1u) : 0u;
-        pick[j] = __umulhi(r[j][0], n_pos);
-        lo[j] = 0;
-        hi[j] = n_words;
+    const bool occupied = j >= n_uniform;       // (base[kSortHalf] == n_uniform: the halves stay where they were)
+    const uint32_t *base = s.base + (occupied ? kSortHalf : 0u);
+    uint32_t lo = 0, hi = kSortHalf;            // largest bin with base[bin] <= j (an empty bin shares its base with the next)
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (base[mid] <= j)
+            lo = mid;
+        else
+            hi = mid;
     }
-    if (occupied && n_pos != 0u) {   // largest w with prefix[w] <= pick, kSortPer searches in step (as draw_cell does one)
-        bool more = true;
-        while (more) {
-            more = false;
-#pragma unroll
-            for (uint32_t j = 0; j < kSortPer; j++) {
-                if (hi[j] - lo[j] > 1u) {
-                    const uint32_t mid = (lo[j] + hi[j]) >> 1;
-                    if (g.prefix[mid] <= pick[j])
-                        lo[j] = mid;
-                    else
-                        hi[j] = mid;
-                    more = more || hi[j] - lo[j] > 1u;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < kSortPer; j++) {
-        if (!on[j]) continue;
-        uint32_t cx = 0, cy = 0, cz = 0;
-        int32_t index;
-        if (!occupied) {
-            cx = __umulhi(r[j][0], H);
-            cy = __umulhi(r[j][1], H);
-            cz = __umulhi(r[j][2], H);
-            index = (int32_t)morton3(cx, cy, cz);
-        } else if (n_pos == 0u) {
-            index = -1;                                 // nothing occupied yet: the reference leaves this half out
+    const uint32_t bin = lo;
+    uint32_t r[4] = {j, draw, 4u, 0u}, q[4] = {j, draw, 5u, 0u};
+    philox4x32_10(r, seed_lo, seed_hi);
+    philox4x32_10(q, seed_lo, seed_hi);
+    uint32_t cell;
+    int32_t index;
+    if (!occupied) {
+        cell = (bin << shift) | (shift ? r[0] >> (32u - shift) : 0u);
+        index = (int32_t)cell;
+    } else {
+        const uint32_t n_pos = g.prefix[n_words];
+        if (n_pos == 0u) {                      // nothing occupied yet: the reference leaves this half out
+            cell = 0;
+            index = -1;
         } else {
-            const uint32_t cell = lo[j] * 64u + select_bit(g.mask[lo[j]], pick[j] - g.prefix[lo[j]]);
-            cx = compact_bits(cell);
-            cy = compact_bits(cell >> 1);
-            cz = compact_bits(cell >> 2);
+            const uint32_t u = (bin << 20) | (r[0] >> 12), pick = __umulhi(u, n_pos);
+            uint32_t wl = 0, wh = n_words;      // largest w with prefix[w] <= pick (as draw_cell)
+            while (wh - wl > 1u) {
+                const uint32_t mid = (wl + wh) >> 1;
+                if (g.prefix[mid] <= pick)
+                    wl = mid;
+                else
+                    wh = mid;
+            }
+            cell = wl * 64u + select_bit(g.mask[wl], pick - g.prefix[wl]);
             index = (int32_t)cell;
         }
-        store_draw(slot[j], index, cx, cy, cz, H, span, half, q[j], indices, xyzs);
     }
+    store_draw(j, index, compact_bits(cell), compact_bits(cell >> 1), compact_bits(cell >> 2), H, span, half, q, indices, xyzs);
 }
 
 __global__ __launch_bounds__(256) void grid_scatter_kernel(const int32_t *__restrict__ indices,
@@ -498,28 +466,30 @@ extern "C" int ngp_x_density_grid_sample(const float *grid_cas, uint32_t H, floa
         grid_positive_mask_kernel<<<dim3(min(ceil_div(n_words, 4u), 2048u)), dim3(256), 0, st>>>(grid_cas, n_words, g);
         grid_prefix_kernel<<<dim3(1), dim3(1024), 0, st>>>(n_words, g);
     }
-    // random draws leave in Morton order of their cells (blocks of cells ascending, any order inside a block): what the
-    // encoder that evaluates them wants.  NGP_REFRESH_SORT=0: in draw order (a full sweep is in Morton order as it is)
+    // random draws leave in Morton order of their cells (bins of cells ascending): what the encoder that evaluates them
+    // wants.  NGP_REFRESH_SORT=0: independent draws in draw order (a full sweep is in Morton order as it is)
     static const bool sort_on = !(getenv("NGP_REFRESH_SORT") && getenv("NGP_REFRESH_SORT")[0] == '0');
-    // (the sort wants whole workgroups of one half and a workspace row for each: anything else is drawn unsorted)
+    // (the binned draw wants a power-of-two grid of at least 4096 cells, whole counting workgroups of one half and a workspace
+    // row for each of them: anything else is drawn unsorted)
+    uint32_t bits = 0;
+    while ((1ull << bits) < cells) bits++;
     const uint32_t wgs = ceil_div(n, kSortTile), wg_uniform = n_uniform / kSortTile;
-    const bool sortable = n_uniform % kSortTile == 0 && (size_t)wgs <= ((size_t)cells / 2 + kSortTile - 1) / kSortTile + 2;
+    const bool sortable = (H & (H - 1u)) == 0 && bits >= 12u && n_uniform % kSortTile == 0 &&
+                          (size_t)wgs <= ((size_t)cells / 2 + kSortTile - 1) / kSortTile + 2;
     if (full || !sort_on || !sortable) {
         grid_sample_cells_kernel<<<dim3(ceil_div(n, 256u)), dim3(256), 0, st>>>(
             g, n_words, H, span, half, n_uniform, n_occupied, full != 0, (uint32_t)seed, (uint32_t)(seed >> 32), draw_dev, draw,
             indices, xyzs);
     } else {
         const SortWs s = sort_ws(workspace, n_words);
-        uint32_t bits = 0;
-        while ((1ull << bits) < cells) bits++;
-        const uint32_t shift = bits > 12u ? bits - 12u : 0u;
+        const uint32_t shift = bits - 12u;
         grid_sort_count_kernel<<<dim3(wgs), dim3(kSortBlock), 0, st>>>(s, H, n_uniform, n, shift, (uint32_t)seed,
                                                                (uint32_t)(seed >> 32), draw_dev, draw);
-        grid_sort_offsets_kernel<<<dim3(kSortBins / 32u), dim3(256), 0, st>>>(s, wg_uniform, wgs);
+        grid_sort_totals_kernel<<<dim3(kSortBins / 32u), dim3(256), 0, st>>>(s, wg_uniform, wgs);
         grid_sort_scan_kernel<<<dim3(1), dim3(1024), 0, st>>>(s);
-        grid_sort_place_kernel<<<dim3(wgs), dim3(kSortBlock), 0, st>>>(g, s, n_words, H, span, half, n_uniform, n_occupied, shift,
-                                                               (uint32_t)seed, (uint32_t)(seed >> 32), draw_dev, draw, indices,
-                                                               xyzs);
+        grid_sort_emit_kernel<<<dim3(ceil_div(n, 256u)), dim3(256), 0, st>>>(g, s, n_words, H, span, half, n_uniform, n_occupied,
+                                                                        shift, (uint32_t)seed, (uint32_t)(seed >> 32), draw_dev,
+                                                                        draw, indices, xyzs);
     }
     NGP_CHECK_LAUNCH("density_grid_sample");
     return NGP_OK;

@@ -570,36 +570,34 @@ def test_density_grid_refresh_kernels_match_oracle(lib, orc, full):
     xyz = torch.empty(n, 3, device="cuda")
     dgrid = dev(grid)
     e.density_grid_sample(dgrid[0], H, bound - half, half, n_uni, n_occ, full, seed, draw, ws, idx, xyz)
-    ridx, rxyz = orc.density_grid_sample(grid[0], H, bound - half, half, n_uni, n_occ, full, seed, draw)
+    # (random draws leave bin by bin, in Morton order of their cells -- the restatement's binned=True; a full sweep is the cells
+    # in order)
+    ridx, rxyz = orc.density_grid_sample(grid[0], H, bound - half, half, n_uni, n_occ, full, seed, draw, binned=True)
     gidx, gxyz = host(idx), host(xyz)
+    np.testing.assert_array_equal(gidx, ridx)                    # slot by slot
+    np.testing.assert_allclose(gxyz, rxyz, rtol=0, atol=2e-7)
     if not full:
-        # random draws arrive half by half in Morton order of their cells, up to the width of a sorting bin (4096 bins per
-        # half: blocks of cells for the uniform half, ranges of picks for the occupied one): the same draws as the
-        # restatement's, as a multiset
+        # Morton order up to the width of a bin (4096 bins per half: blocks of cells for the uniform half, ranges of picks for
+        # the occupied one); the occupied half only picks occupied cells, every one of them about equally often
         shift = max(int(np.ceil(np.log2(cells))) - 12, 0)
         assert np.all(np.diff(gidx[:n_uni] >> shift) >= 0)
         occ = np.flatnonzero(grid[0] > 0)
         rank = np.searchsorted(occ, gidx[n_uni:])
         assert np.all(occ[rank] == gidx[n_uni:]) and np.all(np.diff(rank) >= -(len(occ) // 4096 + 2))
-        assert np.array_equal(np.sort(gidx[:n_uni]), np.sort(ridx[:n_uni]))          # (the halves stay where they were)
-        canon = lambda i, x: np.lexsort((x[:, 2], x[:, 1], x[:, 0], i))      # noqa: E731
-        og, orf = canon(gidx, gxyz), canon(ridx, rxyz)
-        np.testing.assert_array_equal(gidx[og], ridx[orf])
-        np.testing.assert_allclose(gxyz[og], rxyz[orf], rtol=0, atol=2e-7)
-        ridx = gidx                                                          # (the order the scatter below sees)
-    else:
-        np.testing.assert_array_equal(gidx, ridx)
-        np.testing.assert_allclose(gxyz, rxyz, rtol=0, atol=2e-7)
-    if not full:
-        ro, _ = orc.density_grid_sample(grid[0], H, bound - half, half, n_uni, n_occ, full, seed, draw)
-        assert np.all(grid[0, ro[n_uni:]] > 0)                   # second half only picks occupied cells
-        hist = np.bincount(ro[n_uni:], minlength=cells)[grid[0] > 0]
+        hist = np.bincount(gidx[n_uni:], minlength=cells)[grid[0] > 0]
         assert hist.max() <= 12 and abs(hist.mean() - n_occ / (grid[0] > 0).sum()) < 1e-9
+        # the same law as independent draws (the restatement's binned=False: another sample of it): every cell of the uniform
+        # half is hit Binomial(n, 1 / cells) often -- compare the histograms of the hit counts
+        iidx, _ = orc.density_grid_sample(grid[0], H, bound - half, half, n_uni, n_occ, full, seed, draw)
+        hb, hi_ = (np.bincount(np.bincount(v[:n_uni], minlength=cells), minlength=8)[:8] for v in (gidx, iidx))
+        expect = cells * np.array([np.exp(-0.25) * 0.25 ** k / np.prod(np.arange(1, k + 1)) for k in range(8)])
+        for h in (hb, hi_):     # (Poisson(1/4) to within 4 sigma of the bin's count)
+            assert np.all(np.abs(h - expect) <= 4 * np.sqrt(expect) + 2), (h, expect)
     # device counter as the draw number gives the same cells
     idx2 = torch.empty_like(idx)
     e.density_grid_sample(dgrid[0], H, bound - half, half, n_uni, n_occ, full, seed,
                           torch.tensor([draw], dtype=torch.int32, device="cuda"), ws, idx2, torch.empty_like(xyz))
-    assert torch.equal(torch.sort(idx).values, torch.sort(idx2).values)
+    assert torch.equal(idx, idx2)
     # scatter + update + packbits
     sig = rng.uniform(0, 4, n).astype(np.float32)
     tmp = torch.full((1, cells), -1.0, device="cuda")
