@@ -30,27 +30,14 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
     float *__restrict__ out, float *__restrict__ inputs01, const int32_t *__restrict__ B_dev, uint32_t B_cap,
     uint32_t stride, uint32_t nchunks, LevelRes lv, uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w,
     float *__restrict__ dydx = nullptr, uint32_t snake_levels = 0, uint32_t placed_levels = 0, LevelPlacement place = {},
-    uint32_t level_lo = 0)
+    uint32_t level_lo = 0, uint32_t persistent = 0)
 {
     // level_lo: the launch covers levels level_lo .. level_lo + (levels of the grid) - 1 (ngp_x_grid_encode_forward_slab_levels)
     extern __shared__ uint32_t hist[];
-    uint32_t level, tile_;
-    if (placed_levels) {
-        placed_level_tile(place, blockIdx.x, nchunks, placed_levels, level, tile_);
-        if (level == kNoLevel) return;
-    } else if (snake_levels) {
-        snake_level_tile(blockIdx.x, nchunks, snake_levels, level, tile_);
-        if (level == kNoLevel) return;
-    } else {
-        const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
-        level = item / nchunks;
-        tile_ = item - level * nchunks;
-    }
-    level += level_lo;
+    auto do_tile = [&](uint32_t level, uint32_t tile_) {
     const uint32_t b0 = tile_ * kBlock, b = b0 + threadIdx.x;
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
     if (b0 >= B) return;   // whole workgroup
-
     const Geom<3> g = make_geom<3>(offsets, level, lv.res[level], gridtype);
     uint32_t first = 0, nbins = 0;
     if (COUNT) {
@@ -167,6 +154,39 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
         for (uint32_t i = threadIdx.x; i < nbins; i += kBlock)
             if (hist[i]) atomicAdd(&w.count[first + i], hist[i]);
     }
+    };
+    if (!COUNT && persistent) {
+        // Persistent form (the number of points is only known on the device: a grid sized for the arena's capacity is four
+        // fifths workgroups that find nothing to do, dealt to the XCDs in between the ones that do).  gridDim.x = 8 x (workgroups
+        // per XCD); the workgroups with the same blockIdx % 8 share an XCD and stride through that XCD's list (snake: level k,
+        // then level 15 - k) -- every XCD at its own pace, and with fewer workgroups per CU than fit, so that the march on the
+        // side stream keeps its wave slots: forward 43.8 -> 41.3 us in the step, 0.2855 -> 0.2773 ms/step (kSlabWgsPerCu).
+        const uint32_t k = blockIdx.x & 7u, G8 = gridDim.x >> 3;
+        const uint32_t Bq = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
+        const uint32_t tiles = (Bq + kBlock - 1u) / kBlock, len = snake_rounds(snake_levels) * tiles;
+        // (static stride, no work counter: the items of a level cost the same; a counter per XCD was tried -- one atomic per item
+        // costs more than the imbalance it removes)
+        for (uint32_t it = blockIdx.x >> 3; it < len; it += G8) {
+            const uint32_t round = it / tiles, t = it - round * tiles;
+            const uint32_t lvl = (round >> 1) * 16u + ((round & 1u) ? 15u - k : k);
+            if (lvl < snake_levels) do_tile(lvl + level_lo, t);
+        }
+        return;
+    }
+    uint32_t level, tile_;
+    if (placed_levels) {
+        placed_level_tile(place, blockIdx.x, nchunks, placed_levels, level, tile_);
+        if (level == kNoLevel) return;
+    } else if (snake_levels) {
+        snake_level_tile(blockIdx.x, nchunks, snake_levels, level, tile_);
+        if (level == kNoLevel) return;
+    } else {
+        const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+        level = item / nchunks;
+        tile_ = item - level * nchunks;
+    }
+    level += level_lo;
+    do_tile(level, tile_);
 }
 
 // ------------------------------------------------------------------ wave scans
@@ -743,6 +763,15 @@ __global__ void near_far_v2_kernel(const float *__restrict__ rays_o, const float
 
 using namespace ngp;
 
+// workgroups of the persistent slab forward: kSlabWgsPerCu per CU (NGP_SLAB_WGS overrides; 0: the capacity-sized grid).  Six of
+// the eight that fit: 5 / 6 / 7 / 8 per CU give 0.2787 / 0.2773 / 0.2822 / 0.2867 ms/step -- a full CU starves the side stream
+constexpr uint32_t kSlabWgsPerCu = 6;
+static uint32_t slab_persistent_blocks(bool eligible)
+{
+    static const uint32_t per_cu = getenv("NGP_SLAB_WGS") ? (uint32_t)atoi(getenv("NGP_SLAB_WGS")) : kSlabWgsPerCu;
+    return eligible ? 256u * min(per_cu, 16u) : 0u;
+}
+
 extern "C" int ngp_x_grid_encode_forward_slab(const float *xyzs, float bound, const float *embeddings,
                                               const int32_t *offsets, float *out, float *inputs01, const int32_t *B_dev,
                                               uint32_t B_cap, uint32_t stride, uint32_t L, uint32_t max_level, float S,
@@ -773,15 +802,16 @@ extern "C" int ngp_x_grid_encode_forward_slab_levels(const float *xyzs, float bo
     const uint32_t nchunks = ceil_div(B_cap, kBlock), n = level_hi - level_lo;
     static const bool snake_on = !(getenv("NGP_SNAKE") && getenv("NGP_SNAKE")[0] == '0');
     const uint32_t snake_levels = (snake_on && n >= 8) ? n : 0u;
-    const dim3 grid(snake_levels ? snake_blocks(n, nchunks) : nchunks * n);
+    const uint32_t pblocks = slab_persistent_blocks(B_dev != nullptr && snake_levels != 0);
+    const dim3 grid(pblocks ? pblocks : (snake_levels ? snake_blocks(n, nchunks) : nchunks * n));
     if (dydx)
         grid_forward_slab_kernel<false, true><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype, align_corners != 0,
-            interp, WsLayout{}, dydx, snake_levels, 0u, LevelPlacement{}, level_lo);
+            interp, WsLayout{}, dydx, snake_levels, 0u, LevelPlacement{}, level_lo, pblocks ? 1u : 0u);
     else
         grid_forward_slab_kernel<false><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype, align_corners != 0,
-            interp, WsLayout{}, nullptr, snake_levels, 0u, LevelPlacement{}, level_lo);
+            interp, WsLayout{}, nullptr, snake_levels, 0u, LevelPlacement{}, level_lo, pblocks ? 1u : 0u);
     NGP_CHECK_LAUNCH("grid_encode_forward_slab_levels");
     return NGP_OK;
 }
@@ -843,6 +873,8 @@ extern "C" int ngp_x_grid_encode_forward_slab_placed(const float *xyzs, float bo
             grid = dim3(8u * max_level * ceil_div(nchunks, 8u));
         }
     }
+    // a device-side point count under the snake: persistent workgroups (see the kernel)
+    const dim3 pgrid(slab_persistent_blocks(B_dev != nullptr && snake_levels != 0 && placed_levels == 0 && !binned_workspace));
     if (binned_workspace) {
         // the workspace of ngp_x_grid_backward_binned_* for the same samples, planned (mode 2 of prepare): count here
         NGP_REQUIRE(max_level == L && ((uintptr_t)binned_workspace & 15u) == 0 && n_rows_total > 0,
@@ -859,13 +891,13 @@ extern "C" int ngp_x_grid_encode_forward_slab_placed(const float *xyzs, float bo
                 xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
                 align_corners != 0, interp, w, nullptr, snake_levels, placed_levels, place);
     } else if (dydx) {
-        grid_forward_slab_kernel<false, true><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
+        grid_forward_slab_kernel<false, true><<<pgrid.x ? pgrid : grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-            align_corners != 0, interp, WsLayout{}, dydx, snake_levels, placed_levels, place);
+            align_corners != 0, interp, WsLayout{}, dydx, snake_levels, placed_levels, place, 0u, pgrid.x ? 1u : 0u);
     } else {
-        grid_forward_slab_kernel<false><<<grid, dim3(kBlock), 0, as_stream(stream)>>>(
+        grid_forward_slab_kernel<false><<<pgrid.x ? pgrid : grid, dim3(kBlock), 0, as_stream(stream)>>>(
             xyzs, bound, embeddings, offsets, out, inputs01, B_dev, B_cap, stride, nchunks, lv, gridtype,
-            align_corners != 0, interp, WsLayout{}, nullptr, snake_levels, placed_levels, place);
+            align_corners != 0, interp, WsLayout{}, nullptr, snake_levels, placed_levels, place, 0u, pgrid.x ? 1u : 0u);
     }
     NGP_CHECK_LAUNCH("grid_encode_forward_slab");
     return NGP_OK;
