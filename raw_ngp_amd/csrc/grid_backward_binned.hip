@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     const float *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ B_dev, uint32_t B_cap, uint32_t gstride, uint32_t ntiles, uint32_t nbins_cap, LevelRes lv,
     uint32_t gridtype, bool align_corners, uint32_t interp, WsLayout w, uint32_t *__restrict__ dir, uint32_t n_tail,
-    MlpDwReduce tail, uint32_t snake_levels, const int32_t *__restrict__ sample_index)
+    MlpDwReduce tail, uint32_t snake_levels, const int32_t *__restrict__ sample_index, uint32_t persistent = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (blockIdx.x < n_tail) {   // passengers: the tiny MLPs' weight-gradient reduction (see bin_fill_kernel)
@@ -394,15 +394,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     __shared__ float s_wmax[kFillBlock / 64];
 
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
-    uint32_t level, tile;
-    if (snake_levels) {
-        snake_level_tile(blockIdx.x - n_tail, ntiles, snake_levels, level, tile);
-        if (level == kNoLevel) return;
-    } else {
-        const uint32_t item = xcd_remap(blockIdx.x - n_tail, gridDim.x - n_tail);
-        level = item / ntiles;
-        tile = item - level * ntiles;
-    }
+    auto do_item = [&](uint32_t level, uint32_t tile) {
     const uint32_t b0 = tile * kFillTile;
     if (b0 >= B) return;
     const uint32_t b = b0 + threadIdx.x;
@@ -598,6 +590,30 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
         body(std::true_type{});
     else
         body(std::false_type{});
+    };
+    if (persistent) {
+        // persistent form (as the slab forward's, engine_kernels.hip): the list is as long as the samples the device counts,
+        // not as the capacity the launch was sized for; the workgroups of one XCD stride through that XCD's levels
+        const uint32_t bid = blockIdx.x - n_tail, k = bid & 7u, G8 = (gridDim.x - n_tail) >> 3;
+        const uint32_t tiles = (B + kFillTile - 1u) / kFillTile, len = snake_rounds(snake_levels) * tiles;
+        for (uint32_t it = bid >> 3; it < len; it += G8) {
+            const uint32_t round = it / tiles, t = it - round * tiles;
+            const uint32_t lvl = (round >> 1) * 16u + ((round & 1u) ? 15u - k : k);
+            if (lvl < snake_levels) do_item(lvl, t);
+            __syncthreads();   // (the next item reuses the histogram and the staging area)
+        }
+        return;
+    }
+    uint32_t level, tile;
+    if (snake_levels) {
+        snake_level_tile(blockIdx.x - n_tail, ntiles, snake_levels, level, tile);
+        if (level == kNoLevel) return;
+    } else {
+        const uint32_t item = xcd_remap(blockIdx.x - n_tail, gridDim.x - n_tail);
+        level = item / ntiles;
+        tile = item - level * ntiles;
+    }
+    do_item(level, tile);
 }
 
 // ------------------------------------------------------------------ reduce
@@ -1140,9 +1156,16 @@ static int binned_apply(const char *who, const MlpDwReduce *tail, const int32_t 
         static const bool snake = !(getenv("NGP_SNAKE") && getenv("NGP_SNAKE")[0] == '0') &&
                                   !(getenv("NGP_SNAKE_FILL") && getenv("NGP_SNAKE_FILL")[0] == '0');   // (as the slab forward)
         const bool sn = snake && max_level >= 8;
-        bin_fill_local_kernel<<<(sn ? snake_blocks(max_level, ft) : ft * max_level) + n_tail, kFillBlock, lds, st>>>(
+        // a device-side sample count under the snake: persistent workgroups, as many per CU as the LDS admits (NGP_FILL_WGS
+        // overrides; 0: the capacity-sized grid, whose workgroups are 85 % no-ops late in training -- the live list holds ~ 95 k
+        // of 655 k slots -- dealt to the XCDs in between the ones that work: table backward 123-126 -> 112-114 us between the
+        // bench's events, 0.2836 -> 0.2702 ms/step; 2, 3 and 4 per CU measure the same)
+        static const uint32_t fill_wgs = getenv("NGP_FILL_WGS") ? (uint32_t)atoi(getenv("NGP_FILL_WGS")) : 3u;
+        const bool pers = fill_wgs != 0 && sn && B_dev != nullptr && n_tail % 8u == 0;
+        const uint32_t blocks = pers ? 256u * min(fill_wgs, 8u) : (sn ? snake_blocks(max_level, ft) : ft * max_level);
+        bin_fill_local_kernel<<<blocks + n_tail, kFillBlock, lds, st>>>(
             grad, inputs, offsets, B_dev, B, grad_stride, ft, c.nbins_cap, c.lv, gridtype, align_corners != 0, interp, wl, dir,
-            n_tail, tail ? *tail : MlpDwReduce{}, sn ? max_level : 0u, sample_index);
+            n_tail, tail ? *tail : MlpDwReduce{}, sn ? max_level : 0u, sample_index, pers ? 1u : 0u);
         LocalRecords loc;
         loc.dir = dir;
         loc.B_dev = B_dev;
