@@ -34,6 +34,7 @@ __global__ __launch_bounds__(kBlock) void grid_forward_slab_kernel(
 {
     // level_lo: the launch covers levels level_lo .. level_lo + (levels of the grid) - 1 (ngp_x_grid_encode_forward_slab_levels)
     extern __shared__ uint32_t hist[];
+    // one work item = 256 points of one level (the body keeps the indentation it had as the kernel's own)
     auto do_tile = [&](uint32_t level, uint32_t tile_) {
     const uint32_t b0 = tile_ * kBlock, b = b0 + threadIdx.x;
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;

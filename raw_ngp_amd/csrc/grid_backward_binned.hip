@@ -394,6 +394,7 @@ __global__ __launch_bounds__(kFillBlock) void bin_fill_local_kernel(
     __shared__ float s_wmax[kFillBlock / 64];
 
     const uint32_t B = B_dev ? min((uint32_t)max(B_dev[0], 0), B_cap) : B_cap;
+    // one work item = 512 samples of one level (the body keeps the indentation it had as the kernel's own)
     auto do_item = [&](uint32_t level, uint32_t tile) {
     const uint32_t b0 = tile * kFillTile;
     if (b0 >= B) return;
