@@ -39,3 +39,40 @@ def test_sample_rays_matches_reference_get_rays(orc, golden_dir):
     assert abs(hist - mean).max() < 6 * np.sqrt(mean)
     other = orc.sample_rays(images, g["poses"], g["intrinsics"], N, seed=5, draw=4)
     assert (other["index"] != out["index"]).any(1).mean() > 0.9
+
+
+def test_binned_cell_draws_have_the_law_of_independent_draws(orc):
+    """oracle.density_grid_sample(binned=True) -- the draws the device generates in Morton order -- against binned=False, the
+    independent draws of nerf/renderer.py:851-866 (Philox in place of torch's generator): the same number of draws per half,
+    uniform half sorted by 512-cell block with Poisson(1/4) hits per cell like the independent sample, occupied half only on
+    occupied cells, every one of them about equally often; reproducible; a different draw number gives different cells."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    H = 32
+    cells = H ** 3
+    grid = rng.uniform(-0.5, 3.0, cells).astype(np.float32)
+    grid[rng.random(cells) < 0.4] = -1.0
+    n = cells // 4
+    args = (grid, H, 1.9375, 0.0625, n, n, False, (7 << 32) | 99)
+    bi, bx = orc.density_grid_sample(*args, 3, binned=True)
+    ii, ix = orc.density_grid_sample(*args, 3)
+    assert bi.shape == ii.shape == (2 * n,) and bx.shape == (2 * n, 3)
+    assert np.all(np.diff(bi[:n] >> 3) >= 0)                         # 4096 bins of 8 cells at 32^3
+    occ = np.flatnonzero(grid > 0)
+    for v in (bi, ii):
+        assert np.all(np.isin(v[n:], occ)) and 0 <= v[:n].min() and v[:n].max() < cells
+        hits = np.bincount(np.bincount(v[:n], minlength=cells), minlength=6)[:6]
+        expect = cells * np.exp(-0.25) * 0.25 ** np.arange(6) / np.array([1, 1, 2, 6, 24, 120])
+        assert np.all(np.abs(hits - expect) <= 4 * np.sqrt(expect) + 2)
+        per_cell = np.bincount(v[n:], minlength=cells)[occ]
+        assert abs(per_cell.mean() - n / len(occ)) < 1e-9 and per_cell.max() <= 12
+    rank = np.searchsorted(occ, bi[n:])
+    assert np.all(np.diff(rank) >= -(len(occ) // 4096 + 2))          # Morton order up to a bin's width
+    # positions stay inside their cells: |x - centre| <= half along every axis
+    from oracle.oracle import _compact_bits
+    c = np.stack([_compact_bits(bi.astype(np.uint32) >> np.uint32(k)) for k in range(3)], 1).astype(np.float32)
+    centre = (2 * c / (H - 1) - 1) * np.float32(1.9375)
+    assert np.all(np.abs(bx - centre) <= 0.0625 + 1e-6)
+    again, _ = orc.density_grid_sample(*args, 3, binned=True)
+    other, _ = orc.density_grid_sample(*args, 4, binned=True)
+    assert np.array_equal(again, bi) and not np.array_equal(other, bi)
