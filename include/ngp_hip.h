@@ -429,7 +429,8 @@ int ngp_x_mlp_reduce_dw(uint32_t M, float loss_scale, float *dw1, float *dw2, fl
  *            (the BARF window of network.py:99-109); the backward scales d(enc) by the same weights.  NULL = ones
  *   ddirs    optional [M,3]: d loss / d (un-normalised view direction), through the SH basis' Jacobian
  *            (shencoder.cu:126-350) and d / |d| (renderer.py:541): what raymarching.py:319-329 sums per ray
- * Only the default activations (ReLU, trunc_exp density, clamped_exp colour) are implemented.
+ * Hidden layers are ReLU; the output activations default to trunc_exp density and clamped_exp colour, the *_act entry points
+ * take the reference's others (as ngp_x_mlp_forward_act).
  * ---------------------------------------------------------------------------------- */
 size_t ngp_x_mlp_rf_image_bytes(void);
 int ngp_x_mlp_rf_prepare(const float *w1, const float *w2, const float *w3, const float *w4, const float *w5,
@@ -438,6 +439,11 @@ int ngp_x_mlp_rf_prepare(const float *w1, const float *w2, const float *w3, cons
 int ngp_x_mlp_rf_forward(const float *enc, uint32_t stride, const float *dirs, const float *ldirs, const float *level_w,
                          const int32_t *M_dev, uint32_t M, const void *image, float *sigma, float *rgb,
                          ngp_stream_t stream);
+/* ... with the field's other OUTPUT activations (nerf/network.py:115,131-135): color_act 0 = clamp(exp(x - 5), max 5),
+ * 1 = exp(x - 5), 2 = sigmoid; density_act 0 = trunc_exp, 1 = softplus(beta, threshold 20) */
+int ngp_x_mlp_rf_forward_act(const float *enc, uint32_t stride, const float *dirs, const float *ldirs, const float *level_w,
+                             const int32_t *M_dev, uint32_t M, const void *image, float *sigma, float *rgb,
+                             uint32_t color_act, uint32_t density_act, float beta, ngp_stream_t stream);
 size_t ngp_x_mlp_rf_backward_workspace_bytes(uint32_t M);
 /* outputs: d(enc) (slab layout, rows >= M untouched), ddirs (optional), six weight gradients (OVERWRITTEN) */
 int ngp_x_mlp_rf_backward(const float *enc, uint32_t stride, const float *dirs, const float *ldirs, const float *level_w,
@@ -450,6 +456,13 @@ int ngp_x_mlp_rf_backward_list(const float *enc, uint32_t stride, const float *d
                                const int32_t *sample_index, const void *image, float loss_scale, float *denc, float *ddirs,
                                float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6, void *workspace,
                                size_t workspace_bytes, float *loss_scaler, ngp_stream_t stream);
+/* ... with the output activations of ngp_x_mlp_rf_forward_act: their derivatives enter the output deltas */
+int ngp_x_mlp_rf_backward_act(const float *enc, uint32_t stride, const float *dirs, const float *ldirs, const float *level_w,
+                              const float *dsigma, const float *drgb, const int32_t *M_dev, uint32_t M,
+                              const int32_t *sample_index, const void *image, float loss_scale, float *denc, float *ddirs,
+                              float *dw1, float *dw2, float *dw3, float *dw4, float *dw5, float *dw6, void *workspace,
+                              size_t workspace_bytes, float *loss_scaler, uint32_t color_act, uint32_t density_act,
+                              float beta, ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Kernels of the fused training step (csrc/engine_kernels.hip; host side raw_ngp_amd/nerf/engine.py).

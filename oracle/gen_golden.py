@@ -452,7 +452,11 @@ def main():
                               ("plain_exp_softplus", False, dict(color_activation="exp", density_activation="softplus", beta=2.0)),
                               ("plain_sigmoid", False, dict(color_activation="sigmoid")),
                               ("plain_softplus_hidden", False, dict(internal_activation="softplus", density_activation="softplus",
-                                                                   beta=2.0))):
+                                                                   beta=2.0)),
+                              # (the light-conditioned field with the other output activations: ngp_x_mlp_rf_forward_act / _backward_act)
+                              ("rfield_sigmoid_softplus", True, dict(color_activation="sigmoid", density_activation="softplus",
+                                                                     beta=2.0)),
+                              ("rfield_exp", True, dict(color_activation="exp"))):
         fopt = types.SimpleNamespace(**{**base, "rfield": rfield, "pose_opt": "none", **acts})
         torch.manual_seed(3 if rfield else 2)
         net = NW.NeRFNetwork(fopt)

@@ -72,6 +72,9 @@ _SIGNATURES = {
     "ngp_x_mlp_reduce_dw": [_u, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p, _p, _p, _u, _p, _f, _f, _f, _p, _p],
     "ngp_x_mlp_rf_prepare": [_p, _p, _p, _p, _p, _p, _p],
     "ngp_x_mlp_rf_forward": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _p],
+    "ngp_x_mlp_rf_forward_act": [_p, _u, _p, _p, _p, _p, _u, _p, _p, _p, _u, _u, _f],
+    "ngp_x_mlp_rf_backward_act": [_p, _u, _p, _p, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                  ctypes.c_size_t, _p, _u, _u, _f],
     "ngp_x_mlp_rf_backward": [_p, _u, _p, _p, _p, _p, _p, _p, _u, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                               ctypes.c_size_t],
     "ngp_x_mlp_rf_backward_list": [_p, _u, _p, _p, _p, _p, _p, _p, _u, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
@@ -793,10 +796,17 @@ class _MlpRfBackend:
               image.data_ptr())
 
     @staticmethod
-    def forward(enc, stride, dirs, ldirs, level_w, M_dev, M, image, sigma, rgb):
-        _call("ngp_x_mlp_rf_forward", enc, _ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs", True),
-              _ptr(ldirs, "f", "ldirs", True), _ptr(level_w, "f", "level_w", True), _ptr(M_dev, "i", "M_dev", True), M,
-              image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb", True))
+    def forward(enc, stride, dirs, ldirs, level_w, M_dev, M, image, sigma, rgb, act=None):
+        """act = (color_act, density_act, beta[, internal_act = 0]): the field's non-default OUTPUT activations."""
+        args = [_ptr(enc, "f", "enc"), stride, _ptr(dirs, "f", "dirs", True),
+                _ptr(ldirs, "f", "ldirs", True), _ptr(level_w, "f", "level_w", True), _ptr(M_dev, "i", "M_dev", True), M,
+                image.data_ptr(), _ptr(sigma, "f", "sigma"), _ptr(rgb, "f", "rgb", True)]
+        if _default_act(act):
+            _call("ngp_x_mlp_rf_forward", enc, *args)
+        else:
+            if len(act) > 3 and act[3]:
+                raise RuntimeError("mlp_rf forward: the light-conditioned field's hidden layers are ReLU")
+            _call("ngp_x_mlp_rf_forward_act", enc, *args, int(act[0]), int(act[1]), float(act[2]), probe_as="ngp_x_mlp_rf_forward")
 
     @staticmethod
     def density_gradient(enc, stride, M_dev, M, image, denc, level_w=None):
@@ -811,8 +821,9 @@ class _MlpRfBackend:
 
     @staticmethod
     def backward(enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, image, loss_scale, denc, ddirs, dws,
-                 workspace=None, sample_index=None, scaler=None):
-        """sample_index (int32, optional): run over a LIST of M_dev[0] samples -- inputs and ddirs by sample, denc in list order."""
+                 workspace=None, sample_index=None, scaler=None, act=None):
+        """sample_index (int32, optional): run over a LIST of M_dev[0] samples -- inputs and ddirs by sample, denc in list order.
+        act: as forward."""
         nbytes = load().ngp_x_mlp_rf_backward_workspace_bytes(M)
         ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
         if ws.numel() < nbytes or not ws.is_cuda:
@@ -822,7 +833,12 @@ class _MlpRfBackend:
                 _ptr(drgb, "f", "drgb"), _ptr(M_dev, "i", "M_dev", True), M]
         tail = [image.data_ptr(), float(loss_scale), _ptr(denc, "f", "denc"), _ptr(ddirs, "f", "ddirs", True),
                 *[_ptr(w, "f", f"dw{i + 1}") for i, w in enumerate(dws)], ws.data_ptr(), nbytes]
-        if sample_index is not None or scaler is not None:
+        if not _default_act(act):
+            if len(act) > 3 and act[3]:
+                raise RuntimeError("mlp_rf backward: the light-conditioned field's hidden layers are ReLU")
+            _call("ngp_x_mlp_rf_backward_act", enc, *head, _ptr(sample_index, "i", "sample_index", True), *tail,
+                  _scaler_ptr(scaler), int(act[0]), int(act[1]), float(act[2]), probe_as="ngp_x_mlp_rf_backward")
+        elif sample_index is not None or scaler is not None:
             _call("ngp_x_mlp_rf_backward_list", enc, *head, _ptr(sample_index, "i", "sample_index", True), *tail,
                   _scaler_ptr(scaler), probe_as="ngp_x_mlp_rf_backward")
         else:

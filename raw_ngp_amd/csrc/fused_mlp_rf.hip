@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void mlp_rf_forward_kernel(const float *__r
                                                                const float *__restrict__ level_w,
                                                                const int32_t *__restrict__ M_dev, uint32_t M_host,
                                                                const half8 *__restrict__ image,
-                                                               float *__restrict__ sigma, float *__restrict__ rgb)
+                                                               float *__restrict__ sigma, float *__restrict__ rgb,
+                                                               FieldAct act = FieldAct{})
 {
     extern __shared__ half8 lds_w[];   // fragments 0..44: every forward block
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void mlp_rf_forward_kernel(const float *__r
         const f32x16 o = density_mlp(lds_w, lane, x0);
         const float sigma_raw = o[0];
         if (rgb == nullptr) {   // density-only query (density-grid refresh)
-            if (valid && h == 0) sigma[row] = __expf(sigma_raw);
+            if (valid && h == 0) sigma[row] = act_sigma(sigma_raw, act);
             continue;
         }
         const half8 x3a = pack<0, false>(o);
@@ -249,10 +250,11 @@ __global__ __launch_bounds__(256, 2) void mlp_rf_forward_kernel(const float *__r
         half8 h3[5], h4[5];
         const f32x16 c = view_mlp(lds_w, lane, x3a, shd, shl, h3, h4);
         if (valid && h == 0) {
-            sigma[row] = __expf(sigma_raw);
-            rgb[(size_t)row * 3 + 0] = fminf(__expf(c[0] - 5.0f), 5.0f);
-            rgb[(size_t)row * 3 + 1] = fminf(__expf(c[1] - 5.0f), 5.0f);
-            rgb[(size_t)row * 3 + 2] = fminf(__expf(c[2] - 5.0f), 5.0f);
+            // (the field's output activations, network.py:115,131-135; the defaults are trunc_exp and clamp(exp(x - 5), max 5))
+            sigma[row] = act_sigma(sigma_raw, act);
+            rgb[(size_t)row * 3 + 0] = act_color(c[0], act);
+            rgb[(size_t)row * 3 + 1] = act_color(c[1], act);
+            rgb[(size_t)row * 3 + 2] = act_color(c[2], act);
         }
     }
 }
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
     const float *__restrict__ level_w, const float *__restrict__ dsigma, const float *__restrict__ drgb,
     const int32_t *__restrict__ M_dev, uint32_t M_host, const half8 *__restrict__ image, float loss_scale_host,
     half8 *__restrict__ d3buf, half8 *__restrict__ scratch, float *__restrict__ ddirs, float *__restrict__ partial,
-    const int32_t *__restrict__ live_idx, const float *__restrict__ scaler)
+    const int32_t *__restrict__ live_idx, const float *__restrict__ scaler, FieldAct act = FieldAct{})
 {
     extern __shared__ half8 lds_w[];   // fragments 0..67 (68 KiB); reused as the f32 reduction image at the end
     // (scaler: the dynamic loss scale, as in fused_mlp_backward.hip's view kernel)
@@ -336,11 +338,11 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
 
         // ---------------- output deltas (scaled so that they survive f16)
         f32x16 d6 = zero16();
-        if (h == 0) {   // d rgb / d raw = exp(raw - 5) where the clamp at 5 is inactive
-            const float e0 = __expf(c[0] - 5.0f), e1 = __expf(c[1] - 5.0f), e2 = __expf(c[2] - 5.0f);
-            d6[0] = e0 <= 5.0f ? gr0 * e0 * loss_scale : 0.0f;
-            d6[1] = e1 <= 5.0f ? gr1 * e1 * loss_scale : 0.0f;
-            d6[2] = e2 <= 5.0f ? gr2 * e2 * loss_scale : 0.0f;
+        if (h == 0) {   // d rgb / d raw (default: exp(raw - 5) where the clamp at 5 is inactive, else 0)
+            const float e0 = act_dcolor(c[0], act), e1 = act_dcolor(c[1], act), e2 = act_dcolor(c[2], act);
+            d6[0] = e0 != 0.0f ? gr0 * e0 * loss_scale : 0.0f;
+            d6[1] = e1 != 0.0f ? gr1 * e1 * loss_scale : 0.0f;
+            d6[2] = e2 != 0.0f ? gr2 * e2 * loss_scale : 0.0f;
         }
         const half8 p6 = pack_sat<0>(d6, lim);
 
@@ -386,8 +388,8 @@ __global__ __launch_bounds__(256, 1) void mlp_rf_backward_v1_kernel(
         f32x16 dx3 = zero16();
 #pragma unroll
         for (int kk = 0; kk < 5; kk++) dx3 = mfma(RF_FRAG(RF_T4 + kk), p4[kk], dx3);
-        // delta3 row 0 = d sigma_raw = dsigma * exp(clamp(raw, -80, 80))   (trunc_exp backward)
-        if (h == 0) dx3[0] = gs * __expf(fminf(fmaxf(sigma_raw, -80.0f), 80.0f)) * loss_scale;
+        // delta3 row 0 = d sigma_raw = dsigma * d sigma / d raw   (default: exp(clamp(raw, -80, 80)), trunc_exp's backward)
+        if (h == 0) dx3[0] = gs * act_dsigma(sigma_raw, act) * loss_scale;
         if (valid) d3buf[(size_t)c_idx * 2 + h] = pack_sat<0>(dx3, lim);
 
         if (ddirs) {   // d loss / d (un-normalised view direction)
@@ -604,14 +606,27 @@ extern "C" int ngp_x_mlp_rf_forward(const float *enc, uint32_t stride, const flo
                                     const float *level_w, const int32_t *M_dev, uint32_t M, const void *image,
                                     float *sigma, float *rgb, ngp_stream_t stream)
 {
+    return ngp_x_mlp_rf_forward_act(enc, stride, dirs, ldirs, level_w, M_dev, M, image, sigma, rgb, 0, 0, 1.0f, stream);
+}
+
+// ... with the field's other OUTPUT activations (as ngp_x_mlp_forward_act: color_act 0 clamped_exp / 1 exp / 2 sigmoid,
+// density_act 0 trunc_exp / 1 softplus(beta, threshold 20)); the hidden layers of this field are ReLU
+extern "C" int ngp_x_mlp_rf_forward_act(const float *enc, uint32_t stride, const float *dirs, const float *ldirs,
+                                        const float *level_w, const int32_t *M_dev, uint32_t M, const void *image,
+                                        float *sigma, float *rgb, uint32_t color_act, uint32_t density_act, float beta,
+                                        ngp_stream_t stream)
+{
     if (M == 0) return NGP_OK;
+    NGP_REQUIRE(color_act <= 2u && density_act <= 1u && beta > 0.0f, "mlp_rf_forward: unknown activation or beta <= 0");
+    FieldAct act;
+    act.color = color_act, act.density = density_act, act.beta = beta, act.internal = 0;
     NGP_REQUIRE(enc && image && sigma, "mlp_rf_forward: null tensor");
     NGP_REQUIRE(rgb == nullptr || (dirs && ldirs), "mlp_rf_forward: dirs / ldirs missing");
     NGP_REQUIRE(stride >= M, "mlp_rf_forward: encoder slab stride smaller than M");
     const uint32_t tiles = ceil_div(M, 32u);
     const uint32_t blocks = min(ceil_div(tiles, 4u), 256u * 2u);
     mlp_rf_forward_kernel<<<dim3(blocks), dim3(256), (size_t)RF_T6 * 1024, as_stream(stream)>>>(
-        enc, stride, dirs, ldirs, level_w, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb);
+        enc, stride, dirs, ldirs, level_w, M_dev, M, reinterpret_cast<const half8 *>(image), sigma, rgb, act);
     NGP_CHECK_LAUNCH("mlp_rf_forward");
     return NGP_OK;
 }
@@ -649,6 +664,23 @@ extern "C" int ngp_x_mlp_rf_backward_list(const float *enc, uint32_t stride, con
                                           float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
                                           float *loss_scaler, ngp_stream_t stream)
 {
+    return ngp_x_mlp_rf_backward_act(enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, sample_index, image, loss_scale,
+                                     denc, ddirs, dw1, dw2, dw3, dw4, dw5, dw6, workspace, workspace_bytes, loss_scaler, 0, 0,
+                                     1.0f, stream);
+}
+
+// ... with the output activations of ngp_x_mlp_rf_forward_act (their derivatives enter the output deltas)
+extern "C" int ngp_x_mlp_rf_backward_act(const float *enc, uint32_t stride, const float *dirs, const float *ldirs,
+                                         const float *level_w, const float *dsigma, const float *drgb,
+                                         const int32_t *M_dev, uint32_t M, const int32_t *sample_index, const void *image,
+                                         float loss_scale, float *denc, float *ddirs, float *dw1, float *dw2, float *dw3,
+                                         float *dw4, float *dw5, float *dw6, void *workspace, size_t workspace_bytes,
+                                         float *loss_scaler, uint32_t color_act, uint32_t density_act, float beta,
+                                         ngp_stream_t stream)
+{
+    NGP_REQUIRE(color_act <= 2u && density_act <= 1u && beta > 0.0f, "mlp_rf_backward: unknown activation or beta <= 0");
+    FieldAct act;
+    act.color = color_act, act.density = density_act, act.beta = beta, act.internal = 0;
     NGP_REQUIRE(image && workspace && dw1 && dw2 && dw3 && dw4 && dw5 && dw6, "mlp_rf_backward: null tensor");
     NGP_REQUIRE(M == 0 || (enc && dirs && ldirs && dsigma && drgb && denc), "mlp_rf_backward: null sample tensor");
     NGP_REQUIRE(stride >= M, "mlp_rf_backward: encoder slab stride smaller than M");
@@ -675,7 +707,7 @@ extern "C" int ngp_x_mlp_rf_backward_list(const float *enc, uint32_t stride, con
     const half8 *img = reinterpret_cast<const half8 *>(image);
     mlp_rf_backward_v1_kernel<<<dim3(blocks), dim3(256), kV1Lds, st>>>(
         enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, loss_scale, d3buf, scratch, ddirs, part_v1, sample_index,
-        loss_scaler);
+        loss_scaler, act);
     mlp_rf_backward_v2_kernel<<<dim3(blocks), dim3(256), kV2Lds, st>>>(
         enc, stride, dirs, ldirs, level_w, dsigma, drgb, M_dev, M, img, scratch, part_v2, sample_index);
     const int rc = launch_mlp_backward_grid(enc, stride, level_w, M_dev, M, img, RF_T3, 1.0f / loss_scale, d3buf, denc,

@@ -97,9 +97,9 @@ class FusedTrainer:
         from .._lib import field_activations, _default_act
         act = field_activations(opt)
         self.act = None if _default_act(act) else act
-        assert self.act is None or not (self.rfield or self.pose or float(getattr(opt, "lambda_orientation", 0.0)) > 0), \
-            "fused step: softplus hidden layers / density, exp / sigmoid colour are built for the plain field without pose " \
-            "refinement and without the orientation term"
+        assert self.act is None or not ((self.pose and not self.rfield) or float(getattr(opt, "lambda_orientation", 0.0)) > 0), \
+            "fused step: the non-default activations are built for the plain field without pose refinement, for the " \
+            "light-conditioned field (output activations only), and without the orientation term"
         self.rank, self.world_size = parallel.rank(), parallel.world_size()
         # data-parallel step (separate Adam pass, gradient collectives); `dp_rehearsal` runs it on one rank as well
         self.dp = self.world_size > 1 or (bool(getattr(opt, "dp_rehearsal", False)) and parallel.is_dist())
@@ -403,7 +403,8 @@ class FusedTrainer:
         if self.rfield:
             if self.baa:            # f'_l = w_l f_l + (1 - w_l) f_c on the slab, in place
                 eb.slab_window(self.enc, stride, self.L, self.level_w, cnt, M)
-            self.mb.forward(self.enc, stride, dirs, ldirs, None if self.baa else self.level_w, cnt, M, self.mlp_image, sigma, rgb)
+            self.mb.forward(self.enc, stride, dirs, ldirs, None if self.baa else self.level_w, cnt, M, self.mlp_image, sigma, rgb,
+                            act=self.act)
         else:
             if self.pose:           # the plain field kernels carry no level window: BARF scale / BAA blend on the slab
                 eb.slab_window(self.enc, stride, self.L, self.level_w, cnt, M, scale_only=not self.baa)
@@ -506,7 +507,7 @@ class FusedTrainer:
             if self.rfield:         # one call: both view kernels, the density kernel, the weight-gradient reduction
                 self.mb.backward(self.enc, cap, ar.dirs, ar.ldirs, None if self.baa else self.level_w, self.dsigma, self.drgb,
                                  back_n, cap, self.mlp_image, opt.loss_scale, self.denc, self.ddirs if self.pose else None,
-                                 self.dws, self.ws_mlp, sample_index=back_idx, scaler=self.scaler)
+                                 self.dws, self.ws_mlp, sample_index=back_idx, scaler=self.scaler, act=self.act)
                 if self.baa:        # the blend's adjoint: d enc' -> d enc (what the table backward and the ray gradients read)
                     eb.slab_window(self.denc, cap, self.L, self.level_w, back_n, cap, backward=True)
             else:

@@ -130,14 +130,15 @@ class NeRFNetwork(NeRFRenderer):
     # -- fused MFMA path (extension; Options.fused_mlp) ------------------------------------------
     def _fused(self, plain_only=False):
         """The field configuration the MFMA kernels implement: ReLU hidden layers, trunc_exp density and clamped_exp colour, and
-        -- for the plain field -- the reference's other activations (softplus hidden layers / density, exp / sigmoid colour:
-        network.py:31-34,115,131-135).
+        the reference's other activations (network.py:31-34,115,131-135): softplus density and exp / sigmoid colour for both
+        fields, softplus hidden layers for the plain one.
         plain_only: additionally the 31-input view MLP without level windows -- what the autograd op `fused_field`
         covers; the light-conditioned / BARF variants exist for the fused training step only (nerf/engine.py)."""
         from .._lib import field_activations, _default_act
         o = self.opt
         act = field_activations(o)
-        ok = (getattr(o, "fused_mlp", False) and act is not None and (_default_act(act) or not o.rfield)
+        # (the light-conditioned field: other OUTPUT activations yes, softplus hidden layers no)
+        ok = (getattr(o, "fused_mlp", False) and act is not None and (_default_act(act) or not o.rfield or act[3] == 0)
               and self.grid_encoder.embeddings.is_cuda)
         if plain_only:
             ok = ok and not o.rfield and o.pose_opt == "none"

@@ -111,16 +111,24 @@ def _fused_setup(pose_opt, iters, views=24, noise=0.03, rays=2048, image_mode="L
     return P, data, FusedTrainer(opt, NeRFNetwork(opt), data, device=dev, seed=seed, capacity=rays * 200)
 
 
+@pytest.mark.parametrize("acts", [{}, dict(color_activation="sigmoid", density_activation="softplus", beta=2.0)],
+                         ids=["", "sigmoid+softplus"])
 @pytest.mark.parametrize("orient", [0.0, 3e-2], ids=["", "orientation-term"])
 @pytest.mark.parametrize("pose_opt,rfield", [("barf", True), ("baangp", True), ("barf", False), ("baangp", False)])
-def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield, orient):
+def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield, orient, acts):
     """One batch through the fused light-conditioned + BARF (or BAA-NGP) step and through the per-op autograd path (torch
     MLPs in fp32, the reference's call sequence over the `_backend` shims) with the same weights, rays and sample jitter: the
     se(3) gradient, the MLP weight gradients and the loss must agree to what f16 MFMA operands allow.
     orientation-term: with lambda_orientation > 0 (renderer.py:558-571) -- the term reaches the cameras through the weights
-    and through the view directions; its normals are constants."""
+    and through the view directions; its normals are constants.
+    sigmoid+softplus: the light-conditioned field with the reference's other output activations (network.py:115,131-135:
+    ngp_x_mlp_rf_forward_act / _backward_act inside the fused step; torch's own sigmoid / softplus on the per-op side)."""
     from raw_ngp_amd.nerf import pose as Pm
-    P, data, ft = _fused_setup(pose_opt, iters=300, views=6, noise=0.05, rays=1024, rfield=rfield, lambda_orientation=orient)
+    if acts and (orient or not rfield or pose_opt != "barf"):
+        pytest.skip("the non-default activations of the fused step: light-conditioned field, no orientation term")
+    P, data, ft = _fused_setup(pose_opt, iters=300, views=6, noise=0.05, rays=1024, rfield=rfield, lambda_orientation=orient,
+                               **acts)
+    assert (ft.act is not None) == bool(acts)
     model, opt = ft.model, ft.opt
     for _ in range(40):                                  # a few steps so that the field is not flat any more
         ft.train_step()

@@ -40,16 +40,19 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-@pytest.mark.parametrize("tag", ["plain", "rfield", "plain_exp_softplus", "plain_sigmoid", "plain_softplus_hidden"])
+@pytest.mark.parametrize("tag", ["plain", "rfield", "plain_exp_softplus", "plain_sigmoid", "plain_softplus_hidden",
+                                 "rfield_sigmoid_softplus", "rfield_exp"])
 def test_fused_field_matches_the_reference_network(golden_dir, tag):
     """The reference's NeRFNetwork.forward + autograd on CPU (oracle/gen_golden.py: its own MLP class and activations) against
     the fused MFMA kernels.  plain_exp_softplus / plain_sigmoid: the reference's other OUTPUT activations (network.py:115,
-    131-135: softplus density with beta = 2 + exp colour; sigmoid colour) through ngp_x_mlp_forward_act / _backward_act."""
+    131-135: softplus density with beta = 2 + exp colour; sigmoid colour) through ngp_x_mlp_forward_act / _backward_act;
+    rfield_*: the same for the light-conditioned field (ngp_x_mlp_rf_forward_act / _backward_act)."""
     from raw_ngp_amd import _lib
     g = np.load(os.path.join(golden_dir, f"field_{tag}.npz"))
-    rf = tag == "rfield"
+    rf = tag.startswith("rfield")
     # (colour, density, beta, hidden layers): plain_softplus_hidden = internal_activation softplus (network.py:31-34) + softplus density
-    act = {"plain_exp_softplus": (1, 1, 2.0, 0), "plain_sigmoid": (2, 0, 1.0, 0), "plain_softplus_hidden": (0, 1, 2.0, 1)}.get(tag)
+    act = {"plain_exp_softplus": (1, 1, 2.0, 0), "plain_sigmoid": (2, 0, 1.0, 0), "plain_softplus_hidden": (0, 1, 2.0, 1),
+           "rfield_sigmoid_softplus": (2, 1, 2.0, 0), "rfield_exp": (1, 0, 1.0, 0)}.get(tag)
     mb = _lib.mlp_rf_backend if rf else _lib.mlp_backend
     W = [dev(g[f"w{i}"]) for i in range(1, 7)]
     assert tuple(W[3].shape) == ((80, 47) if rf else (64, 31))
@@ -60,7 +63,7 @@ def test_fused_field_matches_the_reference_network(golden_dir, tag):
     mb.prepare(W, image)
     sigma, rgb = torch.empty(M, device="cuda"), torch.empty(M, 3, device="cuda")
     if rf:
-        mb.forward(enc, M, dirs, ldirs, None, None, M, image, sigma, rgb)
+        mb.forward(enc, M, dirs, ldirs, None, None, M, image, sigma, rgb, act=act)
     else:
         mb.forward(enc, M, dirs, None, M, image, sigma, rgb, act=act)
     np.testing.assert_allclose(sigma.cpu().numpy(), g["sigma"], rtol=3e-2, atol=1e-4)
@@ -68,7 +71,7 @@ def test_fused_field_matches_the_reference_network(golden_dir, tag):
     denc = torch.empty(16, M, 2, device="cuda")
     dws = [torch.empty_like(w) for w in W]
     if rf:
-        mb.backward(enc, M, dirs, ldirs, None, dev(g["dsigma"]), dev(g["drgb"]), None, M, image, 1024.0, denc, None, dws)
+        mb.backward(enc, M, dirs, ldirs, None, dev(g["dsigma"]), dev(g["drgb"]), None, M, image, 1024.0, denc, None, dws, act=act)
     else:
         mb.backward(enc, M, dirs, dev(g["dsigma"]), dev(g["drgb"]), None, M, image, 1024.0, denc, dws, act=act)
     got = denc.permute(1, 0, 2).reshape(M, 32).cpu().numpy()
