@@ -97,9 +97,8 @@ class FusedTrainer:
         from .._lib import field_activations, _default_act
         act = field_activations(opt)
         self.act = None if _default_act(act) else act
-        assert self.act is None or not ((self.pose and not self.rfield) or float(getattr(opt, "lambda_orientation", 0.0)) > 0), \
-            "fused step: the non-default activations are built for the plain field without pose refinement, for the " \
-            "light-conditioned field (output activations only), and without the orientation term"
+        assert self.act is None or not float(getattr(opt, "lambda_orientation", 0.0)) > 0, \
+            "fused step: the non-default activations are built without the orientation term (its normal uses trunc_exp's derivative)"
         self.rank, self.world_size = parallel.rank(), parallel.world_size()
         # data-parallel step (separate Adam pass, gradient collectives); `dp_rehearsal` runs it on one rank as well
         self.dp = self.world_size > 1 or (bool(getattr(opt, "dp_rehearsal", False)) and parallel.is_dist())

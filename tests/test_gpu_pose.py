@@ -121,11 +121,12 @@ def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield, orien
     se(3) gradient, the MLP weight gradients and the loss must agree to what f16 MFMA operands allow.
     orientation-term: with lambda_orientation > 0 (renderer.py:558-571) -- the term reaches the cameras through the weights
     and through the view directions; its normals are constants.
-    sigmoid+softplus: the light-conditioned field with the reference's other output activations (network.py:115,131-135:
-    ngp_x_mlp_rf_forward_act / _backward_act inside the fused step; torch's own sigmoid / softplus on the per-op side)."""
+    sigmoid+softplus: both fields with the reference's other output activations (network.py:115,131-135: ngp_x_mlp_rf_forward_act
+    / _backward_act, ngp_x_mlp_forward_act / _backward_act with d dirs, inside the fused step; torch's own sigmoid / softplus
+    on the per-op side)."""
     from raw_ngp_amd.nerf import pose as Pm
-    if acts and (orient or not rfield or pose_opt != "barf"):
-        pytest.skip("the non-default activations of the fused step: light-conditioned field, no orientation term")
+    if acts and (orient or pose_opt != "barf"):
+        pytest.skip("the non-default activations of the fused step: without the orientation term (one window kind is enough)")
     P, data, ft = _fused_setup(pose_opt, iters=300, views=6, noise=0.05, rays=1024, rfield=rfield, lambda_orientation=orient,
                                **acts)
     assert (ft.act is not None) == bool(acts)
