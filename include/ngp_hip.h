@@ -666,6 +666,11 @@ int ngp_x_composite_train_terms(const float *gt_rgba, const float *bg_rgb, float
 int ngp_x_orientation_term(const float *dh_denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
                            const float *sigmas, const float *dirs, const int32_t *M_dev, uint32_t M, float *term,
                            float *dterm_ddirs, ngp_stream_t stream);
+/* ... for a softplus density (nerf/network.py:115; density_act 1, beta as in ngp_x_mlp_forward_act): d sigma / d h0 =
+ * sigmoid(beta h0) = 1 - exp(-beta sigma) */
+int ngp_x_orientation_term_act(const float *dh_denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
+                           const float *sigmas, const float *dirs, const int32_t *M_dev, uint32_t M, float *term,
+                           float *dterm_ddirs, uint32_t density_act, float beta, ngp_stream_t stream);
 /* dterm_ddirs (optional, [M,3]) <- d term[i] / d dirs[i] (un-normalised direction; the normal is a constant, as in the
  * reference, whose autograd.grad runs without create_graph) */
 

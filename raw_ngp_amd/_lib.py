@@ -95,6 +95,7 @@ _SIGNATURES = {
     "ngp_x_composite_train_terms": [_p, _p, _f, _p, _p, _f, _p, _f, _p, _f, _p, _p, _p, _p, _u, _u, _f, _p, _p, _p, _p, _p,
                                     _p, _p, _p, _p, _p, _p],
     "ngp_x_orientation_term": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _p, _p],
+    "ngp_x_orientation_term_act": [_p, _p, _u, _u, _f, _p, _p, _p, _u, _p, _p, _u, _f],
     "ngp_x_ray_gradients_terms": [_p, _p, _u, _u, _f, _p, _p, _p, _p, _p, _p, _p, _u, _u, _p, _p],
     "ngp_x_mlp_density_gradient": [_p, _u, _p, _u, _p, _p],
     "ngp_x_mlp_rf_density_gradient": [_p, _u, _p, _p, _u, _p, _p],
@@ -989,13 +990,17 @@ class _EngineBackend:
               _ptr(M_dev, "i", "M_dev", True), int(M), 2 if scale_only else int(bool(backward)))
 
     @staticmethod
-    def orientation_term(dh_denc, dydx, stride, L, bound, sigmas, dirs, M_dev, M, term, dterm_ddirs=None):
+    def orientation_term(dh_denc, dydx, stride, L, bound, sigmas, dirs, M_dev, M, term, dterm_ddirs=None, act=None):
         """term [M] <- min(0, n . -v)^2 per sample with n = (-normalize(d sigma / d xyz) + 1) / 2 (nerf/renderer.py:558-571);
         dh_denc: mlp_backend.density_gradient's slab, dydx: the Jacobian slab of grid_encode_forward_slab.
-        dterm_ddirs [M,3] (optional) <- d term / d dirs."""
-        _call("ngp_x_orientation_term", term, _ptr(dh_denc, "f", "dh_denc"), _ptr(dydx, "f", "dydx"), stride, L, float(bound),
-              _ptr(sigmas, "f", "sigmas"), _ptr(dirs, "f", "dirs"), _ptr(M_dev, "i", "M_dev", True), M, _ptr(term, "f", "term"),
-              _ptr(dterm_ddirs, "f", "dterm_ddirs", True))
+        dterm_ddirs [M,3] (optional) <- d term / d dirs.  act: the field's activations (a softplus density changes d sigma / d h0)."""
+        args = [_ptr(dh_denc, "f", "dh_denc"), _ptr(dydx, "f", "dydx"), stride, L, float(bound),
+                _ptr(sigmas, "f", "sigmas"), _ptr(dirs, "f", "dirs"), _ptr(M_dev, "i", "M_dev", True), M, _ptr(term, "f", "term"),
+                _ptr(dterm_ddirs, "f", "dterm_ddirs", True)]
+        if act is not None and int(act[1]) != 0:
+            _call("ngp_x_orientation_term_act", term, *args, int(act[1]), float(act[2]), probe_as="ngp_x_orientation_term")
+        else:
+            _call("ngp_x_orientation_term", term, *args)
 
     @staticmethod
     def ray_gradients(denc, dydx, stride, L, bound, ddirs, ts, rays, N, M, grad_rays_o, grad_rays_d, live=None, terms=None):

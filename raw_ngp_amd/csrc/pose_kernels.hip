@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void orientation_term_kernel(const float *__re
                                                                uint32_t stride, uint32_t L, float inv_2bound,
                                                                const float *__restrict__ sigmas, const float *__restrict__ dirs,
                                                                const int32_t *__restrict__ M_dev, uint32_t M_cap,
-                                                               float *__restrict__ term, float *__restrict__ dterm_ddirs)
+                                                               float *__restrict__ term, float *__restrict__ dterm_ddirs,
+                                                               float softplus_beta)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t M = M_dev ? min((uint32_t)max(M_dev[0], 0), M_cap) : M_cap;
@@ -196,8 +197,12 @@ __global__ __launch_bounds__(256) void orientation_term_kernel(const float *__re
             g[d] = fmaf(ge.y, jj.y, g[d]);
         }
     }
-    // exp(clamp(h0, -80, 80)) (activation.py:20) from sigma = exp(h0)
-    const float k = fminf(fmaxf(sigmas[i], 1.8048513878454153e-35f), 5.5406223843935098e+34f) * inv_2bound;
+    // d sigma / d h0 from sigma itself: exp(clamp(h0, -80, 80)) (activation.py:20) for sigma = exp(h0); for a softplus density
+    // (network.py:115: softplus(h0, beta, threshold 20)) sigmoid(beta h0) = 1 - exp(-beta sigma), 1 in the linear region
+    const float sg = sigmas[i];
+    const float dact = softplus_beta > 0.0f ? (softplus_beta * sg > 20.0f ? 1.0f : 1.0f - __expf(-softplus_beta * sg))
+                                            : fminf(fmaxf(sg, 1.8048513878454153e-35f), 5.5406223843935098e+34f);
+    const float k = dact * inv_2bound;
     const float v0 = g[0] * k, v1 = g[1] * k, v2 = g[2] * k;
     const float inv = 1.0f / fmaxf(sqrtf(v0 * v0 + v1 * v1 + v2 * v2), 1e-12f);      // F.normalize
     const float d0 = dirs[(size_t)i * 3], d1 = dirs[(size_t)i * 3 + 1], d2 = dirs[(size_t)i * 3 + 2];
@@ -534,11 +539,21 @@ extern "C" int ngp_x_orientation_term(const float *dh_denc, const float *dydx, u
                                       const float *sigmas, const float *dirs, const int32_t *M_dev, uint32_t M, float *term,
                                       float *dterm_ddirs, ngp_stream_t stream)
 {
+    return ngp_x_orientation_term_act(dh_denc, dydx, stride, L, bound, sigmas, dirs, M_dev, M, term, dterm_ddirs, 0, 1.0f, stream);
+}
+
+// ... for a field whose density activation is softplus(beta, threshold 20) (density_act 1; 0: trunc_exp, the entry above)
+extern "C" int ngp_x_orientation_term_act(const float *dh_denc, const float *dydx, uint32_t stride, uint32_t L, float bound,
+                                          const float *sigmas, const float *dirs, const int32_t *M_dev, uint32_t M, float *term,
+                                          float *dterm_ddirs, uint32_t density_act, float beta, ngp_stream_t stream)
+{
     if (M == 0) return NGP_OK;
+    NGP_REQUIRE(density_act <= 1u && beta > 0.0f, "orientation_term: unknown density activation or beta <= 0");
     NGP_REQUIRE(dh_denc && dydx && sigmas && dirs && term, "orientation_term: null tensor");
     NGP_REQUIRE(stride >= M && bound > 0.0f && L >= 1, "orientation_term: bad stride / bound / L");
     orientation_term_kernel<<<dim3(ceil_div(M, 256u)), dim3(256), 0, as_stream(stream)>>>(
-        dh_denc, dydx, stride, L, 1.0f / (2.0f * bound), sigmas, dirs, M_dev, M, term, dterm_ddirs);
+        dh_denc, dydx, stride, L, 1.0f / (2.0f * bound), sigmas, dirs, M_dev, M, term, dterm_ddirs,
+        density_act ? beta : 0.0f);
     NGP_CHECK_LAUNCH("orientation_term");
     return NGP_OK;
 }

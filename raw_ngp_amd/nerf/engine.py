@@ -97,8 +97,8 @@ class FusedTrainer:
         from .._lib import field_activations, _default_act
         act = field_activations(opt)
         self.act = None if _default_act(act) else act
-        assert self.act is None or not float(getattr(opt, "lambda_orientation", 0.0)) > 0, \
-            "fused step: the non-default activations are built without the orientation term (its normal uses trunc_exp's derivative)"
+        assert self.act is None or act[3] == 0 or not float(getattr(opt, "lambda_orientation", 0.0)) > 0, \
+            "fused step: softplus hidden layers are built without the orientation term (its density-gradient pass is ReLU)"
         self.rank, self.world_size = parallel.rank(), parallel.world_size()
         # data-parallel step (separate Adam pass, gradient collectives); `dp_rehearsal` runs it on one rank as well
         self.dp = self.world_size > 1 or (bool(getattr(opt, "dp_rehearsal", False)) and parallel.is_dist())
@@ -500,7 +500,7 @@ class FusedTrainer:
                 eb.slab_window(self.denc, cap, self.L, self.level_w, cnt, cap, backward=True,
                                scale_only=not self.baa and not self.rfield)
             eb.orientation_term(self.denc, self.dydx, cap, self.L, m.bound, self.sigma, ar.dirs, cnt, cap, self.orient_term,
-                                dterm_ddirs=self.orient_ddirs if self.pose else None)
+                                dterm_ddirs=self.orient_ddirs if self.pose else None, act=self.act)
 
         def mlp_backward():
             if self.rfield:         # one call: both view kernels, the density kernel, the weight-gradient reduction

@@ -485,17 +485,20 @@ def test_fused_step_with_the_hdr_loss_matches_the_per_op_path(lib, loss_weight, 
     assert rel(eng.w_grad, ref_w) < 5e-3, rel(eng.w_grad, ref_w)
 
 
+@pytest.mark.parametrize("acts", [{}, dict(density_activation="softplus", beta=2.0, color_activation="sigmoid")],
+                         ids=["", "softplus-density"])
 @pytest.mark.parametrize("rfield", [False, True], ids=["plain", "light-conditioned"])
-def test_orientation_term_of_a_train_step_matches_autograd(lib, rfield):
+def test_orientation_term_of_a_train_step_matches_autograd(lib, rfield, acts):
     """The per-sample term a train_step leaves behind (graphs, march ahead on the side stream) against torch autograd through
-    the model at the same samples -- learning rate 0, so the weights are the ones the step saw; both fields."""
+    the model at the same samples -- learning rate 0, so the weights are the ones the step saw; both fields; also with a softplus
+    density (ngp_x_orientation_term_act) and sigmoid colour."""
     from raw_ngp_amd.nerf import pose as P
     from raw_ngp_amd.nerf.engine import FusedTrainer
     from raw_ngp_amd.nerf.network import NeRFNetwork
     from raw_ngp_amd.nerf.options import Options
     from raw_ngp_amd.nerf.scene import SyntheticDataset
     torch.manual_seed(0)
-    opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True, lambda_orientation=1e-2, rfield=rfield, lr=0.0)
+    opt = Options(bound=1.0, num_rays=1024, iters=200, fused_mlp=True, lambda_orientation=1e-2, rfield=rfield, lr=0.0, **acts)
     data = SyntheticDataset(opt, torch.device("cuda"), "train", n_views=6, H=64, W=64)
     if rfield:
         data.ldirs = torch.from_numpy(P.synthetic_light_dirs(6)).cuda()

@@ -125,8 +125,8 @@ def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield, orien
     / _backward_act, ngp_x_mlp_forward_act / _backward_act with d dirs, inside the fused step; torch's own sigmoid / softplus
     on the per-op side)."""
     from raw_ngp_amd.nerf import pose as Pm
-    if acts and (orient or pose_opt != "barf"):
-        pytest.skip("the non-default activations of the fused step: without the orientation term (one window kind is enough)")
+    if acts and pose_opt != "barf":
+        pytest.skip("the non-default activations of the fused step: one window kind is enough")
     P, data, ft = _fused_setup(pose_opt, iters=300, views=6, noise=0.05, rays=1024, rfield=rfield, lambda_orientation=orient,
                                **acts)
     assert (ft.act is not None) == bool(acts)
@@ -214,8 +214,11 @@ def test_fused_pose_step_gradients_match_the_per_op_path(pose_opt, rfield, orien
     assert rel < 0.1, rel                                 # f16 MFMA deltas through six layers vs fp32 autograd
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     assert cos > 0.99, cos
+    # (a layer whose gradient has all but vanished -- the view MLP's, 1e-3 of the others', after 40 steps of softplus density +
+    # orientation term -- is compared on the scale of the largest layer: what is left of it is f16 underflow)
+    floor = 1e-2 * max(float(gr.norm()) for gr in grads[1:])
     for k, (gf, gr) in enumerate(zip(w_grad_fused, grads[1:])):
-        rel = float((gf - gr).norm() / (gr.norm() + 1e-30))
+        rel = float((gf - gr).norm() / max(float(gr.norm()), floor))
         assert rel < 8e-2, (k, rel)
 
 
