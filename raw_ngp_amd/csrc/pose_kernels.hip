@@ -133,7 +133,28 @@ __global__ __launch_bounds__(256) void ray_gradients_kernel(const float *__restr
         for (uint32_t k = lane; k < take; k += kWave) {
             const size_t i = (size_t)off + k, ic = at + k;
             float g[3] = {0, 0, 0};
-            for (uint32_t l = 0; l < L; l++) {
+            // eight levels' loads leave before the first multiply-add waits (32 requests in flight per lane -- all sixteen levels at once measure slower, 46 against 43 us; taken level by level
+            // the wave paid a memory round trip per level: 70 us for 262 k samples); the additions keep their order
+            uint32_t l0 = 0;
+            for (; l0 + 8u <= L; l0 += 8u) {
+                float2 ge[8], jj[8][3];
+#pragma unroll
+                for (uint32_t u = 0; u < 8u; u++) {
+                    ge[u] = reinterpret_cast<const float2 *>(denc)[(size_t)(l0 + u) * stride + ic];
+                    const float2 *j = reinterpret_cast<const float2 *>(dydx) + ((size_t)(l0 + u) * stride + i) * 3;
+#pragma unroll
+                    for (int d = 0; d < 3; d++) jj[u][d] = j[d];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 8u; u++) {
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        g[d] = fmaf(ge[u].x, jj[u][d].x, g[d]);
+                        g[d] = fmaf(ge[u].y, jj[u][d].y, g[d]);
+                    }
+                }
+            }
+            for (uint32_t l = l0; l < L; l++) {
                 const float2 ge = reinterpret_cast<const float2 *>(denc)[(size_t)l * stride + ic];
                 const float2 *j = reinterpret_cast<const float2 *>(dydx) + ((size_t)l * stride + i) * 3;
 #pragma unroll
